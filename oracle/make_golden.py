@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REFERENCE.
+
+Run in the build container (needs /root/reference):
+
+    python -m oracle.make_golden
+
+It imports the reference PyTorch TAPIR (tapnet/torch/tapir_model.py) through
+``oracle/ref_import.py``, loads the seeded synthetic weights of
+``tapnet_amd.synthetic.make_weights`` into it, runs it on seeded synthetic
+clips and stores the stage-boundary tensors.  The fixtures hold inputs and
+reference outputs only; weights are regenerated from the seed by the tests.
+
+The reference has no golden vectors of its own; these
+fixtures are what pins ``oracle/tapir_oracle.py`` (and through it the HIP
+kernels) to the reference's behaviour.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.ref_import import import_reference  # noqa: E402
+from tapnet_amd import synthetic  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                          'tests', 'golden')
+
+# name -> dict(kwargs for the reference ctor, clip, queries)
+CASES = {
+    # TAPIR checkpoint kwargs (configs/tapir_config.py:76-81)
+    'tapir': dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0,
+                  causal=False, res=64, video=64, T=5, Q=10, wseed=11),
+    # BootsTAPIR kwargs (configs/tapir_bootstrap_config.py:78-82)
+    'bootstapir': dict(pyramid_level=1, extra_convs=True, softmax_temperature=10.0,
+                       causal=False, res=64, video=64, T=5, Q=10, wseed=12),
+    # causal / online (configs/causal_tapir_config.py:78-79, live_demo.py:51-77)
+    'causal': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
+                   causal=True, res=64, video=64, T=4, Q=6, wseed=13),
+    # two refinement resolutions -> 8 iterations, level averaging (:1142-1152)
+    'multires': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
+                     causal=False, res=64, video=128, T=3, Q=6, wseed=14),
+}
+
+
+def build_reference(tm, cfg, weights):
+  model = tm.TAPIR(pyramid_level=cfg['pyramid_level'], extra_convs=cfg['extra_convs'],
+                   softmax_temperature=cfg['softmax_temperature'],
+                   use_casual_conv=cfg['causal'],
+                   initial_resolution=(cfg['res'], cfg['res']),
+                   feature_extractor_chunk_size=0).eval()
+  sd = {k: torch.from_numpy(v) for k, v in weights.items()}
+  missing, unexpected = model.load_state_dict(sd, strict=True)
+  assert not missing and not unexpected
+  return model
+
+
+def np_(x):
+  return x.detach().cpu().numpy().astype(np.float32)
+
+
+def make_case(tm, name, cfg):
+  weights = synthetic.make_weights(cfg['wseed'], cfg['pyramid_level'], cfg['extra_convs'])
+  model = build_reference(tm, cfg, weights)
+  video = synthetic.make_video(cfg['wseed'] + 100, cfg['T'], cfg['video'], cfg['video'])
+  qpts = synthetic.make_queries(cfg['wseed'] + 200, cfg['Q'], cfg['T'], cfg['video'],
+                                cfg['video'])
+  # put two queries close to the border so the 7x7 patches leave the grid
+  qpts[0, 0, 1:] = [1.25, cfg['video'] - 0.75]
+  qpts[0, 1, 1:] = [cfg['video'] - 2.5, 0.5]
+  out = dict(video=video, query_points=qpts)
+  tv, tq = torch.from_numpy(video), torch.from_numpy(qpts)
+  with torch.no_grad():
+    fg = model.get_feature_grids(tv, False)
+    # consecutive levels at the same resolution share one array in the reference
+    # (tapir_model.py:666,722); store each distinct level once + an index map.
+    level_src, prev = [], None
+    for i, res in enumerate(fg.resolutions):
+      if prev is not None and tuple(res) == tuple(prev):
+        level_src.append(level_src[-1])
+      else:
+        level_src.append(i)
+        out[f'lowres_{i}'] = np_(fg.lowres[i])
+        out[f'hires_{i}'] = np_(fg.hires[i])
+      prev = res
+    out['level_src'] = np.array(level_src, np.int32)
+    out['resolutions'] = np.array([tuple(r) for r in fg.resolutions], np.int32)
+    qf = model.get_query_features(tv, False, tq, fg)
+    for i in sorted(set(level_src)):
+      out[f'qlowres_{i}'] = np_(qf.lowres[i])
+      out[f'qhires_{i}'] = np_(qf.hires[i])
+    if not cfg['causal']:
+      # stage: cost volume -> tracks (R2)
+      im_shp = fg.lowres[0].shape[0:2] + (cfg['res'], cfg['res'], 3)
+      qp_init = tq * torch.tensor([1.0, cfg['res'] / cfg['video'], cfg['res'] / cfg['video']])
+      pts, occ, expd = model.tracks_from_cost_volume(qf.lowres[0], fg.lowres[0],
+                                                     qp_init, im_shp=im_shp)
+      out['cv_points'], out['cv_occ'], out['cv_expd'] = np_(pts), np_(occ), np_(expd)
+      out['cost_volume'] = np_(torch.einsum('bnc,bthwc->tbnhw', qf.lowres[0], fg.lowres[0]))
+      # stage: first refine_pips (R3+R4)
+      queries = [qf.hires[1], qf.lowres[1]]
+      pyramid = [fg.hires[1], fg.lowres[1]]
+      for _ in range(cfg['pyramid_level']):
+        queries.append(queries[-1])
+        pyramid.append(torch.nn.functional.avg_pool3d(
+            pyramid[-1], kernel_size=(2, 2, 1), stride=(2, 2, 1), padding=0))
+      r = model.refine_pips(queries, None, pyramid, pts, occ, expd,
+                            orig_hw=(cfg['res'], cfg['res']), last_iter=None,
+                            resize_hw=fg.resolutions[1])
+      out['it1_points'], out['it1_occ'], out['it1_expd'], out['it1_feats'] = (
+          np_(r[0]), np_(r[1]), np_(r[2]), np_(r[3]))
+      # full call
+      full = model(tv, tq, query_chunk_size=4)
+      out['tracks'], out['occlusion'], out['expected_dist'] = (
+          np_(full['tracks']), np_(full['occlusion']), np_(full['expected_dist']))
+      for i, (a, b, c) in enumerate(zip(full['unrefined_tracks'],
+                                        full['unrefined_occlusion'],
+                                        full['unrefined_expected_dist'])):
+        out[f'unrefined_tracks_{i}'] = np_(a)
+        out[f'unrefined_occlusion_{i}'] = np_(b)
+        out[f'unrefined_expected_dist_{i}'] = np_(c)
+    else:
+      # online: frame-by-frame with causal state (live_demo.py:51-77,
+      # pytorch_live_demo.py:44-85); query features come from the whole clip
+      # here so every query is defined from frame 0.
+      state = model.construct_initial_causal_state(cfg['Q'], len(fg.lowres) - 1)
+      state = [{k: v.clone() for k, v in d.items()} for d in state]
+      tr, oc, ex = [], [], []
+      for t in range(cfg['T']):
+        fg_t = model.get_feature_grids(tv[:, t:t + 1], False)
+        traj = model.estimate_trajectories(
+            (cfg['video'], cfg['video']), False, fg_t, qf, None,
+            query_chunk_size=64, causal_context=state, get_causal_context=True)
+        state = traj['causal_context']
+        tr.append(np_(traj['tracks'][-1]))
+        oc.append(np_(traj['occlusion'][-1]))
+        ex.append(np_(traj['expected_dist'][-1]))
+      out['tracks'] = np.concatenate(tr, axis=2)
+      out['occlusion'] = np.concatenate(oc, axis=2)
+      out['expected_dist'] = np.concatenate(ex, axis=2)
+      out['state_last_block_0_causal_1'] = np_(state[-1]['block_0_causal_1'])
+      out['state_last_block_11_causal_2'] = np_(state[-1]['block_11_causal_2'])
+  path = os.path.join(GOLDEN_DIR, name + '.npz')
+  np.savez_compressed(path, **out)
+  print(name, {k: v.shape for k, v in out.items() if k in ('video', 'tracks')},
+        f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
+def make_backbone_case(tm):
+  """R7 fixture: reference feature grids for a tiny clip (both kwarg sets)."""
+  out = {}
+  video = synthetic.make_video(321, 2, 64, 64)
+  out['video'] = video
+  for tag, extra in (('tapir', False), ('boots', True)):
+    cfg = dict(pyramid_level=1, extra_convs=extra, softmax_temperature=20.0,
+               causal=False, res=64)
+    weights = synthetic.make_weights(21, 1, extra)
+    model = build_reference(tm, cfg, weights)
+    with torch.no_grad():
+      fg = model.get_feature_grids(torch.from_numpy(video), False)
+    out[f'{tag}_lowres'] = np_(fg.lowres[0])
+    out[f'{tag}_hires'] = np_(fg.hires[0])
+  path = os.path.join(GOLDEN_DIR, 'backbone.npz')
+  np.savez_compressed(path, **out)
+  print('backbone', f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
+def main():
+  os.makedirs(GOLDEN_DIR, exist_ok=True)
+  torch.manual_seed(0)
+  torch.set_num_threads(os.cpu_count() or 1)
+  tm, _, _ = import_reference()
+  only = sys.argv[1:]
+  for name, cfg in CASES.items():
+    if only and name not in only:
+      continue
+    make_case(tm, name, cfg)
+  if not only or 'backbone' in only:
+    make_backbone_case(tm)
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,141 @@
+"""Seeded synthetic weights / clips / queries for tests, smoke and bench.
+
+There is no network for checkpoints or datasets, so everything that needs
+"a TAPIR" uses weights generated here: a flat dict keyed by the reference's
+torch ``state_dict`` names (tapnet/torch/tapir_model.py:115-137, nets.py) with
+deterministic numpy values.  ``oracle/make_golden.py`` loads exactly these
+weights into the *reference* model to produce the committed fixtures, so the
+fixtures only need to store a seed, not 100 MB of parameters.
+
+``peaky=True`` shapes the cost-volume head so that the soft-argmax heat maps
+have one dominant peak (hid1 channel 0 passes the cosine similarity through,
+hid2 amplifies it).  With generic random weights the heat maps are nearly flat
+and the reference disagrees *with itself* by >10 px under fp32 re-association
+("hard parts"); peaky heads make track-level parity
+meaningful, like a trained checkpoint would.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def _normal(rng, shape, std):
+  return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+def make_weights(seed: int = 0, pyramid_level: int = 1, extra_convs: bool = True,
+                 peaky: bool = True, num_mixer_blocks: int = 12,
+                 backbone: bool = True) -> Dict[str, np.ndarray]:
+  """Returns {state_dict name: float32 array} for the given TAPIR kwargs."""
+  rng = np.random.default_rng(seed)
+  w: Dict[str, np.ndarray] = {}
+
+  def conv(name, co, ci, k, bias=False, gain=1.0):
+    w[name + '.weight'] = _normal(rng, (co, ci, k, k), gain / np.sqrt(ci * k * k))
+    if bias:
+      w[name + '.bias'] = _normal(rng, (co,), 0.02)
+
+  def linear(name, co, ci, gain=1.0):
+    w[name + '.weight'] = _normal(rng, (co, ci), gain / np.sqrt(ci))
+    w[name + '.bias'] = _normal(rng, (co,), 0.02)
+
+  def norm(name, c, bias=True):
+    w[name + '.weight'] = (1.0 + _normal(rng, (c,), 0.1)).astype(np.float32)
+    if bias:
+      w[name + '.bias'] = _normal(rng, (c,), 0.05)
+
+  if backbone:
+    r = 'resnet_torch.'
+    conv(r + 'initial_conv', 64, 3, 7, gain=1.4)
+    chans = (64, 128, 256, 256)
+    cin = 64
+    for g, cout in enumerate(chans):
+      for b in range(2):
+        p = f'{r}block_groups.{g}.blocks.{b}.'
+        ci = cin if b == 0 else cout
+        if b == 0:
+          conv(p + 'proj_conv', cout, ci, 1)
+        norm(p + 'bn_0', ci)
+        conv(p + 'conv_0', cout, ci, 3, gain=1.4)
+        conv(p + 'conv_1', cout, cout, 3, gain=1.4)
+        norm(p + 'bn_1', cout)
+      cin = cout
+    if extra_convs:
+      for n in range(5):
+        p = f'extra_convs.blocks.{n}.'
+        norm(p + 'layer_norm', 256)
+        conv(p + 'conv', 1024, 256, 3, bias=True, gain=1.4)
+        conv(p + 'conv_1', 256, 1024, 3, bias=True, gain=0.3)
+
+  c = 'torch_cost_volume_track_mods.'
+  conv(c + 'hid1', 16, 1, 3, bias=True)
+  conv(c + 'hid2', 1, 16, 3, bias=True)
+  conv(c + 'hid3', 32, 16, 3, bias=True)
+  linear(c + 'hid4', 16, 32)
+  linear(c + 'occ_out', 2, 16)
+  if peaky:
+    w[c + 'hid1.weight'][0] = 0.0
+    w[c + 'hid1.weight'][0, 0, 1, 1] = 1.0
+    w[c + 'hid1.bias'][0] = 0.0
+    w[c + 'hid2.weight'] *= np.float32(0.1)
+    w[c + 'hid2.weight'][0, 0] = 0.0
+    w[c + 'hid2.weight'][0, 0, 1, 1] = 3.0
+
+  m = 'torch_pips_mixer.'
+  dim = 4 + 128 + 256
+  in_dim = dim + (pyramid_level + 2) * 49
+  linear(m + 'linear', 512, in_dim)
+  norm(m + 'layer_norm', 512, bias=False)
+  linear(m + 'linear_1', dim, 512, gain=0.3)
+  for i in range(num_mixer_blocks):
+    p = f'{m}blocks.{i}.'
+    norm(p + 'layer_norm', 512, bias=False)
+    w[p + 'mlp1_up.weight'] = _normal(rng, (2048, 1, 3), 0.5)
+    w[p + 'mlp1_up.bias'] = _normal(rng, (2048,), 0.05)
+    w[p + 'mlp1_up_1.weight'] = _normal(rng, (2048, 1, 3), 0.3)
+    w[p + 'mlp1_up_1.bias'] = _normal(rng, (2048,), 0.05)
+    norm(p + 'layer_norm_1', 512, bias=False)
+    linear(p + 'conv_channels_mixer.mlp2_up', 2048, 512)
+    linear(p + 'conv_channels_mixer.mlp2_down', 512, 2048, gain=0.5)
+  return w
+
+
+def make_video(seed: int, num_frames: int, height: int, width: int,
+               batch: int = 1, texture: bool = True) -> np.ndarray:
+  """Synthetic clip [B,T,H,W,3] float32 in [-1,1].
+
+  ``texture=True``: a low-pass random texture translated along a smooth seeded
+  path (peaky cost volumes, physically plausible tracks); otherwise U[-1,1).
+  """
+  rng = np.random.default_rng(seed)
+  if not texture:
+    return rng.uniform(-1, 1, (batch, num_frames, height, width, 3)).astype(np.float32)
+  out = np.zeros((batch, num_frames, height, width, 3), np.float32)
+  pad = 32
+  for b in range(batch):
+    big = rng.standard_normal((height + 2 * pad, width + 2 * pad, 3)).astype(np.float32)
+    # separable box blur x3 ~ gaussian, keeps structure at the stride-8 feature scale
+    for _ in range(3):
+      for ax in (0, 1):
+        big = (np.roll(big, 1, ax) + big + np.roll(big, -1, ax)
+               + np.roll(big, 2, ax) + np.roll(big, -2, ax)) / 5.0
+    big = big / (np.abs(big).max() + 1e-6)
+    ph = rng.uniform(0, 2 * np.pi, 2)
+    for t in range(num_frames):
+      dy = int(round(pad * 0.6 * np.sin(ph[0] + 0.35 * t)))
+      dx = int(round(pad * 0.6 * np.cos(ph[1] + 0.27 * t)))
+      out[b, t] = big[pad + dy: pad + dy + height, pad + dx: pad + dx + width]
+  return out
+
+
+def make_queries(seed: int, num_queries: int, num_frames: int, height: int,
+                 width: int, batch: int = 1) -> np.ndarray:
+  """query_points [B,Q,3] float32 (t,y,x): t integer-valued, y/x uniform in the frame
+  (cf. colabs/tapir_demo.ipynb:219-227)."""
+  rng = np.random.default_rng(seed)
+  t = rng.integers(0, num_frames, (batch, num_queries, 1)).astype(np.float32)
+  y = rng.uniform(0, height, (batch, num_queries, 1)).astype(np.float32)
+  x = rng.uniform(0, width, (batch, num_queries, 1)).astype(np.float32)
+  return np.concatenate([t, y, x], axis=-1)
