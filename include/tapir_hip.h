@@ -1,0 +1,168 @@
+/* libtapir_hip -- C ABI of the MI355X (gfx950) TAPIR inference hot path.
+ *
+ * The reference (google-deepmind/tapnet) has no FFI layer: its boundary for
+ * this path is the Python API of tapnet/models/tapir_model.py.  Every entry
+ * point below replaces one reference function (cited per declaration); the
+ * Python mirror of that API lives in tapnet_amd/tapir_model.py and only
+ * marshals pointers through ctypes.
+ *
+ * Conventions
+ *  - return 0 (TAPIR_OK) or a negative error code; never throws; the message
+ *    for the last error of a context is available from tapir_last_error().
+ *  - every tensor argument is a DEVICE pointer owned by the caller (torch),
+ *    dense row-major, float32 unless stated; the library owns only the
+ *    context (weights + workspaces).  tapir_set_weight takes HOST memory.
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream).  No host synchronisation inside.
+ *    Workspaces grow on demand (hipMalloc): call tapir_reserve() first if the
+ *    call is going to be captured into a hipGraph.
+ *  - one context per device; calls on one context are not thread-safe.
+ *  - layouts follow the reference: feature grids [B,T,h,w,C] channels-last,
+ *    query points (t,y,x), tracks (x,y), tokens ordered (b, q, t).
+ */
+#ifndef TAPIR_HIP_H_
+#define TAPIR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAPIR_OK 0
+#define TAPIR_ERR_INVALID (-1)      /* bad argument / shape                           */
+#define TAPIR_ERR_HIP (-2)          /* a HIP runtime call failed                      */
+#define TAPIR_ERR_UNSUPPORTED (-3)  /* shape outside what the kernels are built for   */
+#define TAPIR_ERR_WEIGHTS (-4)      /* weights missing / wrong shape / not finalized  */
+
+#define TAPIR_F32 0   /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32): parity build       */
+#define TAPIR_BF16 1  /* bf16 operands, f32 accumulate (v_mfma_f32_16x16x32_bf16)    */
+
+#define TAPIR_MAX_LEVELS 8   /* 1 + number of refinement resolutions */
+
+typedef struct tapir_ctx tapir_ctx;
+
+/* Mirrors the constructor kwargs of TAPIR.__init__ that matter after the
+ * backbone (tapnet/models/tapir_model.py:299-317). */
+typedef struct tapir_cfg {
+  int pyramid_level;          /* 0 (TAPIR ckpt) or 1 (BootsTAPIR / causal)    */
+  int num_pips_iter;          /* default 4                                     */
+  int num_mixer_blocks;       /* default 12                                    */
+  int use_causal_conv;        /* online model                                  */
+  float softmax_temperature;  /* 20.0 default, 10.0 BootsTAPIR                 */
+  int initial_h, initial_w;   /* initial_resolution, default 256 x 256         */
+  int dtype;                  /* TAPIR_F32 or TAPIR_BF16                        */
+} tapir_cfg;
+
+int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device);
+void tapir_destroy(tapir_ctx* ctx);
+const char* tapir_last_error(const tapir_ctx* ctx);
+const char* tapir_version(void);
+
+/* Weights.  `name` is the reference's torch state_dict key
+ * (tapnet/torch/tapir_model.py:115-137, e.g.
+ * "torch_pips_mixer.blocks.3.conv_channels_mixer.mlp2_up.weight"); `data` is
+ * float32 HOST memory in the state_dict's own layout.  Backbone keys
+ * (resnet_torch.*, extra_convs.*) are accepted and ignored: the backbone runs
+ * in PyTorch-ROCm.  tapir_finalize_weights uploads / re-lays-out everything
+ * and fails with TAPIR_ERR_WEIGHTS if a tensor the hot path needs is missing. */
+int tapir_set_weight(tapir_ctx* ctx, const char* name, const float* data,
+                     const int64_t* shape, int ndim);
+int tapir_finalize_weights(tapir_ctx* ctx);
+
+/* Pre-sizes every workspace for B clips x Q queries x T frames (largest grid
+ * h x w of the low-resolution pyramid), so later calls allocate nothing. */
+int tapir_reserve(tapir_ctx* ctx, int B, int Q, int T, int max_lowres_h, int max_lowres_w);
+
+/* einsum('bnc,bthwc->tbnhw') of TAPIR.tracks_from_cost_volume
+ * (tapir_model.py:433) -- the north_star's "build_cost_volume".
+ * qfeat [B,Q,C], grid [B,T,h,w,C] -> volume [B,Q,T,h,w] (the reference's
+ * 'tbnhw' is a permuted view of this). */
+int tapir_build_cost_volume(tapir_ctx* ctx, const float* qfeat, const float* grid,
+                            int B, int Q, int T, int h, int w, int C,
+                            float* volume, void* stream);
+
+/* TAPIR.tracks_from_cost_volume (tapir_model.py:399-471) incl.
+ * model_utils.heatmaps_to_points / soft_argmax_heatmap (model_utils.py:209-314).
+ * query_points: NULL or [B,Q,3] (t,y,x) in initial_resolution coordinates.
+ * points [B,Q,T,2] (x,y) in initial_resolution pixels; occlusion / expected_dist
+ * [B,Q,T] logits. */
+int tapir_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, const float* grid,
+                                  const float* query_points, int B, int Q, int T,
+                                  int h, int w,
+                                  float* points, float* occlusion, float* expected_dist,
+                                  void* stream);
+
+/* One grid of TAPIR.get_query_features (tapir_model.py:781-849;
+ * model_utils.interp mode='nearest' :177-206): trilinear sample of
+ * grid [B,T,h,w,C] at query_points [B,Q,3] (t,y,x) given in video pixels
+ * (video_h x video_w) -> out [B,Q,C]. */
+int tapir_get_query_features(tapir_ctx* ctx, const float* grid, const float* query_points,
+                             int B, int Q, int T, int h, int w, int C,
+                             int video_h, int video_w, float* out, void* stream);
+
+/* PIPSMLPMixer (tapir_model.py:127-156): x [N,T,Cin] -> out [N,T,388], with
+ * Cin = 388 + 49*(2+pyramid_level).  Causal state (use_causal_conv only), all
+ * optional: ctx1_* [num_blocks,N,2,512], ctx2_* [num_blocks,N,2,2048]
+ * (= the reference's block_i_causal_1 / _2 entries, :48-73); *_in NULL = zeros,
+ * *_out NULL = not requested.  in and out must not alias. */
+int tapir_pips_mixer(tapir_ctx* ctx, const float* x, int N, int T, float* out,
+                     const float* ctx1_in, const float* ctx2_in,
+                     float* ctx1_out, float* ctx2_out, void* stream);
+
+typedef struct tapir_pyramid {
+  int n_levels;                    /* 2 + pyramid_level                              */
+  const float* query[3];           /* [B,Q,C_l]: hires(128), lowres(256), lowres(256) */
+  const float* grid[3];            /* [B,T,h_l,w_l,C_l]                               */
+  int h[3], w[3], C[3];
+} tapir_pyramid;
+
+/* TAPIR.refine_pips (tapir_model.py:473-624), one refinement iteration.
+ * pos [B,Q,T,2] (x,y) in orig (= initial_resolution) pixels, occ / expd [B,Q,T];
+ * last_iter NULL (first iteration of a level) or [B,Q,T,384].
+ * Outputs: pos_out, occ_out, expd_out, feats_out [B,Q,T,384] (may alias the
+ * inputs).  Causal state as in tapir_pips_mixer with N = B*Q. */
+int tapir_refine_pips(tapir_ctx* ctx, const tapir_pyramid* pyr, int B, int Q, int T,
+                      const float* pos, const float* occ, const float* expd,
+                      const float* last_iter, int orig_h, int orig_w,
+                      int resized_h, int resized_w,
+                      float* pos_out, float* occ_out, float* expd_out, float* feats_out,
+                      const float* ctx1_in, const float* ctx2_in,
+                      float* ctx1_out, float* ctx2_out, void* stream);
+
+typedef struct tapir_traj_args {
+  int B, Q, T;
+  int n_levels;                               /* len(feature_grids.lowres)                 */
+  const float* lowres[TAPIR_MAX_LEVELS];      /* [B,T,h_i,w_i,256]  (L2-normalised)        */
+  const float* hires[TAPIR_MAX_LEVELS];       /* [B,T,2h_i,2w_i,128]                       */
+  int lowres_h[TAPIR_MAX_LEVELS], lowres_w[TAPIR_MAX_LEVELS];
+  int hires_h[TAPIR_MAX_LEVELS], hires_w[TAPIR_MAX_LEVELS];
+  int res_h[TAPIR_MAX_LEVELS], res_w[TAPIR_MAX_LEVELS];   /* feature_grids.resolutions      */
+  const float* q_lowres[TAPIR_MAX_LEVELS];    /* [B,Q,256]                                 */
+  const float* q_hires[TAPIR_MAX_LEVELS];     /* [B,Q,128]                                 */
+  const float* query_points;                  /* NULL or [B,Q,3] (t,y,x) in video pixels   */
+  int video_h, video_w;
+  /* causal state, all optional: [num_iters, num_blocks, B*Q, 2, 512 | 2048] */
+  const float* ctx1_in; const float* ctx2_in;
+  float* ctx1_out; float* ctx2_out;
+  /* outputs: one slice per iteration (0 = cost-volume initialisation), video pixels */
+  float* tracks;          /* [num_iters+1, B, Q, T, 2] */
+  float* occlusion;       /* [num_iters+1, B, Q, T]    */
+  float* expected_dist;   /* [num_iters+1, B, Q, T]    */
+} tapir_traj_args;
+
+/* TAPIR.estimate_trajectories (tapir_model.py:858-1066): cost-volume
+ * initialisation on level 0, then num_pips_iter refinement iterations on each
+ * further level, all enqueued on `stream`.  The query permutation / chunking of
+ * the reference (:938-952) does not change per-query results and is not
+ * reproduced. */
+int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, void* stream);
+
+/* RCCL all-gather of frame-sharded feature grids over xGMI is
+ * done by the host layer with torch.distributed (backend "nccl" == RCCL); the
+ * library itself has no collective. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAPIR_HIP_H_ */

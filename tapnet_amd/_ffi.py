@@ -1,0 +1,115 @@
+"""ctypes binding of include/tapir_hip.h (the C ABI of libtapir_hip.so).
+
+north_star asks for a "thin C-ABI cffi layer"; cffi is not installed in this
+image, ctypes (stdlib) binds the same C ABI.  The product path loads ONLY the
+in-tree gfx950 library ``tapnet_amd/csrc/libtapir_hip.so`` and raises if it is
+missing -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+TAPIR_OK = 0
+TAPIR_ERR_INVALID = -1
+TAPIR_ERR_HIP = -2
+TAPIR_ERR_UNSUPPORTED = -3
+TAPIR_ERR_WEIGHTS = -4
+TAPIR_F32 = 0
+TAPIR_BF16 = 1
+TAPIR_MAX_LEVELS = 8
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libtapir_hip.so')
+
+c_float_p = POINTER(c_float)
+
+
+class TapirCfg(ctypes.Structure):
+  _fields_ = [('pyramid_level', c_int), ('num_pips_iter', c_int), ('num_mixer_blocks', c_int),
+              ('use_causal_conv', c_int), ('softmax_temperature', c_float),
+              ('initial_h', c_int), ('initial_w', c_int), ('dtype', c_int)]
+
+
+class TapirPyramid(ctypes.Structure):
+  _fields_ = [('n_levels', c_int), ('query', c_void_p * 3), ('grid', c_void_p * 3),
+              ('h', c_int * 3), ('w', c_int * 3), ('C', c_int * 3)]
+
+
+class TapirTrajArgs(ctypes.Structure):
+  _L = TAPIR_MAX_LEVELS
+  _fields_ = [('B', c_int), ('Q', c_int), ('T', c_int), ('n_levels', c_int),
+              ('lowres', c_void_p * _L), ('hires', c_void_p * _L),
+              ('lowres_h', c_int * _L), ('lowres_w', c_int * _L),
+              ('hires_h', c_int * _L), ('hires_w', c_int * _L),
+              ('res_h', c_int * _L), ('res_w', c_int * _L),
+              ('q_lowres', c_void_p * _L), ('q_hires', c_void_p * _L),
+              ('query_points', c_void_p), ('video_h', c_int), ('video_w', c_int),
+              ('ctx1_in', c_void_p), ('ctx2_in', c_void_p),
+              ('ctx1_out', c_void_p), ('ctx2_out', c_void_p),
+              ('tracks', c_void_p), ('occlusion', c_void_p), ('expected_dist', c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/tapir_hip.h declares
+PROTOTYPES = {
+    'tapir_create': (c_int, [POINTER(c_void_p), POINTER(TapirCfg), c_int]),
+    'tapir_destroy': (None, [c_void_p]),
+    'tapir_last_error': (c_char_p, [c_void_p]),
+    'tapir_version': (c_char_p, []),
+    'tapir_set_weight': (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    'tapir_finalize_weights': (c_int, [c_void_p]),
+    'tapir_reserve': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    'tapir_build_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_void_p, c_void_p]),
+    'tapir_tracks_from_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                              c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p]),
+    'tapir_get_query_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'tapir_pips_mixer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    'tapir_refine_pips': (c_int, [c_void_p, POINTER(TapirPyramid), c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    'tapir_estimate_trajectories': (c_int, [c_void_p, POINTER(TapirTrajArgs), c_void_p]),
+}
+
+
+def declare_prototypes(lib: ctypes.CDLL) -> ctypes.CDLL:
+  """Attaches restype/argtypes for every exported entry point; raises if one is missing."""
+  for name, (restype, argtypes) in PROTOTYPES.items():
+    fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+    fn.restype = restype
+    fn.argtypes = argtypes
+  return lib
+
+
+_LIB = None
+
+
+def load_library() -> ctypes.CDLL:
+  """Loads the in-tree gfx950 library.  Fails loudly when it has not been built."""
+  global _LIB
+  if _LIB is None:
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError(
+          f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
+          'g.build()"` (hipcc --offload-arch=gfx950).  tapnet_amd has no CPU fallback.')
+    _LIB = declare_prototypes(ctypes.CDLL(LIB_PATH))
+  return _LIB
+
+
+class TapirError(RuntimeError):
+  pass
+
+
+def check(lib, ctx, rc: int, what: str):
+  """Maps a C-ABI return code to the exception the reference would raise."""
+  if rc == TAPIR_OK:
+    return
+  msg = lib.tapir_last_error(ctx).decode() if ctx else ''
+  text = f'{what} failed ({rc}): {msg}'
+  if rc in (TAPIR_ERR_INVALID, TAPIR_ERR_UNSUPPORTED):
+    raise ValueError(text)
+  raise TapirError(text)

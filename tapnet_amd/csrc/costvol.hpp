@@ -1,0 +1,236 @@
+// TAPIR.tracks_from_cost_volume after the einsum (tapnet/models/tapir_model.py:438-471)
+// fused per (b, query, frame) heat map; nothing wider than the 1-channel cost
+// map ever leaves the chip:
+//   Conv 1->16 3x3 SAME + ReLU :443-444     (kept in LDS, zero halo)
+//   Conv 16->1 3x3 SAME :446 -> softmax(temp * x) over (h, w) :454
+//   soft-argmax radius 5 -> (x, y) * (W/w, H/h), query-frame override :455
+//     (model_utils.soft_argmax_heatmap :209-247, heatmaps_to_points :250-314)
+//   Conv 16->32 3x3 stride 2 XLA-SAME + ReLU -> mean(h, w) -> Linear 32->16 + ReLU
+//   -> Linear 16->2 = [occlusion, expected_dist] logits :459-470
+// One 256-thread workgroup per map; cells are strided over the threads.
+#pragma once
+#include "common.hpp"
+
+namespace tapir {
+
+constexpr int CV_THREADS = 256;
+// Two instantiations, chosen by the launcher from the grid size:
+//   <1156, 4>: up to 32x32 cells (the 256x256 model), 80 KiB LDS -> 2 workgroups / CU
+//   <1936, 7>: up to 1600 cells / (h+2)(w+2) <= 1936 (e.g. 40x40), 132 KiB LDS
+constexpr int CV_SMALL_PAD = 1156, CV_SMALL_PPT = 4;
+constexpr int CV_LARGE_PAD = 1936, CV_LARGE_PPT = 7;
+
+struct CvHeadWeights {
+  const float* w1;   // [16][9]
+  const float* b1;   // [16]
+  const float* w2;   // [16][9]
+  const float* b2;   // [1]
+  const float* w3;   // [(ci*9+tap)][32]   re-laid-out from [32,16,3,3]
+  const float* b3;   // [32]
+  const float* w4;   // [16][32]
+  const float* b4;   // [16]
+  const float* w5;   // [2][16]
+  const float* b5;   // [2]
+};
+
+struct CvHeadArgs {
+  const float* cv;        // [maps, h*w] cost volume, map index = (b*Q + q)*T + t
+  CvHeadWeights wt;
+  const float* qpts;      // [B*Q, 3] (t, y, x) in initial_resolution coordinates, or null
+  float* points;          // [maps, 2] (x, y) in initial_resolution pixels
+  float* occ;             // [maps]
+  float* expd;            // [maps]
+  int T, h, w;
+  float temperature;
+  float img_h, img_w;     // initial_resolution
+};
+
+template <int CV_MAX_PAD, int CV_PPT>
+__global__ __launch_bounds__(CV_THREADS) void cv_heads_kernel(CvHeadArgs a) {
+  __shared__ float s_cm[CV_MAX_PAD];            // cost map with zero halo
+  __shared__ float s_h1[16 * CV_MAX_PAD];       // relu(hid1) with zero halo
+  __shared__ float s_red[8][4];
+  __shared__ int s_redi[4];
+  __shared__ float s_vec[32 + 16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const long map = blockIdx.x;
+  const int h = a.h, w = a.w, hw = h * w;
+  const int pw = w + 2, ph = h + 2, pn = pw * ph;
+  const float* cv = a.cv + map * hw;
+
+  // ---- cost map + zero halos
+  for (int i = tid; i < pn; i += CV_THREADS) {
+    const int y = i / pw - 1, x = i % pw - 1;
+    const bool in = (y >= 0) && (y < h) && (x >= 0) && (x < w);
+    s_cm[i] = in ? cv[y * w + x] : 0.f;
+    if (!in) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s_h1[c * pn + i] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- hid1 = relu(conv3x3(cost) + b)
+  for (int p = tid; p < hw; p += CV_THREADS) {
+    const int y = p / w, x = p % w;
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_cm[(y + dy) * pw + (x + dx)];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float acc = a.wt.b1[c];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc = fmaf(a.wt.w1[c * 9 + k], v[k], acc);
+      s_h1[c * pn + (y + 1) * pw + (x + 1)] = fmaxf(acc, 0.f);
+    }
+  }
+  __syncthreads();
+
+  // ---- logits = conv3x3(hid1) + b, scaled by the temperature
+  float z[CV_PPT];
+  float zmax = -3.0e38f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    z[s] = -3.0e38f;
+    if (p < hw) {
+      const int y = p / w, x = p % w;
+      float acc = a.wt.b2[0];
+      for (int c = 0; c < 16; ++c) {
+        const float* hp = s_h1 + c * pn + y * pw + x;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            acc = fmaf(a.wt.w2[c * 9 + dy * 3 + dx], hp[dy * pw + dx], acc);
+      }
+      z[s] = acc * a.temperature;
+      zmax = fmaxf(zmax, z[s]);
+    }
+  }
+  // block max
+  zmax = wave_max(zmax);
+  if (lane == 0) s_red[0][wave] = zmax;
+  __syncthreads();
+  zmax = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+  float esum = 0.f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    z[s] = (p < hw) ? fast_exp(z[s] - zmax) : 0.f;
+    esum += z[s];
+  }
+  esum = wave_sum(esum);
+  if (lane == 0) s_red[1][wave] = esum;
+  __syncthreads();
+  esum = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  // softmax values; argmax = FIRST maximum (jnp.argmax), model_utils.py:232
+  float best = -1.f;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    if (p < hw) {
+      z[s] = z[s] / esum;
+      if (z[s] > best) { best = z[s]; besti = p; }   // p increases with s: keeps the first
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(besti, off);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) { s_red[2][wave] = best; s_redi[wave] = besti; }
+  __syncthreads();
+  best = s_red[2][0]; besti = s_redi[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float ob = s_red[2][k]; const int oi = s_redi[k];
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
+  float sx = 0.f, sy = 0.f, sw = 0.f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    if (p < hw) {
+      const float cx = (float)(p % w) + 0.5f, cy = (float)(p / w) + 0.5f;
+      const float d2 = (cx - ax) * (cx - ax) + (cy - ay) * (cy - ay);
+      if (d2 < 25.0f) { sx += cx * z[s]; sy += cy * z[s]; sw += z[s]; }   // threshold 5, strict
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+  if (lane == 0) { s_red[3][wave] = sx; s_red[4][wave] = sy; s_red[5][wave] = sw; }
+
+  // ---- occlusion head: conv 16->32, 3x3, stride 2, XLA SAME (pad_lo = total/2)
+  const int oh = (h + 1) / 2, ow = (w + 1) / 2;
+  const int ply = max((oh - 1) * 2 + 3 - h, 0) / 2, plx = max((ow - 1) * 2 + 3 - w, 0) / 2;
+  float o3[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) o3[k] = 0.f;
+  for (int p = tid; p < oh * ow; p += CV_THREADS) {
+    const int oy = p / ow, ox = p % ow;
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = a.wt.b3[k];
+    for (int c = 0; c < 16; ++c) {
+      // padded coordinates: input row 2*oy + dy - ply, +1 for the halo
+      const float* hp = s_h1 + c * pn + (2 * oy - ply + 1) * pw + (2 * ox - plx + 1);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float v = hp[dy * pw + dx];
+          const float* wp = a.wt.w3 + (c * 9 + dy * 3 + dx) * 32;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) acc[k] = fmaf(wp[k], v, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) o3[k] += fmaxf(acc[k], 0.f);
+  }
+  __syncthreads();              // everyone is done reading s_h1 / s_cm
+  float* s_o3 = s_h1;           // reuse: [256][33]
+#pragma unroll
+  for (int k = 0; k < 32; ++k) s_o3[tid * 33 + k] = o3[k];
+  __syncthreads();
+  if (tid < 32) {
+    float m = 0.f;
+    for (int i = 0; i < CV_THREADS; ++i) m += s_o3[i * 33 + tid];
+    s_vec[tid] = m / (float)(oh * ow);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float acc = a.wt.b4[tid];
+    for (int k = 0; k < 32; ++k) acc = fmaf(a.wt.w4[tid * 32 + k], s_vec[k], acc);
+    s_vec[32 + tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < 2) {
+    float acc = a.wt.b5[tid];
+    for (int k = 0; k < 16; ++k) acc = fmaf(a.wt.w5[tid * 16 + k], s_vec[32 + k], acc);
+    if (tid == 0) a.occ[map] = acc; else a.expd[map] = acc;
+  }
+  if (tid == 0) {
+    const float fsx = s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3];
+    const float fsy = s_red[4][0] + s_red[4][1] + s_red[4][2] + s_red[4][3];
+    const float fsw = fmaxf(s_red[5][0] + s_red[5][1] + s_red[5][2] + s_red[5][3], 1e-12f);
+    float outx = (fsx / fsw) * a.img_w / (float)w;
+    float outy = (fsy / fsw) * a.img_h / (float)h;
+    if (a.qpts != nullptr) {
+      const long bq = map / a.T;
+      const int t = (int)(map % a.T);
+      const float* q = a.qpts + bq * 3;
+      if ((int)rintf(q[0]) == t) { outx = q[2]; outy = q[1]; }   // round-half-even like jnp.round
+    }
+    a.points[map * 2 + 0] = outx;
+    a.points[map * 2 + 1] = outy;
+  }
+}
+
+}  // namespace tapir

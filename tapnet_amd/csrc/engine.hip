@@ -1,0 +1,758 @@
+// libtapir_hip: context, weights, workspaces, stage orchestration and the C ABI
+// declared in include/tapir_hip.h.  Everything is enqueued on the caller's
+// stream; there is no host synchronisation and no CPU compute path.
+#include "../../include/tapir_hip.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "costvol.hpp"
+#include "gemm.hpp"
+#include "mixer.hpp"
+#include "pips.hpp"
+
+using namespace tapir;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct BlockW {
+  float *ln1, *w1, *b1, *w2, *b2, *ln2, *bup, *bdn;
+  void *Wup, *Wdn;   // operand type: [2048,512], [512,2048]
+};
+
+}  // namespace
+
+struct tapir_ctx {
+  tapir_cfg cfg;
+  int device = 0;
+  std::string err;
+  std::map<std::string, HostTensor> host_w;
+  bool finalized = false;
+  std::vector<void*> owned;         // device weight allocations
+
+  // cost-volume head weights (f32)
+  CvHeadWeights cvw;
+  // mixer weights
+  int in_dim = 0, k0_pad = 0;       // 388 + 49*(2+pyr), padded to the GEMM k-step
+  void* W0 = nullptr; float* b0 = nullptr;        // [512, k0_pad]
+  std::vector<BlockW> blocks;
+  float* lnF = nullptr;
+  void* Wout = nullptr; float* bout = nullptr;    // [388, 512]
+
+  // workspaces
+  DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
+  DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
+  // which caller grid each cast slot currently holds (valid within one call)
+  const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int fail(tapir_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                         \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess)                                                        \
+      return fail((c), TAPIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(tapir_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return TAPIR_OK;
+  if (b.p) HIP_TRY(c, hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  const size_t want = (bytes + 255) / 256 * 256;
+  HIP_TRY(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return TAPIR_OK;
+}
+
+size_t esize(int dtype) { return dtype == TAPIR_BF16 ? 2 : 4; }
+
+inline uint16_t host_f2bf(float f) {
+  uint32_t u; ::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// uploads a host f32 matrix [rows, cols] as operand type with row stride ld (zero padded)
+int upload_matrix(tapir_ctx* c, const float* src, int rows, int cols, int ld, void** out) {
+  const size_t es = esize(c->cfg.dtype);
+  std::vector<uint8_t> tmp((size_t)rows * ld * es, 0);
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < cols; ++k) {
+      const float v = src[(size_t)r * cols + k];
+      if (c->cfg.dtype == TAPIR_BF16) ((uint16_t*)tmp.data())[(size_t)r * ld + k] = host_f2bf(v);
+      else ((float*)tmp.data())[(size_t)r * ld + k] = v;
+    }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, tmp.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+  *out = d;
+  return TAPIR_OK;
+}
+
+int upload_f32(tapir_ctx* c, const float* src, size_t n, float** out) {
+  float* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, n * sizeof(float)));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return TAPIR_OK;
+}
+
+int get_w(tapir_ctx* c, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+  auto it = c->host_w.find(name);
+  if (it == c->host_w.end()) return fail(c, TAPIR_ERR_WEIGHTS, "missing weight: " + name);
+  if (it->second.shape != shape) return fail(c, TAPIR_ERR_WEIGHTS, "wrong shape for weight: " + name);
+  *out = &it->second;
+  return TAPIR_OK;
+}
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != TAPIR_OK) return rc_; } while (0)
+
+// ----------------------------------------------------------------------------
+// small helper kernels
+// ----------------------------------------------------------------------------
+struct InitArgs {
+  const float* qpts_video;  // [BQ,3] or null
+  float* qpts_init;         // [BQ,3] (t,y,x) scaled to initial_resolution
+  long BQ;
+  float sy, sx;             // initial / video
+};
+__global__ void scale_qpts_kernel(InitArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.BQ) return;
+  a.qpts_init[i * 3 + 0] = a.qpts_video[i * 3 + 0];
+  a.qpts_init[i * 3 + 1] = a.qpts_video[i * 3 + 1] * a.sy;
+  a.qpts_init[i * 3 + 2] = a.qpts_video[i * 3 + 2] * a.sx;
+}
+
+struct Iter0Args {
+  const float* pos; const float* occ; const float* expd;   // state after the cost-volume stage
+  float* occ0; float* expd0;
+  float* out_tracks; float* out_occ; float* out_expd;
+  long R; float vx, vy;
+};
+__global__ void iter0_kernel(Iter0Args a) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.R) return;
+  a.out_tracks[r * 2 + 0] = a.pos[r * 2 + 0] * a.vx;
+  a.out_tracks[r * 2 + 1] = a.pos[r * 2 + 1] * a.vy;
+  a.out_occ[r] = a.occ[r]; a.out_expd[r] = a.expd[r];
+  a.occ0[r] = a.occ[r]; a.expd0[r] = a.expd[r];
+}
+
+// ----------------------------------------------------------------------------
+// stage drivers (templated on the operand type)
+// ----------------------------------------------------------------------------
+template <typename TA>
+int cast_or_pool(tapir_ctx* c, const float* src, long frames, int h, int w, int C, int pool,
+                 DevBuf& dst, hipStream_t s) {
+  const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
+  TRY(ensure(c, dst, (size_t)frames * oh * ow * C * sizeof(TA)));
+  PoolArgs pa{src, dst.p, frames, h, w, C, pool};
+  const long total = frames * oh * ow * (C / 4);
+  const int nb = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL((pool_cast_kernel<TA>), dim3(nb), dim3(256), 0, s, pa);
+  return TAPIR_OK;
+}
+
+template <typename TA>
+int cost_volume_gemm(tapir_ctx* c, const void* qf, const void* grid, int Q, int T, int hw, int C,
+                     float* vol, hipStream_t s) {
+  GemmArgs g{};
+  g.A = qf; g.lda = C; g.strideA = 0;
+  g.W = grid; g.ldw = C; g.strideW = 0;
+  g.bias = nullptr; g.resid = nullptr; g.ldr = 0;
+  g.C = vol; g.ldc = (long)T * hw; g.strideC = 0;
+  g.M = Q; g.N = T * hw; g.K = C;
+  launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+  return TAPIR_OK;
+}
+
+int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long maps, int T,
+                    int h, int w, float* points, float* occ, float* expd, hipStream_t s) {
+  CvHeadArgs a{};
+  a.cv = cv; a.wt = c->cvw; a.qpts = qpts_init;
+  a.points = points; a.occ = occ; a.expd = expd;
+  a.T = T; a.h = h; a.w = w;
+  a.temperature = c->cfg.softmax_temperature;
+  a.img_h = (float)c->cfg.initial_h; a.img_w = (float)c->cfg.initial_w;
+  const int pn = (h + 2) * (w + 2), hw = h * w;
+  if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
+    hipLaunchKernelGGL((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps),
+                       dim3(CV_THREADS), 0, s, a);
+  } else if (pn <= CV_LARGE_PAD && hw <= CV_LARGE_PPT * CV_THREADS) {
+    hipLaunchKernelGGL((cv_heads_kernel<CV_LARGE_PAD, CV_LARGE_PPT>), dim3((unsigned)maps),
+                       dim3(CV_THREADS), 0, s, a);
+  } else {
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "cost-volume grid larger than 1600 cells");
+  }
+  return TAPIR_OK;
+}
+
+// cost volume -> tracks for B clips.  qpts_init: device [B*Q,3] or null.
+template <typename TA>
+int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const float* qpts_init,
+                      int B, int Q, int T, int h, int w, float* points, float* occ, float* expd,
+                      hipStream_t s) {
+  const int C = kLowresDim, hw = h * w;
+  const void* qf_op = qfeat;
+  const void* grid_op = grid;
+  if (sizeof(TA) == 2) {   // stage bf16 copies of both operands
+    TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
+    TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
+    c->cast_src[1] = nullptr;   // slot no longer mirrors a pyramid level
+    qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
+  }
+  // bound the cost-volume workspace to ~256 MiB per launch
+  long qc = (256L << 20) / ((long)T * hw * 4);
+  qc = std::max<long>(1, std::min<long>(qc, Q));
+  TRY(ensure(c, c->cv, (size_t)qc * T * hw * sizeof(float)));
+  for (int b = 0; b < B; ++b) {
+    for (long q0 = 0; q0 < Q; q0 += qc) {
+      const int nq = (int)std::min<long>(qc, Q - q0);
+      const long bq = (long)b * Q + q0;
+      const TA* qa = reinterpret_cast<const TA*>(qf_op) + bq * C;
+      const TA* ga = reinterpret_cast<const TA*>(grid_op) + (long)b * T * hw * C;
+      TRY(cost_volume_gemm<TA>(c, qa, ga, nq, T, hw, C, (float*)c->cv.p, s));
+      TRY(launch_cv_heads(c, (const float*)c->cv.p, qpts_init ? qpts_init + bq * 3 : nullptr,
+                          (long)nq * T, T, h, w, points + bq * T * 2, occ + bq * T,
+                          expd + bq * T, s));
+    }
+  }
+  return TAPIR_OK;
+}
+
+int pick_time_chunk(int N, int T) {
+  int nch = 1;
+  if (T > 16) {
+    nch = (512 + N - 1) / N;
+    nch = std::max(1, std::min(nch, (T + 7) / 8));
+  }
+  nch = std::max(nch, (T + MIX_MAX_TC - 1) / MIX_MAX_TC);
+  return (T + nch - 1) / nch;
+}
+
+// PIPSMLPMixer on R = N*T token rows already staged in c->mlp_in -> c->res [R,388]
+template <typename TA>
+int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
+              float* ctx1_out, float* ctx2_out, hipStream_t s) {
+  const long R = (long)N * T;
+  const int nb = c->cfg.num_mixer_blocks;
+  TRY(ensure(c, c->xa, (size_t)R * kHidden * 4));
+  TRY(ensure(c, c->xb, (size_t)R * kHidden * 4));
+  TRY(ensure(c, c->xn, (size_t)R * kHidden * sizeof(TA)));
+  TRY(ensure(c, c->hid, (size_t)R * kHidden4 * sizeof(TA)));
+  TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
+  {
+    GemmArgs g{};
+    g.A = c->mlp_in.p; g.lda = c->k0_pad; g.W = c->W0; g.ldw = c->k0_pad; g.bias = c->b0;
+    g.C = c->xa.p; g.ldc = kHidden; g.M = (int)R; g.N = kHidden; g.K = c->k0_pad;
+    launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+  }
+  const int TC = pick_time_chunk(N, T);
+  const int nch = (T + TC - 1) / TC;
+  for (int i = 0; i < nb; ++i) {
+    const BlockW& bw = c->blocks[i];
+    MixArgs m{};
+    m.x_in = (const float*)c->xa.p; m.x_out = (float*)c->xb.p; m.xn2 = c->xn.p;
+    m.ln1 = bw.ln1; m.w1 = bw.w1; m.b1 = bw.b1; m.w2 = bw.w2; m.b2 = bw.b2; m.ln2 = bw.ln2;
+    m.ctx1_in = ctx1_in ? ctx1_in + (size_t)i * N * 2 * kHidden : nullptr;
+    m.ctx2_in = ctx2_in ? ctx2_in + (size_t)i * N * 2 * kHidden4 : nullptr;
+    m.ctx1_out = ctx1_out ? ctx1_out + (size_t)i * N * 2 * kHidden : nullptr;
+    m.ctx2_out = ctx2_out ? ctx2_out + (size_t)i * N * 2 * kHidden4 : nullptr;
+    m.T = T; m.TC = TC; m.causal = c->cfg.use_causal_conv;
+    hipLaunchKernelGGL((mix_kernel<TA>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m);
+    GemmArgs g1{};
+    g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
+    g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
+    launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, 1, s);
+    GemmArgs g2{};
+    g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
+    g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
+    g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
+    launch_gemm<TA, float, EPI_BIAS_RESID>(g2, 1, s);
+  }
+  LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
+  hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
+  GemmArgs g{};
+  g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
+  g.C = c->res.p; g.ldc = kMixOut; g.M = (int)R; g.N = kMixOut; g.K = kHidden;
+  launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+  return TAPIR_OK;
+}
+
+struct LevelGrids {   // operand-type pyramid of one feature level
+  const void* grid[kMaxLevels];
+  int h[kMaxLevels], w[kMaxLevels], C[kMaxLevels];
+  const float* query[kMaxLevels];
+  int n;
+};
+
+template <typename TA>
+int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const float* pos,
+                 const float* occ, const float* expd, const float* feats, int orig_h, int orig_w,
+                 hipStream_t s) {
+  const long R = (long)B * Q * T;
+  TRY(ensure(c, c->mlp_in, (size_t)R * c->k0_pad * sizeof(TA)));
+  PatchArgs pa{};
+  pa.n_levels = lg.n;
+  for (int l = 0; l < lg.n; ++l) {
+    pa.lvl[l].grid = lg.grid[l]; pa.lvl[l].query = lg.query[l];
+    pa.lvl[l].h = lg.h[l]; pa.lvl[l].w = lg.w[l]; pa.lvl[l].C = lg.C[l];
+    pa.lvl[l].feat_off = (l == 0) ? 0 : kHiresDim;
+  }
+  pa.pos = pos; pa.occ = occ; pa.expd = expd; pa.feats = feats;
+  pa.mlp_in = c->mlp_in.p; pa.ld = c->k0_pad;
+  pa.B = B; pa.Q = Q; pa.T = T;
+  pa.orig_h = (float)orig_h; pa.orig_w = (float)orig_w;
+  hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3((unsigned)R), dim3(256), 0, s, pa);
+  return TAPIR_OK;
+}
+
+int check_pyramid(tapir_ctx* c, const LevelGrids& lg) {
+  if (lg.n != 2 + c->cfg.pyramid_level) return fail(c, TAPIR_ERR_INVALID, "pyramid must have 2 + pyramid_level levels");
+  if (lg.C[0] != kHiresDim) return fail(c, TAPIR_ERR_INVALID, "pyramid level 0 must have 128 channels");
+  for (int l = 1; l < lg.n; ++l)
+    if (lg.C[l] != kLowresDim) return fail(c, TAPIR_ERR_INVALID, "pyramid levels >= 1 must have 256 channels");
+  return TAPIR_OK;
+}
+
+template <typename TA>
+int do_build_cost_volume(tapir_ctx* c, const float* qfeat, const float* grid, int B, int Q, int T,
+                         int h, int w, int C, float* volume, hipStream_t s) {
+  const int hw = h * w;
+  const void* qf_op = qfeat; const void* grid_op = grid;
+  if (sizeof(TA) == 2) {
+    TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
+    TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
+    c->cast_src[1] = nullptr;
+    qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
+  }
+  for (int b = 0; b < B; ++b) {
+    const TA* qa = reinterpret_cast<const TA*>(qf_op) + (long)b * Q * C;
+    const TA* ga = reinterpret_cast<const TA*>(grid_op) + (long)b * T * hw * C;
+    TRY(cost_volume_gemm<TA>(c, qa, ga, Q, T, hw, C, volume + (long)b * Q * T * hw, s));
+  }
+  return TAPIR_OK;
+}
+
+struct StageArgs { const float* src; void* dst; long R; int cols, ld; };
+template <typename TO>
+__global__ void stage_rows_kernel(StageArgs a) {
+  const long r = blockIdx.x;
+  TO* d = reinterpret_cast<TO*>(a.dst) + r * a.ld;
+  for (int k = threadIdx.x; k < a.ld; k += blockDim.x)
+    Elem<TO>::st(d + k, k < a.cols ? a.src[r * a.cols + k] : 0.f);
+}
+
+template <typename TA>
+int do_pips_mixer(tapir_ctx* c, const float* x, int N, int T, float* out, const float* c1i,
+                  const float* c2i, float* c1o, float* c2o, hipStream_t s) {
+  const long R = (long)N * T;
+  TRY(ensure(c, c->mlp_in, (size_t)R * c->k0_pad * sizeof(TA)));
+  StageArgs sa{x, c->mlp_in.p, R, c->in_dim, c->k0_pad};
+  hipLaunchKernelGGL((stage_rows_kernel<TA>), dim3((unsigned)R), dim3(256), 0, s, sa);
+  TRY(run_mixer<TA>(c, N, T, c1i, c2i, c1o, c2o, s));
+  HIP_TRY(c, hipMemcpyAsync(out, c->res.p, (size_t)R * kMixOut * 4, hipMemcpyDeviceToDevice, s));
+  return TAPIR_OK;
+}
+
+// Builds the operand-type pyramid for one feature level: casts (bf16 build) and
+// average-pools as needed.  slot 0 = hires, 1 = lowres, 2 = pooled lowres.
+template <typename TA>
+int prepare_level(tapir_ctx* c, const float* hires, int hh, int hw_, const float* lowres, int lh,
+                  int lw, const float* q_hires, const float* q_lowres, int B, int T,
+                  LevelGrids* lg, hipStream_t s) {
+  const long frames = (long)B * T;
+  lg->n = 2 + c->cfg.pyramid_level;
+  lg->h[0] = hh; lg->w[0] = hw_; lg->C[0] = kHiresDim; lg->query[0] = q_hires;
+  lg->h[1] = lh; lg->w[1] = lw; lg->C[1] = kLowresDim; lg->query[1] = q_lowres;
+  if (sizeof(TA) == 4) {
+    lg->grid[0] = hires; lg->grid[1] = lowres;
+  } else {
+    if (c->cast_src[0] != hires) {
+      TRY(cast_or_pool<TA>(c, hires, frames, hh, hw_, kHiresDim, 0, c->grid_cast[0], s));
+      c->cast_src[0] = hires;
+    }
+    if (c->cast_src[1] != lowres) {
+      TRY(cast_or_pool<TA>(c, lowres, frames, lh, lw, kLowresDim, 0, c->grid_cast[1], s));
+      c->cast_src[1] = lowres;
+    }
+    lg->grid[0] = c->grid_cast[0].p; lg->grid[1] = c->grid_cast[1].p;
+  }
+  if (c->cfg.pyramid_level >= 1) {
+    if (c->cast_src[2] != lowres) {
+      TRY(cast_or_pool<TA>(c, lowres, frames, lh, lw, kLowresDim, 1, c->pooled, s));
+      c->cast_src[2] = lowres;
+    }
+    lg->grid[2] = c->pooled.p; lg->h[2] = lh / 2; lg->w[2] = lw / 2; lg->C[2] = kLowresDim;
+    lg->query[2] = q_lowres;
+  }
+  return TAPIR_OK;
+}
+
+// one refinement iteration on state buffers (pos/occ/expd/feats are in/out)
+template <typename TA>
+int refine_iter(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, float* pos, float* occ,
+                float* expd, float* feats, bool first_of_level, bool last_of_level,
+                const float* occ0, const float* expd0, int orig_h, int orig_w, int res_h, int res_w,
+                float vx, float vy, float* out_tracks, float* out_occ, float* out_expd,
+                const float* c1i, const float* c2i, float* c1o, float* c2o, hipStream_t s) {
+  const long R = (long)B * Q * T;
+  TRY(launch_patch<TA>(c, lg, B, Q, T, pos, occ, expd, first_of_level ? nullptr : feats, orig_h,
+                       orig_w, s));
+  TRY(run_mixer<TA>(c, B * Q, T, c1i, c2i, c1o, c2o, s));
+  UpdateArgs u{};
+  u.res = (const float*)c->res.p; u.pos = pos; u.occ = occ; u.expd = expd; u.feats = feats;
+  u.q_hires = lg.query[0]; u.q_lowres = lg.query[1];
+  u.out_tracks = out_tracks; u.out_occ = out_occ; u.out_expd = out_expd;
+  u.occ0 = occ0; u.expd0 = expd0; u.R = R; u.T = T;
+  u.sx = (float)orig_w / (float)res_w; u.sy = (float)orig_h / (float)res_h;
+  u.vx = vx; u.vy = vy;
+  u.first_of_level = first_of_level ? 1 : 0;
+  u.last_of_level = last_of_level ? 1 : 0;
+  hipLaunchKernelGGL(update_kernel, dim3((unsigned)R), dim3(128), 0, s, u);
+  return TAPIR_OK;
+}
+
+template <typename TA>
+int do_refine_pips(tapir_ctx* c, const tapir_pyramid* pyr, int B, int Q, int T, const float* pos,
+                   const float* occ, const float* expd, const float* last_iter, int orig_h,
+                   int orig_w, int res_h, int res_w, float* pos_out, float* occ_out,
+                   float* expd_out, float* feats_out, const float* c1i, const float* c2i,
+                   float* c1o, float* c2o, hipStream_t s) {
+  const long R = (long)B * Q * T;
+  LevelGrids lg{};
+  lg.n = pyr->n_levels;
+  if (lg.n < 2 || lg.n > kMaxLevels) return fail(c, TAPIR_ERR_INVALID, "bad pyramid size");
+  for (int l = 0; l < lg.n; ++l) {
+    lg.h[l] = pyr->h[l]; lg.w[l] = pyr->w[l]; lg.C[l] = pyr->C[l]; lg.query[l] = pyr->query[l];
+    if (sizeof(TA) == 4) {
+      lg.grid[l] = pyr->grid[l];
+    } else {
+      DevBuf& dst = (l == 2) ? c->pooled : c->grid_cast[l];
+      TRY(cast_or_pool<TA>(c, pyr->grid[l], (long)B * T, pyr->h[l], pyr->w[l], pyr->C[l], 0, dst, s));
+      c->cast_src[l] = nullptr;
+      lg.grid[l] = dst.p;
+    }
+  }
+  TRY(check_pyramid(c, lg));
+  // copy the inputs into the output buffers and update those in place
+  if (pos_out != pos) HIP_TRY(c, hipMemcpyAsync(pos_out, pos, R * 2 * 4, hipMemcpyDeviceToDevice, s));
+  if (occ_out != occ) HIP_TRY(c, hipMemcpyAsync(occ_out, occ, R * 4, hipMemcpyDeviceToDevice, s));
+  if (expd_out != expd) HIP_TRY(c, hipMemcpyAsync(expd_out, expd, R * 4, hipMemcpyDeviceToDevice, s));
+  if (last_iter != nullptr && feats_out != last_iter)
+    HIP_TRY(c, hipMemcpyAsync(feats_out, last_iter, R * kFeatDim * 4, hipMemcpyDeviceToDevice, s));
+  TRY(ensure(c, c->pos, (size_t)R * 2 * 4));   // scratch for the per-iteration outputs
+  TRY(ensure(c, c->occ0, (size_t)R * 4));
+  TRY(ensure(c, c->expd0, (size_t)R * 4));
+  return refine_iter<TA>(c, lg, B, Q, T, pos_out, occ_out, expd_out, feats_out,
+                         last_iter == nullptr, false, nullptr, nullptr, orig_h, orig_w, res_h,
+                         res_w, 1.0f, 1.0f, (float*)c->pos.p, (float*)c->occ0.p,
+                         (float*)c->expd0.p, c1i, c2i, c1o, c2o, s);
+}
+
+template <typename TA>
+int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
+  const int B = a->B, Q = a->Q, T = a->T;
+  const long BQ = (long)B * Q, R = BQ * T;
+  const int P = c->cfg.num_pips_iter;
+  const int num_iters = P * (a->n_levels - 1);
+  const int nb = c->cfg.num_mixer_blocks;
+  const int ih = c->cfg.initial_h, iw = c->cfg.initial_w;
+  for (int l = 0; l < kMaxLevels; ++l) c->cast_src[l] = nullptr;
+  TRY(ensure(c, c->pos, (size_t)R * 2 * 4));
+  TRY(ensure(c, c->occ, (size_t)R * 4));
+  TRY(ensure(c, c->expd, (size_t)R * 4));
+  TRY(ensure(c, c->occ0, (size_t)R * 4));
+  TRY(ensure(c, c->expd0, (size_t)R * 4));
+  TRY(ensure(c, c->feats, (size_t)R * kFeatDim * 4));
+  float* pos = (float*)c->pos.p; float* occ = (float*)c->occ.p; float* expd = (float*)c->expd.p;
+  float* occ0 = (float*)c->occ0.p; float* expd0 = (float*)c->expd0.p;
+  float* feats = (float*)c->feats.p;
+
+  // query points: video -> initial_resolution coordinates (tapir_model.py:959-969)
+  const float* qinit = nullptr;
+  if (a->query_points != nullptr) {
+    TRY(ensure(c, c->qpts, (size_t)BQ * 3 * 4));
+    InitArgs ia{a->query_points, (float*)c->qpts.p, BQ, (float)ih / (float)a->video_h,
+                (float)iw / (float)a->video_w};
+    hipLaunchKernelGGL(scale_qpts_kernel, dim3((unsigned)((BQ + 255) / 256)), dim3(256), 0, s, ia);
+    qinit = (const float*)c->qpts.p;
+  }
+  TRY(cost_volume_stage<TA>(c, a->q_lowres[0], a->lowres[0], qinit, B, Q, T, a->lowres_h[0],
+                            a->lowres_w[0], pos, occ, expd, s));
+  const float vx = (float)a->video_w / (float)iw, vy = (float)a->video_h / (float)ih;
+  Iter0Args i0{pos, occ, expd, occ0, expd0, a->tracks, a->occlusion, a->expected_dist, R, vx, vy};
+  hipLaunchKernelGGL(iter0_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, i0);
+
+  for (int i = 0; i < num_iters; ++i) {
+    const int lvl = i / P + 1;
+    LevelGrids lg{};
+    TRY(prepare_level<TA>(c, a->hires[lvl], a->hires_h[lvl], a->hires_w[lvl], a->lowres[lvl],
+                          a->lowres_h[lvl], a->lowres_w[lvl], a->q_hires[lvl], a->q_lowres[lvl], B,
+                          T, &lg, s));
+    const size_t s1 = (size_t)nb * BQ * 2 * kHidden, s2 = (size_t)nb * BQ * 2 * kHidden4;
+    TRY(refine_iter<TA>(c, lg, B, Q, T, pos, occ, expd, feats, i % P == 0, (i + 1) % P == 0, occ0,
+                        expd0, ih, iw, a->res_h[lvl], a->res_w[lvl], vx, vy,
+                        a->tracks + (size_t)(i + 1) * R * 2, a->occlusion + (size_t)(i + 1) * R,
+                        a->expected_dist + (size_t)(i + 1) * R,
+                        a->ctx1_in ? a->ctx1_in + i * s1 : nullptr,
+                        a->ctx2_in ? a->ctx2_in + i * s2 : nullptr,
+                        a->ctx1_out ? a->ctx1_out + i * s1 : nullptr,
+                        a->ctx2_out ? a->ctx2_out + i * s2 : nullptr, s));
+  }
+  return TAPIR_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+#define DISPATCH(ctx, fn, ...) \
+  ((ctx)->cfg.dtype == TAPIR_BF16 ? fn<bf16_t>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+#define REQUIRE_READY(ctx)                                                         \
+  do {                                                                             \
+    if (!(ctx)) return TAPIR_ERR_INVALID;                                          \
+    if (!(ctx)->finalized) return fail((ctx), TAPIR_ERR_WEIGHTS, "weights not finalized"); \
+    HIP_TRY((ctx), hipSetDevice((ctx)->device));                                   \
+  } while (0)
+
+extern "C" {
+
+const char* tapir_version(void) { return "tapir_hip 0.1 (gfx950)"; }
+
+int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
+  if (!out || !cfg) return TAPIR_ERR_INVALID;
+  if (cfg->pyramid_level < 0 || cfg->pyramid_level > 1) return TAPIR_ERR_UNSUPPORTED;
+  if (cfg->num_pips_iter < 1 || cfg->num_mixer_blocks < 1) return TAPIR_ERR_INVALID;
+  if (cfg->dtype != TAPIR_F32 && cfg->dtype != TAPIR_BF16) return TAPIR_ERR_INVALID;
+  if (cfg->initial_h % 8 || cfg->initial_w % 8 || cfg->initial_h <= 0 || cfg->initial_w <= 0)
+    return TAPIR_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return TAPIR_ERR_HIP;
+  tapir_ctx* c = new tapir_ctx();
+  c->cfg = *cfg;
+  c->device = device;
+  c->in_dim = kMixOut + kPatch * (2 + cfg->pyramid_level);
+  c->k0_pad = (c->in_dim + 63) / 64 * 64;
+  *out = c;
+  return TAPIR_OK;
+}
+
+void tapir_destroy(tapir_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void* p : c->owned) (void)hipFree(p);
+  DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
+                    &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
+                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  delete c;
+}
+
+const char* tapir_last_error(const tapir_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int tapir_set_weight(tapir_ctx* c, const char* name, const float* data, const int64_t* shape,
+                     int ndim) {
+  if (!c || !name || !data || !shape || ndim < 1 || ndim > 4) return TAPIR_ERR_INVALID;
+  const std::string n(name);
+  if (n.rfind("resnet_torch.", 0) == 0 || n.rfind("extra_convs.", 0) == 0) return TAPIR_OK;
+  HostTensor t;
+  size_t cnt = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); cnt *= (size_t)shape[i]; }
+  t.data.assign(data, data + cnt);
+  c->host_w[n] = std::move(t);
+  c->finalized = false;
+  return TAPIR_OK;
+}
+
+int tapir_finalize_weights(tapir_ctx* c) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (void* p : c->owned) (void)hipFree(p);
+  c->owned.clear();
+  c->blocks.clear();
+  const HostTensor* t;
+  const std::string cv = "torch_cost_volume_track_mods.";
+  float* tmp;
+  TRY(get_w(c, cv + "hid1.weight", {16, 1, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); c->cvw.w1 = tmp;
+  TRY(get_w(c, cv + "hid1.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); c->cvw.b1 = tmp;
+  TRY(get_w(c, cv + "hid2.weight", {1, 16, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); c->cvw.w2 = tmp;
+  TRY(get_w(c, cv + "hid2.bias", {1}, &t)); TRY(upload_f32(c, t->data.data(), 1, &tmp)); c->cvw.b2 = tmp;
+  TRY(get_w(c, cv + "hid3.weight", {32, 16, 3, 3}, &t));
+  {
+    std::vector<float> r(144 * 32);
+    for (int co = 0; co < 32; ++co)
+      for (int ci = 0; ci < 16; ++ci)
+        for (int k = 0; k < 9; ++k) r[(ci * 9 + k) * 32 + co] = t->data[(co * 16 + ci) * 9 + k];
+    TRY(upload_f32(c, r.data(), r.size(), &tmp)); c->cvw.w3 = tmp;
+  }
+  TRY(get_w(c, cv + "hid3.bias", {32}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); c->cvw.b3 = tmp;
+  TRY(get_w(c, cv + "hid4.weight", {16, 32}, &t)); TRY(upload_f32(c, t->data.data(), 512, &tmp)); c->cvw.w4 = tmp;
+  TRY(get_w(c, cv + "hid4.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); c->cvw.b4 = tmp;
+  TRY(get_w(c, cv + "occ_out.weight", {2, 16}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); c->cvw.w5 = tmp;
+  TRY(get_w(c, cv + "occ_out.bias", {2}, &t)); TRY(upload_f32(c, t->data.data(), 2, &tmp)); c->cvw.b5 = tmp;
+
+  const std::string mx = "torch_pips_mixer.";
+  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &t));
+  TRY(upload_matrix(c, t->data.data(), kHidden, c->in_dim, c->k0_pad, &c->W0));
+  TRY(get_w(c, mx + "linear.bias", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &c->b0));
+  TRY(get_w(c, mx + "layer_norm.weight", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &c->lnF));
+  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &t));
+  TRY(upload_matrix(c, t->data.data(), kMixOut, kHidden, kHidden, &c->Wout));
+  TRY(get_w(c, mx + "linear_1.bias", {kMixOut}, &t)); TRY(upload_f32(c, t->data.data(), kMixOut, &c->bout));
+  for (int i = 0; i < c->cfg.num_mixer_blocks; ++i) {
+    const std::string p = mx + "blocks." + std::to_string(i) + ".";
+    BlockW b{};
+    TRY(get_w(c, p + "layer_norm.weight", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.ln1));
+    TRY(get_w(c, p + "mlp1_up.weight", {kHidden4, 1, 3}, &t)); TRY(upload_f32(c, t->data.data(), kHidden4 * 3, &b.w1));
+    TRY(get_w(c, p + "mlp1_up.bias", {kHidden4}, &t)); TRY(upload_f32(c, t->data.data(), kHidden4, &b.b1));
+    TRY(get_w(c, p + "mlp1_up_1.weight", {kHidden4, 1, 3}, &t)); TRY(upload_f32(c, t->data.data(), kHidden4 * 3, &b.w2));
+    TRY(get_w(c, p + "mlp1_up_1.bias", {kHidden4}, &t)); TRY(upload_f32(c, t->data.data(), kHidden4, &b.b2));
+    TRY(get_w(c, p + "layer_norm_1.weight", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.ln2));
+    TRY(get_w(c, p + "conv_channels_mixer.mlp2_up.weight", {kHidden4, kHidden}, &t));
+    TRY(upload_matrix(c, t->data.data(), kHidden4, kHidden, kHidden, &b.Wup));
+    TRY(get_w(c, p + "conv_channels_mixer.mlp2_up.bias", {kHidden4}, &t)); TRY(upload_f32(c, t->data.data(), kHidden4, &b.bup));
+    TRY(get_w(c, p + "conv_channels_mixer.mlp2_down.weight", {kHidden, kHidden4}, &t));
+    TRY(upload_matrix(c, t->data.data(), kHidden, kHidden4, kHidden4, &b.Wdn));
+    TRY(get_w(c, p + "conv_channels_mixer.mlp2_down.bias", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.bdn));
+    c->blocks.push_back(b);
+  }
+  c->host_w.clear();
+  c->finalized = true;
+  return TAPIR_OK;
+}
+
+int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
+  REQUIRE_READY(c);
+  if (B < 1 || Q < 1 || T < 1 || mh < 1 || mw < 1) return fail(c, TAPIR_ERR_INVALID, "bad sizes");
+  const size_t es = esize(c->cfg.dtype);
+  const size_t R = (size_t)B * Q * T, BQ = (size_t)B * Q, frames = (size_t)B * T;
+  TRY(ensure(c, c->mlp_in, R * c->k0_pad * es));
+  TRY(ensure(c, c->xa, R * kHidden * 4)); TRY(ensure(c, c->xb, R * kHidden * 4));
+  TRY(ensure(c, c->xn, R * kHidden * es)); TRY(ensure(c, c->hid, R * kHidden4 * es));
+  TRY(ensure(c, c->res, R * kMixOut * 4));
+  TRY(ensure(c, c->pos, R * 8)); TRY(ensure(c, c->occ, R * 4)); TRY(ensure(c, c->expd, R * 4));
+  TRY(ensure(c, c->occ0, R * 4)); TRY(ensure(c, c->expd0, R * 4));
+  TRY(ensure(c, c->feats, R * kFeatDim * 4)); TRY(ensure(c, c->qpts, BQ * 12));
+  long qc = (256L << 20) / ((long)T * mh * mw * 4);
+  qc = std::max<long>(1, std::min<long>(qc, Q));
+  TRY(ensure(c, c->cv, (size_t)qc * T * mh * mw * 4));
+  if (c->cfg.dtype == TAPIR_BF16) {
+    TRY(ensure(c, c->qf_cast, BQ * kLowresDim * es));
+    TRY(ensure(c, c->grid_cast[0], frames * 4 * mh * mw * kHiresDim * es));
+    TRY(ensure(c, c->grid_cast[1], frames * mh * mw * kLowresDim * es));
+  }
+  if (c->cfg.pyramid_level >= 1) TRY(ensure(c, c->pooled, frames * (mh / 2) * (mw / 2) * kLowresDim * es));
+  return TAPIR_OK;
+}
+
+int tapir_build_cost_volume(tapir_ctx* c, const float* qfeat, const float* grid, int B, int Q, int T,
+                            int h, int w, int C, float* volume, void* stream) {
+  REQUIRE_READY(c);
+  if (!qfeat || !grid || !volume || B < 1 || Q < 1 || T < 1 || h < 1 || w < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (C % 64 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "channels must be a multiple of 64");
+  if (((long)T * h * w) % 4 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
+  return DISPATCH(c, do_build_cost_volume, c, qfeat, grid, B, Q, T, h, w, C, volume, (hipStream_t)stream);
+}
+
+int tapir_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float* grid,
+                                  const float* query_points, int B, int Q, int T, int h, int w,
+                                  float* points, float* occlusion, float* expected_dist,
+                                  void* stream) {
+  REQUIRE_READY(c);
+  if (!qfeat || !grid || !points || !occlusion || !expected_dist || B < 1 || Q < 1 || T < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (((long)T * h * w) % 4 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
+  return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points,
+                  occlusion, expected_dist, (hipStream_t)stream);
+}
+
+int tapir_get_query_features(tapir_ctx* c, const float* grid, const float* query_points, int B,
+                             int Q, int T, int h, int w, int C, int video_h, int video_w,
+                             float* out, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!grid || !query_points || !out || B < 1 || Q < 1 || T < 1 || h < 1 || w < 1 || C < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  SampleArgs a{grid, query_points, out, B, Q, T, h, w, C, (float)video_h, (float)video_w};
+  hipLaunchKernelGGL(query_feature_kernel, dim3((unsigned)((long)B * Q)), dim3(128), 0,
+                     (hipStream_t)stream, a);
+  return TAPIR_OK;
+}
+
+int tapir_pips_mixer(tapir_ctx* c, const float* x, int N, int T, float* out, const float* ctx1_in,
+                     const float* ctx2_in, float* ctx1_out, float* ctx2_out, void* stream) {
+  REQUIRE_READY(c);
+  if (!x || !out || N < 1 || T < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if ((ctx1_in || ctx2_in || ctx1_out || ctx2_out) && !c->cfg.use_causal_conv)
+    return fail(c, TAPIR_ERR_INVALID, "causal context needs use_causal_conv");
+  if ((ctx1_in == nullptr) != (ctx2_in == nullptr) || (ctx1_out == nullptr) != (ctx2_out == nullptr))
+    return fail(c, TAPIR_ERR_INVALID, "causal context pointers must come in pairs");
+  return DISPATCH(c, do_pips_mixer, c, x, N, T, out, ctx1_in, ctx2_in, ctx1_out, ctx2_out,
+                  (hipStream_t)stream);
+}
+
+int tapir_refine_pips(tapir_ctx* c, const tapir_pyramid* pyr, int B, int Q, int T, const float* pos,
+                      const float* occ, const float* expd, const float* last_iter, int orig_h,
+                      int orig_w, int resized_h, int resized_w, float* pos_out, float* occ_out,
+                      float* expd_out, float* feats_out, const float* ctx1_in, const float* ctx2_in,
+                      float* ctx1_out, float* ctx2_out, void* stream) {
+  REQUIRE_READY(c);
+  if (!pyr || !pos || !occ || !expd || !pos_out || !occ_out || !expd_out || !feats_out || B < 1 ||
+      Q < 1 || T < 1 || resized_h < 1 || resized_w < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if ((ctx1_in || ctx1_out) && !c->cfg.use_causal_conv)
+    return fail(c, TAPIR_ERR_INVALID, "causal context needs use_causal_conv");
+  return DISPATCH(c, do_refine_pips, c, pyr, B, Q, T, pos, occ, expd, last_iter, orig_h, orig_w,
+                  resized_h, resized_w, pos_out, occ_out, expd_out, feats_out, ctx1_in, ctx2_in,
+                  ctx1_out, ctx2_out, (hipStream_t)stream);
+}
+
+int tapir_estimate_trajectories(tapir_ctx* c, const tapir_traj_args* a, void* stream) {
+  REQUIRE_READY(c);
+  if (!a || a->B < 1 || a->Q < 1 || a->T < 1 || a->n_levels < 2 || a->n_levels > TAPIR_MAX_LEVELS)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!a->tracks || !a->occlusion || !a->expected_dist) return fail(c, TAPIR_ERR_INVALID, "null output");
+  for (int l = 0; l < a->n_levels; ++l) {
+    if (!a->lowres[l] || !a->hires[l] || !a->q_lowres[l] || !a->q_hires[l])
+      return fail(c, TAPIR_ERR_INVALID, "null feature level");
+    if (a->res_h[l] < 1 || a->res_w[l] < 1) return fail(c, TAPIR_ERR_INVALID, "bad resolution");
+  }
+  if (((long)a->T * a->lowres_h[0] * a->lowres_w[0]) % 4 != 0)
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
+  if ((a->ctx1_in || a->ctx1_out) && !c->cfg.use_causal_conv)
+    return fail(c, TAPIR_ERR_INVALID, "causal context needs use_causal_conv");
+  if ((a->ctx1_in == nullptr) != (a->ctx2_in == nullptr) ||
+      (a->ctx1_out == nullptr) != (a->ctx2_out == nullptr))
+    return fail(c, TAPIR_ERR_INVALID, "causal context pointers must come in pairs");
+  return DISPATCH(c, do_estimate, c, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

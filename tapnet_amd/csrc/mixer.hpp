@@ -1,0 +1,290 @@
+// Token-mixing half of a PIPsConvBlock and the small row-wise kernels of the
+// PIPs MLP-mixer (tapnet/models/tapir_model.py:33-156).
+//
+// mix_kernel fuses, per track and time chunk:
+//   LN1 (scale only, eps 1e-5)  :111      -> depthwise Conv1D k=3 x4 channels :59-66
+//   -> GELU(tanh) :67 -> depthwise Conv1D k=3 :75-82 -> sum of each group of 4 :87
+//   -> + skip :119 -> LN2 :121
+// and writes the new residual stream (f32) plus LN2(x) in the GEMM operand
+// type.  The 2048-wide intermediate never leaves registers.  Temporal padding
+// is SAME (zeros at both clip ends) or causal (two frames on the left taken
+// from the causal context, zeros if there is none) :64,80,49-53,69-73.
+#pragma once
+#include "common.hpp"
+
+namespace tapir {
+
+constexpr int MIX_THREADS = 256;     // 2 channels per thread x 256 = 512
+constexpr int MIX_MAX_TC = 64;       // max frames per time chunk
+constexpr float kLnEps = 1e-5f;      // hk.LayerNorm default
+
+struct MixArgs {
+  const float* x_in;      // [N, T, 512]
+  float* x_out;           // [N, T, 512]   (must not alias x_in: halo rows are re-read)
+  void* xn2;              // [N*T, 512] LN2(x_out) * scale, operand type
+  const float* ln1;       // [512]
+  const float* w1;        // [2048, 3]  out channel 4c+m <- in channel c  (mlp1_up)
+  const float* b1;        // [2048]
+  const float* w2;        // [2048, 3]  (mlp1_up_1)
+  const float* b2;        // [2048]
+  const float* ln2;       // [512]
+  const float* ctx1_in;   // [N, 2, 512]  or null   (block_i_causal_1)
+  const float* ctx2_in;   // [N, 2, 2048] or null   (block_i_causal_2)
+  float* ctx1_out;        // or null
+  float* ctx2_out;        // or null
+  int T;                  // frames per track
+  int TC;                 // frames per workgroup (<= MIX_MAX_TC)
+  int causal;             // use_causal_conv
+};
+
+// block-wide sum of one float per thread; `slot` alternates so that consecutive
+// calls need a single barrier each.
+__device__ __forceinline__ float block_sum_256(float v, float (*red)[4], int slot) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[slot][threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[slot][0] + red[slot][1] + red[slot][2] + red[slot][3];
+}
+
+template <typename TO>
+__global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
+  __shared__ float s_part[MIX_MAX_TC + 8][4];
+  __shared__ float s_mean[MIX_MAX_TC + 8];
+  __shared__ float s_rstd[MIX_MAX_TC + 8];
+  __shared__ float s_red[4][4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y;
+  const int T = a.T;
+  const int t0 = blockIdx.x * a.TC;
+  const int t1 = min(T, t0 + a.TC);
+  const int off0 = a.causal ? -2 : -1;        // tap k reads frame t + off0 + k
+  const int c0 = tid * 2;                      // this thread's two channels
+  const float* __restrict__ xin = a.x_in + (long)n * T * kHidden;
+
+  // ---- phase 1: LayerNorm statistics of every input row this chunk touches
+  const int xlo = max(0, t0 + 2 * off0);
+  const int xhi = min(T - 1, t1 - 1 + 2 * off0 + 4);
+  const int nrows = xhi - xlo + 1;
+  for (int r = 0; r < nrows; ++r) {
+    const float2 v = *reinterpret_cast<const float2*>(xin + (long)(xlo + r) * kHidden + c0);
+    const float s = wave_sum(v.x + v.y);
+    if (lane == 0) s_part[r][wave] = s;
+  }
+  __syncthreads();
+  if (tid < nrows)
+    s_mean[tid] = (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]) * (1.0f / kHidden);
+  __syncthreads();
+  for (int r = 0; r < nrows; ++r) {
+    const float2 v = *reinterpret_cast<const float2*>(xin + (long)(xlo + r) * kHidden + c0);
+    const float m = s_mean[r];
+    const float s = wave_sum((v.x - m) * (v.x - m) + (v.y - m) * (v.y - m));
+    if (lane == 0) s_part[r][wave] = s;
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    const float var = (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]) * (1.0f / kHidden);
+    s_rstd[tid] = 1.0f / sqrtf(var + kLnEps);
+  }
+  __syncthreads();
+
+  // ---- per-thread weights (2 channels x 4 multipliers x 3 taps, twice)
+  float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2], sc2[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    sc1[ch] = a.ln1[c0 + ch];
+    sc2[ch] = a.ln2[c0 + ch];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int o = 4 * (c0 + ch) + m;
+      b1[ch][m] = a.b1[o];
+      b2[ch][m] = a.b2[o];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        w1[ch][m][k] = a.w1[o * 3 + k];
+        w2[ch][m][k] = a.w2[o * 3 + k];
+      }
+    }
+  }
+
+  // LN1(x)[tau, c0..c0+1]; outside the clip: causal context or zeros
+  auto load_xn = [&](int tau, float& o0, float& o1) {
+    if (tau >= 0 && tau < T) {
+      const float2 v = *reinterpret_cast<const float2*>(xin + (long)tau * kHidden + c0);
+      const float m = s_mean[tau - xlo], rs = s_rstd[tau - xlo];
+      o0 = (v.x - m) * rs * sc1[0];
+      o1 = (v.y - m) * rs * sc1[1];
+    } else if (tau < 0 && tau >= -2 && a.ctx1_in != nullptr) {
+      const float2 v = *reinterpret_cast<const float2*>(a.ctx1_in + ((long)n * 2 + (tau + 2)) * kHidden + c0);
+      o0 = v.x; o1 = v.y;
+    } else {
+      o0 = 0.f; o1 = 0.f;
+    }
+  };
+
+  float xw[2][3];          // LN1(x) window: frames tau+off0 .. tau+off0+2
+  float gw[2][4][3];       // GELU window:   frames tau-2 .. tau
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gw[ch][m][0] = gw[ch][m][1] = gw[ch][m][2] = 0.f;
+
+  const int g_lo = t0 + off0;                 // first / last frame of g this chunk needs
+  const int g_hi = t1 - 1 + off0 + 2;
+  load_xn(g_lo + off0, xw[0][0], xw[1][0]);
+  load_xn(g_lo + off0 + 1, xw[0][1], xw[1][1]);
+
+  for (int tau = g_lo; tau <= g_hi; ++tau) {
+    load_xn(tau + off0 + 2, xw[0][2], xw[1][2]);
+    // g(tau): GELU(conv1(LN1 x)) inside the clip, causal context / zeros outside
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        gw[ch][m][0] = gw[ch][m][1];
+        gw[ch][m][1] = gw[ch][m][2];
+      }
+    if (tau >= 0 && tau < T) {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float u = b1[ch][m];
+          u = fmaf(w1[ch][m][0], xw[ch][0], u);
+          u = fmaf(w1[ch][m][1], xw[ch][1], u);
+          u = fmaf(w1[ch][m][2], xw[ch][2], u);
+          gw[ch][m][2] = gelu_tanh(u);
+        }
+    } else if (tau < 0 && tau >= -2 && a.ctx2_in != nullptr) {
+      const float* p = a.ctx2_in + ((long)n * 2 + (tau + 2)) * kHidden4 + 4 * c0;
+      const float4 v0 = *reinterpret_cast<const float4*>(p);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+      gw[0][0][2] = v0.x; gw[0][1][2] = v0.y; gw[0][2][2] = v0.z; gw[0][3][2] = v0.w;
+      gw[1][0][2] = v1.x; gw[1][1][2] = v1.y; gw[1][2][2] = v1.z; gw[1][3][2] = v1.w;
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gw[ch][m][2] = 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) { xw[ch][0] = xw[ch][1]; xw[ch][1] = xw[ch][2]; }
+
+    // output frame whose last tap is g(tau)
+    const int t = tau - off0 - 2;
+    if (t >= t0 && t < t1) {   // uniform over the workgroup
+      float y[2];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float v = b2[ch][m];
+          v = fmaf(w2[ch][m][0], gw[ch][m][0], v);
+          v = fmaf(w2[ch][m][1], gw[ch][m][1], v);
+          v = fmaf(w2[ch][m][2], gw[ch][m][2], v);
+          acc += v;
+        }
+        y[ch] = acc;
+      }
+      const float2 xv = *reinterpret_cast<const float2*>(xin + (long)t * kHidden + c0);
+      const float x0 = xv.x + y[0], x1 = xv.y + y[1];
+      const long row = (long)n * T + t;
+      *reinterpret_cast<float2*>(a.x_out + row * kHidden + c0) = make_float2(x0, x1);
+      // LN2 over the 512 channels of this frame
+      const int slot = (t & 1) * 2;
+      const float mean = block_sum_256(x0 + x1, s_red, slot) * (1.0f / kHidden);
+      const float d0 = x0 - mean, d1 = x1 - mean;
+      const float var = block_sum_256(d0 * d0 + d1 * d1, s_red, slot + 1) * (1.0f / kHidden);
+      const float rs = 1.0f / sqrtf(var + kLnEps);
+      TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden + c0;
+      Elem<TO>::st(o, d0 * rs * sc2[0]);
+      Elem<TO>::st(o + 1, d1 * rs * sc2[1]);
+    }
+  }
+
+  // ---- new causal context: last two frames of [ctx ; new] (tapir_model.py:58,73)
+  if (a.ctx1_out != nullptr && t1 == T) {
+    // after the loop the windows hold frames T-3..T-1 in slots 0..2 of gw and
+    // frames T-2, T-1 of LN1(x) in slots 0, 1 of xw
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<float2*>(a.ctx1_out + ((long)n * 2 + j) * kHidden + c0) =
+          make_float2(xw[0][j], xw[1][j]);
+      float* p = a.ctx2_out + ((long)n * 2 + j) * kHidden4 + 4 * c0;
+      *reinterpret_cast<float4*>(p) = make_float4(gw[0][0][1 + j], gw[0][1][1 + j], gw[0][2][1 + j], gw[0][3][1 + j]);
+      *reinterpret_cast<float4*>(p + 4) = make_float4(gw[1][0][1 + j], gw[1][1][1 + j], gw[1][2][1 + j], gw[1][3][1 + j]);
+    }
+  }
+}
+
+// Row-wise LayerNorm (scale only) -> operand type; one wave per row of 512.
+struct LnArgs { const float* x; const float* scale; void* out; long rows; };
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* p = a.x + row * kHidden + lane * 8;
+  const float4 u = *reinterpret_cast<const float4*>(p);
+  const float4 v = *reinterpret_cast<const float4*>(p + 4);
+  float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += e[i];
+  const float mean = wave_sum(s) * (1.0f / kHidden);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] -= mean; q += e[i] * e[i]; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / kHidden) + kLnEps);
+  TO* o = reinterpret_cast<TO*>(a.out) + row * kHidden + lane * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) Elem<TO>::st(o + i, e[i] * rs * a.scale[lane * 8 + i]);
+}
+
+// Applies one mixer output to the running estimate (tapir_model.py:613-623,
+// 1026-1039):  pos += d_xy * (orig/resized), occ += d, expd += d, feats += d.
+struct UpdateArgs {
+  const float* res;        // [R, 388]
+  float* pos;              // [R, 2]  (x, y) in initial_resolution pixels
+  float* occ; float* expd; // [R]
+  float* feats;            // [R, 384] in/out
+  const float* q_hires;    // [B*Q, 128] used when first_of_level
+  const float* q_lowres;   // [B*Q, 256]
+  float* out_tracks;       // [R, 2] this iteration's slice, video pixels
+  float* out_occ; float* out_expd;
+  const float* occ0; const float* expd0;   // cost-volume values (reset after a level)
+  long R; int T;
+  float sx, sy;            // orig / resized  (x, y)
+  float vx, vy;            // video / initial_resolution (train2orig)
+  int first_of_level;      // feats input was the tiled query feature
+  int last_of_level;       // reset occ/expd to the cost-volume values afterwards
+};
+__global__ __launch_bounds__(128) void update_kernel(UpdateArgs a) {
+  const long r = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* res = a.res + r * kMixOut;
+  const long bq = r / a.T;
+  for (int c = tid; c < kFeatDim; c += 128) {
+    float prev;
+    if (a.first_of_level)
+      prev = (c < kHiresDim) ? a.q_hires[bq * kHiresDim + c] : a.q_lowres[bq * kLowresDim + (c - kHiresDim)];
+    else
+      prev = a.feats[r * kFeatDim + c];
+    a.feats[r * kFeatDim + c] = res[4 + c] + prev;
+  }
+  if (tid == 0) {
+    const float px = a.pos[r * 2 + 0] + res[0] * a.sx;
+    const float py = a.pos[r * 2 + 1] + res[1] * a.sy;
+    const float oc = a.occ[r] + res[2];
+    const float ex = a.expd[r] + res[3];
+    a.pos[r * 2 + 0] = px; a.pos[r * 2 + 1] = py;
+    a.out_tracks[r * 2 + 0] = px * a.vx; a.out_tracks[r * 2 + 1] = py * a.vy;
+    a.out_occ[r] = oc; a.out_expd[r] = ex;
+    a.occ[r] = a.last_of_level ? a.occ0[r] : oc;
+    a.expd[r] = a.last_of_level ? a.expd0[r] : ex;
+  }
+}
+
+}  // namespace tapir

@@ -1,0 +1,239 @@
+// Front half of TAPIR.refine_pips (tapnet/models/tapir_model.py:496-594):
+// 7x7 bilinear patch correlation around the current position estimate on each
+// pyramid level, and assembly of the mixer input row
+//   [0, 0, occ, expd, feats(384), corr_hires(49), corr_lowres(49), (corr_pooled(49))]
+//
+// The 49 sample positions are the estimate plus INTEGER offsets (:509-515), so
+// they share one pair of fractional weights: the kernel computes the raw dot
+// products of the query vector with the 8x8 integer window of grid cells and
+// blends neighbouring products (the reference's own TPU path :542-562 is the
+// same linear re-association).  Cells outside the grid contribute zero
+// (interp(mode='constant') :524).
+//
+// One workgroup per token (b, q, t); wave L handles pyramid level L: the 64
+// lanes split the C channels of one grid cell (coalesced 16-byte loads along
+// the channels-last feature grid), accumulate 64 per-cell partial dots in
+// registers, and a 63-shuffle transposed butterfly leaves the full dot product
+// of cell p in lane p.
+#pragma once
+#include "common.hpp"
+
+namespace tapir {
+
+struct PyrLevel {
+  const void* grid;     // [B, T, h, w, C] operand type
+  const float* query;   // [B*Q, C] f32 (used when feats == null)
+  int h, w, C;
+  int feat_off;         // offset of this level's slice in feats[384]: 0 (hires) or 128
+};
+
+struct PatchArgs {
+  PyrLevel lvl[kMaxLevels];
+  int n_levels;
+  const float* pos;     // [R, 2] (x, y) in initial_resolution pixels
+  const float* occ;     // [R]
+  const float* expd;    // [R]
+  const float* feats;   // [R, 384] or null (first iteration of a level: tiled query features)
+  void* mlp_in;         // [R, ld] operand type
+  int ld;               // row stride (>= 388 + 49*n_levels, zero padded)
+  int B, Q, T;
+  float orig_h, orig_w; // initial_resolution
+};
+
+template <int CPL, typename TG>
+__device__ __forceinline__ float cell_dot(const TG* p, const float* qv);
+
+template <> __device__ __forceinline__ float cell_dot<4, float>(const float* p, const float* qv) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return v.x * qv[0] + v.y * qv[1] + v.z * qv[2] + v.w * qv[3];
+}
+template <> __device__ __forceinline__ float cell_dot<2, float>(const float* p, const float* qv) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  return v.x * qv[0] + v.y * qv[1];
+}
+template <> __device__ __forceinline__ float cell_dot<4, bf16_t>(const bf16_t* p, const float* qv) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return __uint_as_float(v.x << 16) * qv[0] + __uint_as_float(v.x & 0xffff0000u) * qv[1] +
+         __uint_as_float(v.y << 16) * qv[2] + __uint_as_float(v.y & 0xffff0000u) * qv[3];
+}
+template <> __device__ __forceinline__ float cell_dot<2, bf16_t>(const bf16_t* p, const float* qv) {
+  const unsigned v = *reinterpret_cast<const unsigned*>(p);
+  return __uint_as_float(v << 16) * qv[0] + __uint_as_float(v & 0xffff0000u) * qv[1];
+}
+
+// 8x8 window of dot products for one level; returns the 7x7 blended value for
+// lane (i=lane>>3, j=lane&7) (garbage for i==7 or j==7).
+template <int CPL, typename TG>
+__device__ __forceinline__ float level_corr(const PyrLevel& L, const float* qv, long frame,
+                                            float px, float py, float orig_w, float orig_h,
+                                            int lane) {
+  // coords = pos * grid_size / orig_size (transforms.py:75-76), then -0.5 (model_utils.py:199)
+  const float gx = px * (float)L.w / orig_w - 0.5f;
+  const float gy = py * (float)L.h / orig_h - 0.5f;
+  const float fx0 = floorf(gx), fy0 = floorf(gy);
+  const float fx = gx - fx0, fy = gy - fy0;
+  const int x0 = (int)fx0 - 3, y0 = (int)fy0 - 3;   // window origin (offset -3)
+  const TG* base = reinterpret_cast<const TG*>(L.grid) + frame * ((long)L.h * L.w * L.C) + lane * CPL;
+
+  float part[64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int y = y0 + i;
+    const bool vy = (y >= 0) && (y < L.h);
+    const int yc = min(max(y, 0), L.h - 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int x = x0 + j;
+      const bool v = vy && (x >= 0) && (x < L.w);
+      const int xc = min(max(x, 0), L.w - 1);
+      const float d = cell_dot<CPL, TG>(base + ((long)yc * L.w + xc) * L.C, qv);
+      part[i * 8 + j] = v ? d : 0.f;
+    }
+  }
+  // transposed butterfly: after the step with offset `off`, a lane keeps the
+  // half of its values whose cell index has bit `off` equal to the lane's.
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int k = 0; k < off; ++k) {
+      const float send = up ? part[k] : part[k + off];
+      const float keep = up ? part[k + off] : part[k];
+      part[k] = keep + __shfl_xor(send, off);
+    }
+  }
+  const float d00 = part[0];              // lane p holds cell p = i*8 + j
+  const float d01 = __shfl_down(d00, 1);
+  const float d10 = __shfl_down(d00, 8);
+  const float d11 = __shfl_down(d00, 9);
+  const float wy0 = 1.0f - fy, wx0 = 1.0f - fx;
+  return d00 * (wy0 * wx0) + d01 * (wy0 * fx) + d10 * (fy * wx0) + d11 * (fy * fx);
+}
+
+template <typename TG, typename TO>
+__global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
+  const long r = blockIdx.x;                 // token (b, q, t)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int t = (int)(r % a.T);
+  const long bq = r / a.T;
+  const int b = (int)(bq / a.Q);
+  TO* out = reinterpret_cast<TO*>(a.mlp_in) + r * a.ld;
+
+  // header + features + zero padding of the K tail
+  const int ncorr0 = kMixOut;
+  for (int c = tid; c < a.ld; c += 256) {
+    float v;
+    if (c < 2) v = 0.f;                       // position channels are always zero (:583)
+    else if (c == 2) v = a.occ[r];
+    else if (c == 3) v = a.expd[r];
+    else if (c < ncorr0) {
+      const int f = c - 4;
+      if (a.feats != nullptr) v = a.feats[r * kFeatDim + f];
+      else v = (f < kHiresDim) ? a.lvl[0].query[bq * kHiresDim + f]
+                               : a.lvl[1].query[bq * kLowresDim + (f - kHiresDim)];
+    } else if (c >= ncorr0 + kPatch * a.n_levels) v = 0.f;
+    else continue;                            // correlation slots: written below
+    Elem<TO>::st(out + c, v);
+  }
+
+  if (wave >= a.n_levels) return;
+  const PyrLevel& L = a.lvl[wave];
+  const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
+  const long frame = (long)b * a.T + t;
+  float corr;
+  if (L.C == 256) {
+    float qv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      qv[k] = (a.feats != nullptr) ? a.feats[r * kFeatDim + L.feat_off + lane * 4 + k]
+                                   : L.query[bq * 256 + lane * 4 + k];
+    corr = level_corr<4, TG>(L, qv, frame, px, py, a.orig_w, a.orig_h, lane);
+  } else {   // C == 128
+    float qv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      qv[k] = (a.feats != nullptr) ? a.feats[r * kFeatDim + L.feat_off + lane * 2 + k]
+                                   : L.query[bq * 128 + lane * 2 + k];
+    corr = level_corr<2, TG>(L, qv, frame, px, py, a.orig_w, a.orig_h, lane);
+  }
+  const int i = lane >> 3, j = lane & 7;
+  if (i < 7 && j < 7) Elem<TO>::st(out + ncorr0 + kPatch * wave + i * 7 + j, corr);
+}
+
+// ---- query features: trilinear sample with index clamping
+// (get_query_features tapir_model.py:781-849; interp(mode='nearest') model_utils.py:177-206)
+struct SampleArgs {
+  const float* grid;     // [B, T, h, w, C]
+  const float* qpts;     // [B, Q, 3] (t, y, x) in video coordinates
+  float* out;            // [B, Q, C]
+  int B, Q, T, h, w, C;
+  float vid_h, vid_w;
+};
+__global__ __launch_bounds__(128) void query_feature_kernel(SampleArgs a) {
+  const long bq = blockIdx.x;
+  const int b = (int)(bq / a.Q);
+  const float* q = a.qpts + bq * 3;
+  // position_in_grid = q * [T,h,w] / [T,H,W]; t unshifted, y/x - 0.5
+  const float ct = q[0] * (float)a.T / (float)a.T;
+  const float cy = q[1] * (float)a.h / a.vid_h - 0.5f;
+  const float cx = q[2] * (float)a.w / a.vid_w - 0.5f;
+  const float ft = floorf(ct), fy = floorf(cy), fx = floorf(cx);
+  const float wt = ct - ft, wy = cy - fy, wx = cx - fx;
+  const int it = (int)ft, iy = (int)fy, ix = (int)fx;
+  const float* g = a.grid + (long)b * a.T * a.h * a.w * a.C;
+  for (int c = threadIdx.x; c < a.C; c += 128) {
+    float acc = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int tt = min(max(it + dt, 0), a.T - 1);
+      const float wtt = dt ? wt : 1.0f - wt;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yy = min(max(iy + dy, 0), a.h - 1);
+        const float wyy = dy ? wy : 1.0f - wy;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = min(max(ix + dx, 0), a.w - 1);
+          const float wxx = dx ? wx : 1.0f - wx;
+          acc += g[(((long)tt * a.h + yy) * a.w + xx) * a.C + c] * (wtt * wyy * wxx);
+        }
+      }
+    }
+    a.out[bq * a.C + c] = acc;
+  }
+}
+
+// ---- 2x2 average pool over (h, w) of a channels-last grid (tapir_model.py:995-1000),
+// optionally converting to the operand type; also the plain cast (pool = 0).
+struct PoolArgs { const float* in; void* out; long frames; int h, w, C; int pool; };
+template <typename TO>
+__global__ __launch_bounds__(256) void pool_cast_kernel(PoolArgs a) {
+  const int oh = a.pool ? a.h / 2 : a.h, ow = a.pool ? a.w / 2 : a.w;
+  const long total = a.frames * oh * ow * (a.C / 4);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c4 = (int)(idx % (a.C / 4));
+    long p = idx / (a.C / 4);
+    const int x = (int)(p % ow); p /= ow;
+    const int y = (int)(p % oh);
+    const long f = p / oh;
+    float4 v;
+    if (a.pool) {
+      const float* s = a.in + ((f * a.h + 2 * y) * a.w + 2 * x) * a.C + c4 * 4;
+      const float4 v00 = *reinterpret_cast<const float4*>(s);
+      const float4 v01 = *reinterpret_cast<const float4*>(s + a.C);
+      const float4 v10 = *reinterpret_cast<const float4*>(s + (long)a.w * a.C);
+      const float4 v11 = *reinterpret_cast<const float4*>(s + (long)a.w * a.C + a.C);
+      v.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f;
+      v.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
+      v.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f;
+      v.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
+    } else {
+      v = *reinterpret_cast<const float4*>(a.in + ((f * a.h + y) * a.w + x) * a.C + c4 * 4);
+    }
+    TO* o = reinterpret_cast<TO*>(a.out) + ((f * oh + y) * ow + x) * a.C + c4 * 4;
+    Elem<TO>::st(o, v.x); Elem<TO>::st(o + 1, v.y); Elem<TO>::st(o + 2, v.z); Elem<TO>::st(o + 3, v.w);
+  }
+}
+
+}  // namespace tapir

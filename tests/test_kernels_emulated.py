@@ -1,0 +1,150 @@
+"""Runs the UNMODIFIED HIP kernel sources on the CPU fiber emulator
+(tests/hipemu) through the C ABI and checks them against the oracle and the
+reference-generated golden fixtures.  This validates indexing / fragment
+layouts / halo logic without a GPU; the `-m gpu` tests repeat the same checks
+on the real gfx950 library."""
+import numpy as np
+import pytest
+
+from oracle import tapir_oracle as O
+from tapnet_amd import _ffi, synthetic
+from tests.emu_engine import EmuEngine
+from tests.golden_util import CASES, load_case
+
+
+def bf16_round(x):
+  u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+  u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+  return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.fixture(scope='module')
+def small_engine():
+  w = synthetic.make_weights(5, pyramid_level=1, extra_convs=False, num_mixer_blocks=2,
+                             backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64))
+  yield e, w
+  e.close()
+
+
+def test_build_cost_volume_f32(small_engine):
+  e, _ = small_engine
+  rng = np.random.default_rng(0)
+  qf = rng.standard_normal((2, 37, 256)).astype(np.float32)
+  grid = rng.standard_normal((2, 3, 8, 12, 256)).astype(np.float32)
+  vol = e.build_cost_volume(qf, grid)
+  ref = O.build_cost_volume(qf, grid).transpose(1, 2, 0, 3, 4)
+  np.testing.assert_allclose(vol, ref, atol=2e-4)
+
+
+def test_build_cost_volume_bf16():
+  w = synthetic.make_weights(5, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64),
+                dtype=_ffi.TAPIR_BF16)
+  rng = np.random.default_rng(1)
+  qf = rng.standard_normal((1, 130, 256)).astype(np.float32)
+  grid = rng.standard_normal((1, 2, 8, 8, 256)).astype(np.float32)
+  vol = e.build_cost_volume(qf, grid)
+  ref = O.build_cost_volume(bf16_round(qf), bf16_round(grid)).transpose(1, 2, 0, 3, 4)
+  np.testing.assert_allclose(vol, ref, atol=2e-3)
+  e.close()
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir'])
+def test_query_features_golden(name, small_engine):
+  e, _ = small_engine
+  cfg, g, _ = load_case(name)
+  ql = e.get_query_features(g['lowres'][0], g['query_points'], g['video'].shape[2:4])
+  qh = e.get_query_features(g['hires'][0], g['query_points'], g['video'].shape[2:4])
+  np.testing.assert_allclose(ql, g['qlowres'][0], atol=2e-6)
+  np.testing.assert_allclose(qh, g['qhires'][0], atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir'])
+def test_cost_volume_stage_golden(name):
+  cfg, g, w = load_case(name)
+  e = EmuEngine(w, pyramid_level=cfg['pyramid_level'], softmax_temperature=cfg['softmax_temperature'],
+                initial_resolution=(cfg['res'], cfg['res']))
+  r = cfg['res'] / cfg['video']
+  qp = g['query_points'] * np.array([1.0, r, r], np.float32)
+  pts, occ, expd = e.tracks_from_cost_volume(g['qlowres'][0], g['lowres'][0], qp)
+  _, _, _, st = O.tracks_from_cost_volume(w, g['qlowres'][0], g['lowres'][0], qp,
+                                          (cfg['res'], cfg['res']), cfg['softmax_temperature'],
+                                          return_stages=True)
+  np.testing.assert_allclose(occ, g['cv_occ'], atol=1e-4)
+  np.testing.assert_allclose(expd, g['cv_expd'], atol=1e-4)
+  ok = st['top2_rel_gap'] > 1e-4
+  np.testing.assert_allclose(pts[ok], g['cv_points'][ok], atol=1e-3)
+  e.close()
+
+
+def test_cost_volume_stage_odd_grid():
+  """odd h/w exercises the XLA-SAME stride-2 padding (pad_lo = 1) and ragged tiles."""
+  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(72, 40))
+  rng = np.random.default_rng(3)
+  grid = O.l2_normalize(rng.standard_normal((1, 4, 9, 5, 256)).astype(np.float32))
+  qf = O.l2_normalize(rng.standard_normal((1, 7, 256)).astype(np.float32))
+  qp = np.stack([rng.integers(0, 4, (1, 7)), rng.uniform(0, 72, (1, 7)),
+                 rng.uniform(0, 40, (1, 7))], -1).astype(np.float32)
+  pts, occ, expd = e.tracks_from_cost_volume(qf, grid, qp)
+  rp, ro, re, st = O.tracks_from_cost_volume(w, qf, grid, qp, (72, 40), 20.0, return_stages=True)
+  np.testing.assert_allclose(occ, ro, atol=1e-4)
+  np.testing.assert_allclose(expd, re, atol=1e-4)
+  ok = st['top2_rel_gap'] > 1e-4
+  np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3)
+  e.close()
+
+
+@pytest.mark.parametrize('causal', [False, True])
+def test_pips_mixer(causal):
+  w = synthetic.make_weights(6, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=2, use_causal_conv=causal, initial_resolution=(64, 64))
+  rng = np.random.default_rng(2)
+  x = rng.standard_normal((3, 19, 535)).astype(np.float32)   # T=19 -> time chunks with halos
+  out = e.pips_mixer(x)
+  ref, _ = O.pips_mlp_mixer(w, x, num_blocks=2, use_causal_conv=causal)
+  np.testing.assert_allclose(out, ref, atol=2e-4)
+  e.close()
+
+
+def test_pips_mixer_causal_state():
+  w = synthetic.make_weights(7, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=2, use_causal_conv=True, initial_resolution=(64, 64))
+  rng = np.random.default_rng(4)
+  N = 3
+  xs = rng.standard_normal((N, 3, 535)).astype(np.float32)
+  c1 = np.zeros((2, N, 2, 512), np.float32); c2 = np.zeros((2, N, 2, 2048), np.float32)
+  octx = {}
+  for i in range(2):
+    octx[f'block_{i}_causal_1'] = c1[i]; octx[f'block_{i}_causal_2'] = c2[i]
+  for t in range(3):
+    out, c1, c2 = e.pips_mixer(xs[:, t:t + 1], c1, c2, get_ctx=True)
+    ref, octx = O.pips_mlp_mixer(w, xs[:, t:t + 1], 2, True, octx, True)
+    np.testing.assert_allclose(out, ref, atol=2e-4)
+    for i in range(2):
+      np.testing.assert_allclose(c1[i], octx[f'block_{i}_causal_1'], atol=2e-4)
+      np.testing.assert_allclose(c2[i], octx[f'block_{i}_causal_2'], atol=2e-4)
+  e.close()
+
+
+def test_refine_pips_vs_oracle(small_engine):
+  """includes out-of-frame windows and the last_iter (per-frame query) path."""
+  e, w = small_engine
+  rng = np.random.default_rng(8)
+  B, Q, T = 1, 5, 3
+  hires = O.l2_normalize(rng.standard_normal((B, T, 16, 16, 128)).astype(np.float32))
+  lowres = O.l2_normalize(rng.standard_normal((B, T, 8, 8, 256)).astype(np.float32))
+  pyramid = [hires, lowres, O.avg_pool_2x2(lowres)]
+  qh = rng.standard_normal((B, Q, 128)).astype(np.float32)
+  ql = rng.standard_normal((B, Q, 256)).astype(np.float32)
+  queries = [qh, ql, ql]
+  pos = rng.uniform(-6, 70, (B, Q, T, 2)).astype(np.float32)
+  occ = rng.standard_normal((B, Q, T)).astype(np.float32)
+  expd = rng.standard_normal((B, Q, T)).astype(np.float32)
+  for last in (None, rng.standard_normal((B, Q, T, 384)).astype(np.float32)):
+    got = e.refine_pips(queries, pyramid, pos, occ, expd, last, (64, 64), (64, 64))
+    ref = O.refine_pips(w, queries, pyramid, pos, occ, expd, (64, 64), last_iter=last,
+                        resize_hw=(64, 64), num_blocks=2)
+    for a, b in zip(got, ref[:4]):
+      np.testing.assert_allclose(a, b, atol=3e-4)
