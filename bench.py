@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Headline benchmark: tracked points/sec of TAPIR inference on MI355X.
+
+Workload (BASELINE.json configs[1]): one synthetic 256x256x48 clip, 256 query
+points, 4 refinement iterations, random-init TAPIR weights, bf16 GEMM operands.
+A "step" is one full ``TAPIR.__call__`` (ResNet backbone on PyTorch-ROCm ->
+query features -> cost volume -> 4 PIPs iterations in HIP) with the clip
+already resident in HBM.  points/s = clips * queries / seconds.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU (weak scaling, default): every rank tracks its own clip x 256 queries;
+clips are independent units, so there is no data-path collective;
+``--shard queries`` instead runs ONE clip: frame-sharded backbone, RCCL
+all-gather of the feature grids, query-sharded hot path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+``roofline`` (dominant kernel, measured with hipEvents inside the timed region)
+and ``cpu_baseline`` (numpy oracle + torch-CPU backbone on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+MODELS = {
+    # kwargs of the released checkpoints (configs/tapir_config.py:76-81,
+    # configs/tapir_bootstrap_config.py:78-82)
+    'tapir': dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0),
+    'bootstapir': dict(pyramid_level=1, extra_convs=True, softmax_temperature=10.0),
+}
+PEAK_TFLOPS = {'bfloat16': 2500.0, 'float32': 157.3}   # MI355X_MICROARCH.md, dense
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--model', default='tapir', choices=list(MODELS))
+  ap.add_argument('--frames', type=int, default=48)
+  ap.add_argument('--queries', type=int, default=256)
+  ap.add_argument('--size', type=int, default=256)
+  ap.add_argument('--shard', default='clips', choices=['clips', 'queries'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-sample-queries', type=int, default=16)
+  ap.add_argument('--cpu-sample-frames', type=int, default=6)
+  return ap.parse_args()
+
+
+def cpu_baseline(args, kw, weights, video, qpts):
+  """The oracle (numpy port of the reference hot path) + the backbone restatement on torch-CPU,
+  timed on this host's cores on a bounded sample and extrapolated linearly to the workload:
+  backbone cost is per frame, hot-path cost per query (both are independent units)."""
+  from oracle import tapir_oracle as O
+  from tapnet_amd import backbone
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  T, Q = video.shape[1], qpts.shape[1]
+  sf, sq = min(args.cpu_sample_frames, T), min(args.cpu_sample_queries, Q)
+  bb = backbone.Backbone(weights, kw['extra_convs'], 'cpu')
+  frames = torch.as_tensor(video[0, :sf])
+  t0 = time.perf_counter()
+  bb.features(frames)
+  t_bb = (time.perf_counter() - t0) / sf * T
+  # hot path on sq queries, all T frames, from GPU-independent grids (random unit vectors)
+  rng = np.random.default_rng(0)
+  h = args.size // 8
+  low = O.l2_normalize(rng.standard_normal((1, T, h, h, 256)).astype(np.float32))
+  hi = O.l2_normalize(rng.standard_normal((1, T, 2 * h, 2 * h, 128)).astype(np.float32))
+  res = [(args.size, args.size)] * 2
+  t0 = time.perf_counter()
+  O.tapir_from_grids(weights, video.shape, [low, low], [hi, hi], res, qpts[:, :sq],
+                     pyramid_level=kw['pyramid_level'],
+                     softmax_temperature=kw['softmax_temperature'])
+  t_hot = (time.perf_counter() - t0) / sq * Q
+  total = t_bb + t_hot
+  return dict(value=round(Q / total, 3), unit='points/s', cores=cores, kind='port',
+              sample=f'backbone (torch-CPU restatement) on {sf}/{T} frames + numpy oracle hot path '
+                     f'on {sq}/{Q} queries x {T} frames, extrapolated per-frame / per-query',
+              backbone_s=round(t_bb, 2), hot_path_s=round(t_hot, 2))
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+
+  from tapnet_amd import distributed as tdist
+  from tapnet_amd import synthetic, tapir_model
+  kw = MODELS[args.model]
+  dtype = 'bfloat16' if args.dtype == 'bf16' else 'float32'
+  weights = synthetic.make_weights(0, kw['pyramid_level'], kw['extra_convs'])
+  model = tapir_model.TAPIR(**kw, weights=weights, dtype=dtype, device=dev)
+  T, Q, S = args.frames, args.queries, args.size
+  clip_seed = 1 if args.shard == 'queries' else 1 + rank
+  video_np = synthetic.make_video(clip_seed, T, S, S)
+  qpts_np = synthetic.make_queries(100 + clip_seed, Q, T, S, S)
+  video = torch.as_tensor(video_np, device=dev)
+  qpts = torch.as_tensor(qpts_np, device=dev)
+
+  if args.shard == 'queries' and world > 1:
+    step = lambda: tdist.sharded_call(model, video, qpts)
+  else:
+    step = lambda: model(video, False, qpts)
+
+  def barrier():
+    if world > 1:
+      import torch.distributed as dist
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  model.profile_enable(True)
+  model.profile_read()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = step()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  prof = model.profile_read()
+  model.profile_enable(False)
+  if world > 1:
+    import torch.distributed as dist
+    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+  assert torch.isfinite(out['tracks']).all()
+
+  # hot path only (feature grids precomputed): R8 + R1
+  fg = model.get_feature_grids(video)
+  for _ in range(2):
+    model(video, False, qpts, feature_grids=fg)
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  for _ in range(args.steps):
+    model(video, False, qpts, feature_grids=fg)
+  torch.cuda.synchronize()
+  hot_s = (time.perf_counter() - t1) / args.steps
+
+  clips = world if args.shard == 'clips' else 1
+  points = clips * Q
+  ms_per_step = elapsed / args.steps * 1e3
+  value = points / (elapsed / args.steps)
+
+  if rank == 0:
+    R = Q * T if args.shard == 'clips' else (Q // world) * T
+    up_ms, up_n = prof['gemm_up']
+    flops = 2.0 * R * 2048 * 512
+    ach = (flops / (up_ms / up_n * 1e-3) / 1e12) if up_n else None
+    peak = PEAK_TFLOPS[dtype]
+    roof = dict(bound='mfma', kernel='gemm_nt_kernel<mlp2_up: [R,512]x[512,2048]+bias+GELU>',
+                achieved=round(ach, 2) if ach else None, peak=peak, unit='TFLOP/s',
+                frac=round(ach / peak, 4) if ach else None, traffic=None,
+                launches=up_n, avg_us=round(up_ms / up_n * 1e3, 2) if up_n else None,
+                flops_per_launch=flops)
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc):
+      try:
+        roof['traffic'] = json.load(open(pmc)).get('gemm_up_hbm_bytes_per_launch')
+      except Exception:
+        pass
+    kernels = {k: dict(total_ms=round(v[0], 3), launches=v[1],
+                       avg_us=round(v[0] / v[1] * 1e3, 2) if v[1] else None)
+               for k, v in prof.items()}
+    line = dict(
+        metric='tracked points/sec (256x256x48 video, Q=256)', value=round(value, 2),
+        unit='points/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+        scaling='weak' if args.shard == 'clips' else 'strong', vs_baseline=None,
+        dtype='bf16' if dtype == 'bfloat16' else 'f32', data='synthetic',
+        config=dict(workload=f'TAPIR.__call__ ({args.model} kwargs), {S}x{S}x{T} clip, Q={Q}, '
+                             f'4 refinement iters, random-init weights', clips=clips,
+                    shard=args.shard, backbone='PyTorch-ROCm', hot_path='HIP gfx950'),
+        hot_path_ms=round(hot_s * 1e3, 3),
+        hot_path_points_per_s=round(Q / hot_s, 2),
+        point_frames_per_s=round(value * T, 1),
+        roofline=roof, kernels=kernels)
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(args, kw, weights, video_np, qpts_np)
+    print(json.dumps(line))
+  if world > 1:
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

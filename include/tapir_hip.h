@@ -158,6 +158,20 @@ typedef struct tapir_traj_args {
  * reproduced. */
 int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, void* stream);
 
+/* Measurement support (bench.py).  When enabled, every launch of the kernel classes below
+ * is bracketed by two hipEvents recorded on the caller's stream; tapir_profile_read()
+ * synchronises on them and returns the number of launches and their summed duration since
+ * the previous read of that class. */
+#define TAPIR_PROF_GEMM_UP 0    /* mixer mlp2_up GEMM   [R,512]x[512,2048] + bias + GELU  */
+#define TAPIR_PROF_GEMM_DOWN 1  /* mixer mlp2_down GEMM [R,2048]x[2048,512] + bias + skip */
+#define TAPIR_PROF_MIX 2        /* LN + temporal depthwise convs + LN (mix_kernel)         */
+#define TAPIR_PROF_PATCH 3      /* pyramid patch correlation (patch_corr_kernel)           */
+#define TAPIR_PROF_CV_HEADS 4   /* cost-volume heads (cv_heads_kernel)                     */
+#define TAPIR_PROF_CV_GEMM 5    /* cost-volume einsum GEMM                                 */
+#define TAPIR_PROF_KINDS 6
+int tapir_profile_enable(tapir_ctx* ctx, int on);
+int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
+
 /* RCCL all-gather of frame-sharded feature grids over xGMI is
  * done by the host layer with torch.distributed (backend "nccl" == RCCL); the
  * library itself has no collective. */

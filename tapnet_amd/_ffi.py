@@ -73,7 +73,11 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     'tapir_estimate_trajectories': (c_int, [c_void_p, POINTER(TapirTrajArgs), c_void_p]),
+    'tapir_profile_enable': (c_int, [c_void_p, c_int]),
+    'tapir_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
+
+PROF_KINDS = {'gemm_up': 0, 'gemm_down': 1, 'mix': 2, 'patch_corr': 3, 'cv_heads': 4, 'cv_gemm': 5}
 
 
 def declare_prototypes(lib: ctypes.CDLL) -> ctypes.CDLL:

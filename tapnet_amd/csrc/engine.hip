@@ -59,6 +59,12 @@ struct tapir_ctx {
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
   // which caller grid each cast slot currently holds (valid within one call)
   const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
+
+  // optional per-kernel-class timing with hipEvents on the caller's stream
+  bool prof = false;
+  struct ProfEv { hipEvent_t a, b; };
+  std::vector<ProfEv> prof_ev[TAPIR_PROF_KINDS];   // recorded, not yet read
+  std::vector<ProfEv> prof_free;                   // recycled event pairs
 };
 
 namespace {
@@ -67,6 +73,22 @@ int fail(tapir_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
 }
+
+// brackets one kernel launch with events when profiling is on
+struct ProfScope {
+  tapir_ctx* c; int kind; hipStream_t s; tapir_ctx::ProfEv ev; bool on;
+  ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_) : c(c_), kind(kind_), s(s_), on(c_->prof) {
+    if (!on) return;
+    if (!c->prof_free.empty()) { ev = c->prof_free.back(); c->prof_free.pop_back(); }
+    else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(ev.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, s);
+    c->prof_ev[kind].push_back(ev);
+  }
+};
 
 #define HIP_TRY(c, expr)                                                         \
   do {                                                                           \
@@ -186,7 +208,7 @@ int cost_volume_gemm(tapir_ctx* c, const void* qf, const void* grid, int Q, int 
   g.bias = nullptr; g.resid = nullptr; g.ldr = 0;
   g.C = vol; g.ldc = (long)T * hw; g.strideC = 0;
   g.M = Q; g.N = T * hw; g.K = C;
-  launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+  { ProfScope ps(c, TAPIR_PROF_CV_GEMM, s); launch_gemm<TA, float, EPI_BIAS>(g, 1, s); }
   return TAPIR_OK;
 }
 
@@ -199,6 +221,7 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
   a.temperature = c->cfg.softmax_temperature;
   a.img_h = (float)c->cfg.initial_h; a.img_w = (float)c->cfg.initial_w;
   const int pn = (h + 2) * (w + 2), hw = h * w;
+  ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
   if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
     hipLaunchKernelGGL((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps),
                        dim3(CV_THREADS), 0, s, a);
@@ -283,16 +306,17 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     m.ctx1_out = ctx1_out ? ctx1_out + (size_t)i * N * 2 * kHidden : nullptr;
     m.ctx2_out = ctx2_out ? ctx2_out + (size_t)i * N * 2 * kHidden4 : nullptr;
     m.T = T; m.TC = TC; m.causal = c->cfg.use_causal_conv;
-    hipLaunchKernelGGL((mix_kernel<TA>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m);
+    { ProfScope ps(c, TAPIR_PROF_MIX, s);
+      hipLaunchKernelGGL((mix_kernel<TA>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m); }
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
-    launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, 1, s);
+    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, 1, s); }
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
-    launch_gemm<TA, float, EPI_BIAS_RESID>(g2, 1, s);
+    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); launch_gemm<TA, float, EPI_BIAS_RESID>(g2, 1, s); }
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
@@ -327,7 +351,8 @@ int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const 
   pa.mlp_in = c->mlp_in.p; pa.ld = c->k0_pad;
   pa.B = B; pa.Q = Q; pa.T = T;
   pa.orig_h = (float)orig_h; pa.orig_w = (float)orig_w;
-  hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3((unsigned)R), dim3(256), 0, s, pa);
+  { ProfScope ps(c, TAPIR_PROF_PATCH, s);
+    hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3((unsigned)R), dim3(256), 0, s, pa); }
   return TAPIR_OK;
 }
 
@@ -572,6 +597,9 @@ void tapir_destroy(tapir_ctx* c) {
                     &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
+    for (auto& ev : c->prof_ev[k]) c->prof_free.push_back(ev);
+  for (auto& ev : c->prof_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   delete c;
 }
 
@@ -733,6 +761,29 @@ int tapir_refine_pips(tapir_ctx* c, const tapir_pyramid* pyr, int B, int Q, int 
   return DISPATCH(c, do_refine_pips, c, pyr, B, Q, T, pos, occ, expd, last_iter, orig_h, orig_w,
                   resized_h, resized_w, pos_out, occ_out, expd_out, feats_out, ctx1_in, ctx2_in,
                   ctx1_out, ctx2_out, (hipStream_t)stream);
+}
+
+int tapir_profile_enable(tapir_ctx* c, int on) {
+  if (!c) return TAPIR_ERR_INVALID;
+  c->prof = on != 0;
+  return TAPIR_OK;
+}
+
+int tapir_profile_read(tapir_ctx* c, int kind, double* total_ms, int64_t* launches) {
+  if (!c || kind < 0 || kind >= TAPIR_PROF_KINDS || !total_ms || !launches) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double tot = 0.0;
+  for (auto& ev : c->prof_ev[kind]) {
+    HIP_TRY(c, hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+    tot += ms;
+    c->prof_free.push_back(ev);
+  }
+  *total_ms = tot;
+  *launches = (int64_t)c->prof_ev[kind].size();
+  c->prof_ev[kind].clear();
+  return TAPIR_OK;
 }
 
 int tapir_estimate_trajectories(tapir_ctx* c, const tapir_traj_args* a, void* stream) {

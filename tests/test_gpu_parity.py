@@ -1,0 +1,243 @@
+"""`-m gpu`: parity tests proper -- the gfx950 library through the product API
+(tapnet_amd.tapir_model, i.e. through the C ABI) against the oracle and the
+golden fixtures produced by the reference.  Tolerance: 1e-3 abs in fp32
+(north_star), argmax-margin gated where the soft-argmax is discontinuous."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import tapir_oracle as O  # noqa: E402
+from tapnet_amd import synthetic  # noqa: E402
+from tests.golden_util import CASES, load_case, oracle_kwargs  # noqa: E402
+
+
+def _model(cfg, w, dtype='float32', **kw):
+  from tapnet_amd import tapir_model
+  return tapir_model.TAPIR(pyramid_level=cfg['pyramid_level'], extra_convs=cfg['extra_convs'],
+                           softmax_temperature=cfg['softmax_temperature'],
+                           use_causal_conv=cfg['causal'],
+                           initial_resolution=(cfg['res'], cfg['res']), weights=w, dtype=dtype,
+                           device='cuda:0', **kw)
+
+
+def _grids(g):
+  from tapnet_amd import tapir_model
+  return tapir_model.FeatureGrids(tuple(g['lowres']), tuple(g['hires']), tuple(g['res_list']))
+
+
+def bf16_round(x):
+  u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+  u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+  return u.astype(np.uint32).view(np.float32)
+
+
+def test_library_is_native():
+  """the HIP extension must be the thing that runs (no silent fallback)."""
+  from tapnet_amd import _ffi
+  lib = _ffi.load_library()
+  assert b'gfx950' in lib.tapir_version()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_build_cost_volume(dtype):
+  """MFMA fragment layouts on real hardware; asymmetric operands (transpose-detecting)."""
+  cfg, g, w = load_case('tapir')
+  m = _model(cfg, w, dtype)
+  rng = np.random.default_rng(0)
+  qf = rng.standard_normal((2, 150, 256)).astype(np.float32)
+  grid = rng.standard_normal((2, 5, 8, 12, 256)).astype(np.float32)
+  vol = m.build_cost_volume(qf, grid)
+  if dtype == 'bfloat16':
+    qf, grid = bf16_round(qf), bf16_round(grid)
+  ref = O.build_cost_volume(qf, grid)
+  np.testing.assert_allclose(vol, ref, atol=3e-4 if dtype == 'float32' else 3e-3)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_query_features_golden(name):
+  cfg, g, w = load_case(name)
+  m = _model(cfg, w)
+  qf = m.get_query_features(g['video'], False, g['query_points'], _grids(g))
+  for a, b in zip(qf.lowres, g['qlowres']):
+    np.testing.assert_allclose(a.cpu().numpy(), b, atol=2e-6)
+  for a, b in zip(qf.hires, g['qhires']):
+    np.testing.assert_allclose(a.cpu().numpy(), b, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir', 'multires'])
+def test_cost_volume_stage_golden(name):
+  cfg, g, w = load_case(name)
+  m = _model(cfg, w)
+  r = cfg['res'] / cfg['video']
+  qp = g['query_points'] * np.array([1.0, r, r], np.float32)
+  pts, occ, expd = m.tracks_from_cost_volume(g['qlowres'][0], g['lowres'][0], qp)
+  _, _, _, st = O.tracks_from_cost_volume(w, g['qlowres'][0], g['lowres'][0], qp,
+                                          (cfg['res'], cfg['res']), cfg['softmax_temperature'],
+                                          return_stages=True)
+  np.testing.assert_allclose(occ, g['cv_occ'], atol=1e-4)
+  np.testing.assert_allclose(expd, g['cv_expd'], atol=1e-4)
+  ok = st['top2_rel_gap'] > 1e-4
+  assert ok.mean() > 0.95
+  np.testing.assert_allclose(pts[ok], g['cv_points'][ok], atol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir', 'multires'])
+def test_first_refinement_golden(name):
+  cfg, g, w = load_case(name)
+  m = _model(cfg, w)
+  hw = (cfg['res'], cfg['res'])
+  queries = [g['qhires'][1], g['qlowres'][1]]
+  pyramid = [g['hires'][1], g['lowres'][1]]
+  for _ in range(cfg['pyramid_level']):
+    queries.append(queries[-1])
+    pyramid.append(O.avg_pool_2x2(pyramid[-1]))
+  out = m.refine_pips(queries, None, pyramid, g['cv_points'], g['cv_occ'], g['cv_expd'], hw,
+                      last_iter=None, resize_hw=g['res_list'][1])
+  np.testing.assert_allclose(out[0], g['it1_points'], atol=1e-3)
+  np.testing.assert_allclose(out[1], g['it1_occ'], atol=1e-3)
+  np.testing.assert_allclose(out[2], g['it1_expd'], atol=1e-3)
+  np.testing.assert_allclose(out[3], g['it1_feats'], atol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir', 'multires'])
+def test_hot_path_golden(name):
+  """estimate_trajectories from the reference's feature grids vs the reference's outputs."""
+  cfg, g, w = load_case(name)
+  m = _model(cfg, w)
+  fg = _grids(g)
+  qf = m.get_query_features(g['video'], False, g['query_points'], fg)
+  traj = m.estimate_trajectories((cfg['video'], cfg['video']), False, fg, qf, g['query_points'])
+  n_it = 4 * (len(g['res_list']) - 1)
+  for i in range(n_it):
+    np.testing.assert_allclose(traj['tracks'][i], g[f'unrefined_tracks_{i}'], atol=1e-3)
+    np.testing.assert_allclose(traj['occlusion'][i], g[f'unrefined_occlusion_{i}'], atol=1e-3)
+    np.testing.assert_allclose(traj['expected_dist'][i], g[f'unrefined_expected_dist_{i}'], atol=1e-3)
+  out = m(g['video'], False, g['query_points'], feature_grids=fg)
+  np.testing.assert_allclose(out['tracks'], g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(out['occlusion'], g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'], g['expected_dist'], atol=1e-3)
+
+
+def test_causal_streaming_golden():
+  cfg, g, w = load_case('causal')
+  m = _model(cfg, w)
+  fg_all = _grids(g)
+  qf = m.get_query_features(g['video'], False, g['query_points'], fg_all)
+  state = m.construct_initial_causal_state(cfg['Q'], len(g['res_list']) - 1)
+  tr, oc, ex = [], [], []
+  from tapnet_amd import tapir_model
+  for t in range(cfg['T']):
+    fg = tapir_model.FeatureGrids(tuple(torch.as_tensor(x[:, t:t + 1]) for x in g['lowres']),
+                                  tuple(torch.as_tensor(x[:, t:t + 1]) for x in g['hires']),
+                                  tuple(g['res_list']))
+    traj = m.estimate_trajectories((cfg['video'], cfg['video']), False, fg, qf, None,
+                                   causal_context=state, get_causal_context=True)
+    state = traj['causal_context']
+    tr.append(traj['tracks'][-1].cpu().numpy()); oc.append(traj['occlusion'][-1].cpu().numpy())
+    ex.append(traj['expected_dist'][-1].cpu().numpy())
+  np.testing.assert_allclose(np.concatenate(tr, 2), g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(oc, 2), g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(ex, 2), g['expected_dist'], atol=1e-3)
+  np.testing.assert_allclose(state[-1]['block_0_causal_1'].cpu().numpy(),
+                             g['state_last_block_0_causal_1'], atol=1e-3)
+  np.testing.assert_allclose(state[-1]['block_11_causal_2'].cpu().numpy(),
+                             g['state_last_block_11_causal_2'], atol=1e-3)
+  # invariant: streaming == whole-clip causal run (zero left padding), SURVEY 3.2
+  whole = m.estimate_trajectories((cfg['video'], cfg['video']), False, fg_all, qf, None)
+  np.testing.assert_allclose(whole['tracks'][-1], g['tracks'], atol=1e-3)
+
+
+@pytest.mark.parametrize('tag,extra', [('tapir', False), ('boots', True)])
+def test_backbone_golden_gpu(tag, extra):
+  from tests.golden_util import GOLDEN_DIR
+  import os
+  from tapnet_amd import backbone
+  g = np.load(os.path.join(GOLDEN_DIR, 'backbone.npz'))
+  w = synthetic.make_weights(21, 1, extra)
+  bb = backbone.Backbone(w, extra, 'cuda:0')
+  v = torch.as_tensor(g['video']).cuda()
+  low, hi = bb.features(v.reshape(-1, 64, 64, 3))
+  np.testing.assert_allclose(low.cpu().numpy(), g[f'{tag}_lowres'][0], atol=2e-4)
+  np.testing.assert_allclose(hi.cpu().numpy(), g[f'{tag}_hires'][0], atol=2e-4)
+
+
+def test_full_call_golden_with_backbone():
+  """video -> tracks entirely on the GPU vs the reference end to end."""
+  cfg, g, w = load_case('bootstapir')
+  m = _model(cfg, w)
+  out = m(g['video'], False, g['query_points'])
+  np.testing.assert_allclose(out['tracks'], g['tracks'], atol=5e-3)
+  np.testing.assert_allclose(out['occlusion'], g['occlusion'], atol=5e-3)
+
+
+# ---------------------------------------------------------------- full-size properties
+@pytest.fixture(scope='module')
+def config2():
+  """BASELINE.json configs[1] shape: 256x256x48 clip, 256 queries (random-init TAPIR)."""
+  w = synthetic.make_weights(3, pyramid_level=0, extra_convs=False)
+  video = synthetic.make_video(7, 48, 256, 256)
+  qp = synthetic.make_queries(8, 256, 48, 256, 256)
+  return w, video, qp
+
+
+def test_config2_properties(config2):
+  from tapnet_amd import tapir_model
+  w, video, qp = config2
+  m = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0')
+  fg = m.get_feature_grids(torch.as_tensor(video).cuda())
+  out = m(video, False, qp, feature_grids=fg)
+  tr = out['tracks']
+  assert tr.shape == (1, 256, 48, 2) and np.isfinite(tr).all()
+  # (a) query-frame override: unrefined_tracks[0] returns the query verbatim (model_utils.py:294-312)
+  t_q = np.round(qp[0, :, 0]).astype(int)
+  got = out['unrefined_tracks'][0][0, np.arange(256), t_q]
+  np.testing.assert_array_equal(got, qp[0, :, 2:0:-1])
+  # (b) per-query independence (tapnet/tapvid/README.md:32-38): a permuted, split batch gives
+  #     the same tracks -- bitwise, since no arithmetic depends on the batch composition
+  perm = np.random.default_rng(0).permutation(256)
+  a = m(video, False, qp[:, perm[:100]], feature_grids=fg)['tracks']
+  b = m(video, False, qp[:, perm[100:]], feature_grids=fg)['tracks']
+  np.testing.assert_array_equal(np.concatenate([a, b], 1), tr[:, perm])
+  # (c) precomputed feature_grids == recomputed (tapir_model.py:1112)
+  out2 = m(video, False, qp)
+  np.testing.assert_array_equal(out2['tracks'], tr)
+
+
+def test_config1_vs_oracle():
+  """BASELINE.json configs[0] shape (256x256x8, Q=32): HIP hot path vs the oracle, fp32 1e-3."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(4, pyramid_level=0, extra_convs=False)
+  video = synthetic.make_video(9, 8, 256, 256)
+  qp = synthetic.make_queries(10, 32, 8, 256, 256)
+  m = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0')
+  fg = m.get_feature_grids(video)
+  out = m(video, False, qp, feature_grids=fg)
+  lows = [x.cpu().numpy() for x in fg.lowres]; his = [x.cpu().numpy() for x in fg.hires]
+  ref = O.tapir_from_grids(w, video.shape, lows, his, list(fg.resolutions), qp, pyramid_level=0)
+  ql, _ = O.get_query_features(lows, his, list(fg.resolutions), qp, video.shape)
+  _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], qp, return_stages=True)
+  ok = (st['top2_rel_gap'] > 1e-4).all(axis=-1)   # queries whose every frame has a clear argmax
+  assert ok.mean() > 0.9
+  np.testing.assert_allclose(out['tracks'][ok], ref['tracks'][ok], atol=1e-3)
+  np.testing.assert_allclose(out['occlusion'][ok], ref['occlusion'][ok], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'][ok], ref['expected_dist'][ok], atol=1e-3)
+
+
+def test_bf16_close_to_f32(config2):
+  """bf16 speed build vs f32 parity build: bounded drift (median ~8e-3 px)."""
+  from tapnet_amd import tapir_model
+  w, video, qp = config2
+  v, q = video[:, :16], qp[:, :64].copy()
+  q[..., 0] = np.minimum(q[..., 0], 15)
+  m32 = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0')
+  m16 = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0',
+                          dtype='bfloat16')
+  fg = m32.get_feature_grids(v)
+  a = m32(v, False, q, feature_grids=fg)
+  b = m16(v, False, q, feature_grids=fg)
+  d = np.linalg.norm(a['tracks'] - b['tracks'], axis=-1)
+  assert np.median(d) < 0.1, np.median(d)
+  assert np.mean(d < 1.0) > 0.97
+  assert np.median(np.abs(a['occlusion'] - b['occlusion'])) < 0.1

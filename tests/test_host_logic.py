@@ -1,0 +1,98 @@
+"""CPU tests of the host layer: C-ABI symbols, model_utils mirror, backbone
+restatement vs the reference-generated fixture, checkpoint name conversion."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tapnet_amd import _ffi, backbone, model_utils, synthetic, weights
+from tests.golden_util import GOLDEN_DIR
+
+
+def test_abi_symbols_exported():
+  """the gfx950 library loads on a CPU-only host and exports every declared symbol."""
+  if not os.path.exists(_ffi.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  lib = _ffi.declare_prototypes(ctypes.CDLL(_ffi.LIB_PATH))
+  assert b'gfx950' in lib.tapir_version()
+  hdr = open(os.path.join(os.path.dirname(GOLDEN_DIR), '..', 'include', 'tapir_hip.h')).read()
+  for name in _ffi.PROTOTYPES:
+    assert name + '(' in hdr, name
+
+
+def test_product_refuses_cpu():
+  from tapnet_amd import tapir_model
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  with pytest.raises(RuntimeError):
+    tapir_model.TAPIR()
+
+
+def test_generate_default_resolutions():
+  assert model_utils.generate_default_resolutions((256, 256), (256, 256)) == [(256, 256)]
+  assert model_utils.generate_default_resolutions((512, 512), (256, 256)) == [(256, 256), (512, 512)]
+  assert model_utils.generate_default_resolutions((480, 640), (256, 256)) == \
+      [(256, 256), (344, 400), (480, 640)]
+
+
+def test_convert_grid_coordinates_errors():
+  c = np.ones((2, 3), np.float32)
+  with pytest.raises(ValueError):
+    model_utils.convert_grid_coordinates(c, (1, 2, 3), (2, 2, 3), 'tyx')
+  with pytest.raises(ValueError):
+    model_utils.convert_grid_coordinates(c, (1, 2), (2, 2), 'abc')
+  out = model_utils.convert_grid_coordinates(c, (4, 8, 8), (4, 2, 4), 'tyx')
+  np.testing.assert_allclose(out, [[1, 0.25, 0.5]] * 2)
+
+
+def test_postprocess_occlusions():
+  v = model_utils.postprocess_occlusions(np.array([-5.0, 5.0, -5.0]), np.array([-5.0, -5.0, 5.0]))
+  assert v.tolist() == [True, False, False]
+
+
+@pytest.mark.parametrize('tag,extra', [('tapir', False), ('boots', True)])
+def test_backbone_matches_reference_fixture(tag, extra):
+  """R7 restatement (torch ops, CPU here) vs the reference's feature grids."""
+  g = np.load(os.path.join(GOLDEN_DIR, 'backbone.npz'))
+  w = synthetic.make_weights(21, 1, extra)
+  bb = backbone.Backbone(w, extra, 'cpu')
+  low, hi = bb.features(torch.as_tensor(g['video']).reshape(-1, 64, 64, 3))
+  np.testing.assert_allclose(low.numpy(), g[f'{tag}_lowres'][0], atol=2e-5)
+  np.testing.assert_allclose(hi.numpy(), g[f'{tag}_hires'][0], atol=2e-5)
+
+
+def test_haiku_name_conversion_shapes():
+  """round trip: torch-named weights -> fake Haiku params -> torch names."""
+  w = synthetic.make_weights(1, 1, True, num_mixer_blocks=2)
+  hk = {}
+  def conv(name, t): hk[name] = {'w': np.transpose(w[t + '.weight'], (2, 3, 1, 0))}
+  root = 'tapir/~/'
+  for t, h in {'hid1': 'cost_volume_regression_1', 'hid2': 'cost_volume_regression_2',
+               'hid3': 'cost_volume_occlusion_1'}.items():
+    conv(root + h, 'torch_cost_volume_track_mods.' + t)
+    hk[root + h]['b'] = w[f'torch_cost_volume_track_mods.{t}.bias']
+  for t, h in {'hid4': 'cost_volume_occlusion_2', 'occ_out': 'occlusion_out'}.items():
+    hk[root + h] = {'w': w[f'torch_cost_volume_track_mods.{t}.weight'].T,
+                    'b': w[f'torch_cost_volume_track_mods.{t}.bias']}
+  mx = root + 'pips_mlp_mixer/'
+  for t in ('linear', 'linear_1'):
+    hk[mx + t] = {'w': w[f'torch_pips_mixer.{t}.weight'].T, 'b': w[f'torch_pips_mixer.{t}.bias']}
+  hk[mx + 'layer_norm'] = {'scale': w['torch_pips_mixer.layer_norm.weight']}
+  for i in range(2):
+    blk = mx + ('block' if i == 0 else f'block_{i}') + '/'
+    p = f'torch_pips_mixer.blocks.{i}.'
+    hk[blk + 'layer_norm'] = {'scale': w[p + 'layer_norm.weight']}
+    hk[blk + 'layer_norm_1'] = {'scale': w[p + 'layer_norm_1.weight']}
+    for t in ('mlp1_up', 'mlp1_up_1'):
+      hk[blk + t] = {'w': np.transpose(w[p + t + '.weight'], (2, 1, 0)), 'b': w[p + t + '.bias']}
+    for t in ('mlp2_up', 'mlp2_down'):
+      hk[blk + t] = {'w': w[p + f'conv_channels_mixer.{t}.weight'].T,
+                     'b': w[p + f'conv_channels_mixer.{t}.bias']}
+  assert weights.is_haiku_params(hk)
+  back = weights.to_torch_names(hk)
+  for k, v in back.items():
+    np.testing.assert_array_equal(v, w[k])
+  assert 'torch_pips_mixer.blocks.1.mlp1_up.weight' in back

@@ -148,3 +148,47 @@ def test_refine_pips_vs_oracle(small_engine):
                         resize_hw=(64, 64), num_blocks=2)
     for a, b in zip(got, ref[:4]):
       np.testing.assert_allclose(a, b, atol=3e-4)
+
+
+def _run_estimate(e, cfg, g, **kw):
+  return e.estimate_trajectories((cfg['video'], cfg['video']), g['lowres'], g['hires'],
+                                 g['res_list'], g['qlowres'], g['qhires'], g['query_points'], **kw)
+
+
+@pytest.mark.parametrize('name', ['tapir', 'bootstapir', 'multires'])
+def test_estimate_trajectories_golden(name):
+  """Whole hot path (R1) on the emulator vs the reference's outputs."""
+  cfg, g, w = load_case(name)
+  e = EmuEngine(w, pyramid_level=cfg['pyramid_level'], softmax_temperature=cfg['softmax_temperature'],
+                initial_resolution=(cfg['res'], cfg['res']))
+  out = _run_estimate(e, cfg, g)
+  n_it = 4 * (len(g['res_list']) - 1)
+  for i in range(n_it):
+    np.testing.assert_allclose(out['tracks'][i], g[f'unrefined_tracks_{i}'], atol=1e-3)
+    np.testing.assert_allclose(out['occlusion'][i], g[f'unrefined_occlusion_{i}'], atol=1e-3)
+    np.testing.assert_allclose(out['expected_dist'][i], g[f'unrefined_expected_dist_{i}'], atol=1e-3)
+  np.testing.assert_allclose(out['tracks'][4::4].mean(0), g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(out['occlusion'][4::4].mean(0), g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'][4::4].mean(0), g['expected_dist'], atol=1e-3)
+  e.close()
+
+
+def test_causal_streaming_golden():
+  """Online path: one frame per call with the causal state fed back (live_demo.py:62-77)."""
+  cfg, g, w = load_case('causal')
+  e = EmuEngine(w, pyramid_level=1, use_causal_conv=True, softmax_temperature=20.0,
+                initial_resolution=(cfg['res'], cfg['res']))
+  Q = cfg['Q']
+  c1 = np.zeros((4, 12, Q, 2, 512), np.float32); c2 = np.zeros((4, 12, Q, 2, 2048), np.float32)
+  tr, oc = [], []
+  for t in range(cfg['T']):
+    lo = [x[:, t:t + 1] for x in g['lowres']]; hi = [x[:, t:t + 1] for x in g['hires']]
+    out = e.estimate_trajectories((cfg['video'], cfg['video']), lo, hi, g['res_list'],
+                                  g['qlowres'], g['qhires'], None, ctx_in=(c1, c2), get_ctx=True)
+    c1, c2 = out['ctx']
+    tr.append(out['tracks'][-1]); oc.append(out['occlusion'][-1])
+  np.testing.assert_allclose(np.concatenate(tr, 2), g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(oc, 2), g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(c1[-1, 0].reshape(1, Q, 2, 512), g['state_last_block_0_causal_1'], atol=1e-3)
+  np.testing.assert_allclose(c2[-1, 11].reshape(1, Q, 2, 2048), g['state_last_block_11_causal_2'], atol=1e-3)
+  e.close()
