@@ -53,8 +53,8 @@ def parse():
   ap.add_argument('--size', type=int, default=256)
   ap.add_argument('--shard', default='clips', choices=['clips', 'queries'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-sample-queries', type=int, default=16)
-  ap.add_argument('--cpu-sample-frames', type=int, default=6)
+  ap.add_argument('--cpu-sample-queries', type=int, default=48)
+  ap.add_argument('--cpu-sample-frames', type=int, default=12)
   return ap.parse_args()
 
 
@@ -64,8 +64,13 @@ def cpu_baseline(args, kw, weights, video, qpts):
   backbone cost is per frame, hot-path cost per query (both are independent units)."""
   from oracle import tapir_oracle as O
   from tapnet_amd import backbone
-  cores = os.cpu_count() or 1
+  cores = min(os.cpu_count() or 1, 32)   # more threads only add contention for these sizes
   torch.set_num_threads(cores)
+  try:
+    import threadpoolctl
+    threadpoolctl.threadpool_limits(cores)
+  except Exception:
+    pass
   T, Q = video.shape[1], qpts.shape[1]
   sf, sq = min(args.cpu_sample_frames, T), min(args.cpu_sample_queries, Q)
   bb = backbone.Backbone(weights, kw['extra_convs'], 'cpu')
@@ -156,6 +161,14 @@ def main():
   torch.cuda.synchronize()
   hot_s = (time.perf_counter() - t1) / args.steps
 
+  # backbone only (R7, PyTorch-ROCm)
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  for _ in range(args.steps):
+    model.get_feature_grids(video)
+  torch.cuda.synchronize()
+  bb_s = (time.perf_counter() - t2) / args.steps
+
   clips = world if args.shard == 'clips' else 1
   points = clips * Q
   ms_per_step = elapsed / args.steps * 1e3
@@ -190,7 +203,7 @@ def main():
         config=dict(workload=f'TAPIR.__call__ ({args.model} kwargs), {S}x{S}x{T} clip, Q={Q}, '
                              f'4 refinement iters, random-init weights', clips=clips,
                     shard=args.shard, backbone='PyTorch-ROCm', hot_path='HIP gfx950'),
-        hot_path_ms=round(hot_s * 1e3, 3),
+        hot_path_ms=round(hot_s * 1e3, 3), backbone_ms=round(bb_s * 1e3, 3),
         hot_path_points_per_s=round(Q / hot_s, 2),
         point_frames_per_s=round(value * T, 1),
         roofline=roof, kernels=kernels)
