@@ -7,4 +7,4 @@ c = sqlite3.connect(sys.argv[1])
 cur = c.execute('select name, total_calls, total_duration, average, percentage from top_kernels')
 print('kernel,calls,total_us,avg_us,percent')
 for name, calls, tot, avg, pct in cur.fetchall():
-  print(f'"{name}",{calls},{tot / 1e3:.1f},{avg / 1e3:.2f},{pct:.2f}')
+  print(f'"{name[:140]}",{calls},{tot:.1f},{avg:.2f},{pct:.2f}')   # the view reports microseconds
