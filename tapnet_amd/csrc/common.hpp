@@ -36,6 +36,15 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The hardware writes to
+// M0 (the FIRST lane's LDS address) + lane * 16: `lds` must be wave-uniform base + lane*16;
+// the global address is free per lane.  Completion is tracked by vmcnt; __syncthreads() drains it.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void glds16(const void* gptr, void* lds) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)gptr, (lds_ptr_t)(uintptr_t)lds, 16, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32);
   v += __shfl_xor(v, 16);

@@ -268,12 +268,11 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
 }
 
 int pick_time_chunk(int N, int T) {
-  int nch = 1;
-  if (T > 16) {
-    nch = (512 + N - 1) / N;
-    nch = std::max(1, std::min(nch, (T + 7) / 8));
-  }
-  nch = std::max(nch, (T + MIX_MAX_TC - 1) / MIX_MAX_TC);
+  // enough workgroups to fill 256 CUs x 4, chunks of at most MIX_MAX_TC frames, at least ~6
+  // frames per chunk so the halo recompute stays small
+  int nch = (T + MIX_MAX_TC - 1) / MIX_MAX_TC;
+  const int want = std::min((1024 + N - 1) / N, (T + 5) / 6);
+  nch = std::max(nch, std::max(1, want));
   return (T + nch - 1) / nch;
 }
 

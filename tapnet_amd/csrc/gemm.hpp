@@ -9,11 +9,18 @@
 //
 // Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
 // 4x4 MFMA 16x16 fragments, 64 accumulator VGPRs).  K-step = 128 bytes per row
-// (64 bf16 / 32 f32), LDS double-buffered (2 x 32 KiB), global->register->LDS
-// staging with the loads for tile k+1 issued before the MFMAs of tile k.
-// LDS rows are 128 B = eight 16-B chunks; chunk c of row r is stored at
-// c ^ (r & 7) so that the ds_read_b128 fragment reads (16 rows x one chunk)
-// spread over all banks (cdna_hip_programming.md T2 / Guideline 4).
+// (64 bf16 / 32 f32), LDS double-buffered (2 x 32 KiB).  Tiles are staged with
+// the LDS DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): the
+// copy of tile k+1 is issued before the MFMAs of tile k and drained by the
+// barrier that ends the step.  LDS rows are 128 B = eight 16-B chunks; physical
+// chunk p of row r holds logical chunk p ^ (r & 7) -- the DMA writes LDS
+// lane-linearly, so the swizzle is applied to the per-lane SOURCE address and
+// again on the ds_read_b128 fragment reads (cdna_hip_programming.md rule 21 /
+// T2), which then spread over all banks.
+//
+// Workgroups are numbered so that the ones sharing an A row-panel are
+// consecutive on ONE XCD (block b runs on XCD b % 8): the panel is fetched into
+// that XCD's private L2 once instead of up to eight times (T1).
 //
 // Operand roles are swapped in the MFMA (W rows feed the "A" port, activation
 // rows the "B" port), so a lane ends up with 4 CONSECUTIVE output columns of
@@ -74,30 +81,23 @@ template <> struct Store4<bf16_t> {
   }
 };
 
+// Issues the LDS-DMA copies of one k-step: rows 0..127 = A rows m0.., rows 128..255 = W rows
+// n0..; 2048 16-byte chunks, 8 per thread, chunk id = s*256 + tid (lane-linear in LDS).
+// Rows past M / N are clamped to the last valid row (their products are never stored).
 template <typename TA>
-__device__ __forceinline__ void gemm_load_tile(const TA* __restrict__ A, const TA* __restrict__ W,
-                                               long lda, long ldw, int M, int N, int m0, int n0,
-                                               int k0, int tid, uint4 (&ra)[4], uint4 (&rw)[4]) {
+__device__ __forceinline__ void gemm_stage_tile(const TA* __restrict__ A, const TA* __restrict__ W,
+                                                long lda, long ldw, int M, int N, int m0, int n0,
+                                                int k0, int tid, uint4* lds) {
   constexpr int EPC = 16 / (int)sizeof(TA);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < 8; ++s) {
     const int id = tid + GEMM_THREADS * s;
-    const int row = id >> 3, c = id & 7;
-    const int gm = m0 + row, gn = n0 + row;
-    ra[s] = make_uint4(0u, 0u, 0u, 0u);
-    rw[s] = make_uint4(0u, 0u, 0u, 0u);
-    if (gm < M) ra[s] = *reinterpret_cast<const uint4*>(A + (long)gm * lda + k0 + c * EPC);
-    if (gn < N) rw[s] = *reinterpret_cast<const uint4*>(W + (long)gn * ldw + k0 + c * EPC);
-  }
-}
-__device__ __forceinline__ void gemm_store_tile(uint4* lds, int tid, const uint4 (&ra)[4],
-                                                const uint4 (&rw)[4]) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int id = tid + GEMM_THREADS * s;
-    const int row = id >> 3, c = id & 7;
-    lds[row * 8 + (c ^ (row & 7))] = ra[s];
-    lds[(GEMM_BM + row) * 8 + (c ^ (row & 7))] = rw[s];
+    const int row = id >> 3, p = id & 7;
+    const int c = p ^ (row & 7);
+    const TA* src;
+    if (s < 4) src = A + (long)min(m0 + row, M - 1) * lda + k0 + c * EPC;
+    else src = W + (long)min(n0 + row - GEMM_BM, N - 1) * ldw + k0 + c * EPC;
+    glds16(src, lds + id);
   }
 }
 
@@ -112,14 +112,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GEMM_BM;
-  const int n0 = blockIdx.x * GEMM_BN;
+  // XCD-aware numbering: hardware block b -> XCD b % 8; give every XCD a contiguous range of
+  // logical tiles, N fastest, so tiles sharing an A panel follow each other on one XCD.
+  const int tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int m0 = (logical / tiles_n) * GEMM_BM;
+  const int n0 = (logical % tiles_n) * GEMM_BN;
   const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A) + (long)blockIdx.z * g.strideA;
   const TA* __restrict__ W = reinterpret_cast<const TA*>(g.W) + (long)blockIdx.z * g.strideW;
   TO* __restrict__ C = reinterpret_cast<TO*>(g.C) + (long)blockIdx.z * g.strideC;
 
-  // staging assignment: chunk id = tid + 256*s -> row = id>>3, chunk = id&7
-  uint4 ra[4], rw[4];
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -127,16 +132,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  gemm_load_tile<TA>(A, W, g.lda, g.ldw, g.M, g.N, m0, n0, 0, tid, ra, rw);
-  gemm_store_tile(lds[0], tid, ra, rw);
-  __syncthreads();
+  gemm_stage_tile<TA>(A, W, g.lda, g.ldw, g.M, g.N, m0, n0, 0, tid, lds[0]);
+  __syncthreads();   // drains the DMA (vmcnt) and makes the tile visible to every wave
 
   const int fr = lane & 15;   // fragment row handled by this lane
   const int fg = lane >> 4;   // k lane-group
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk)   // in flight during the MFMAs below
-      gemm_load_tile<TA>(A, W, g.lda, g.ldw, g.M, g.N, m0, n0, (kt + 1) * BK, tid, ra, rw);
+    if (kt + 1 < nk)   // DMA of the next tile into the other buffer, in flight during the MFMAs
+      gemm_stage_tile<TA>(A, W, g.lda, g.ldw, g.M, g.N, m0, n0, (kt + 1) * BK, tid, lds[buf ^ 1]);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int c = kk * 4 + fg;
@@ -156,8 +160,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) MfmaStep<TA>::run(fw[j], fa[i], acc[i][j]);
     }
-    if (kt + 1 < nk) gemm_store_tile(lds[buf ^ 1], tid, ra, rw);   // buf^1 was last read before the previous barrier
-    __syncthreads();
+    __syncthreads();   // next tile landed; everyone is done reading `buf`
   }
 
   // epilogue: lane holds C[m = .. + (l&15)][n = .. + 4*(l>>4) + 0..3]
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm(const GemmArgs& g, int batch, hipStream_t stream) {
-  dim3 grid((g.N + GEMM_BN - 1) / GEMM_BN, (g.M + GEMM_BM - 1) / GEMM_BM, batch);
+  dim3 grid(((g.N + GEMM_BN - 1) / GEMM_BN) * ((g.M + GEMM_BM - 1) / GEMM_BM), 1, batch);
   hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI>), grid, dim3(GEMM_THREADS), 0, stream, g);
 }
 

@@ -11,11 +11,13 @@
 // from the causal context, zeros if there is none) :64,80,49-53,69-73.
 #pragma once
 #include "common.hpp"
+#include "gemm.hpp"   // Store4
 
 namespace tapir {
 
 constexpr int MIX_THREADS = 256;     // 2 channels per thread x 256 = 512
-constexpr int MIX_MAX_TC = 64;       // max frames per time chunk
+constexpr int MIX_MAX_TC = 16;       // max frames per time chunk
+constexpr int MIX_MAX_ROWS = MIX_MAX_TC + 4;   // + halo rows (2 each side / 4 on the left if causal)
 constexpr float kLnEps = 1e-5f;      // hk.LayerNorm default
 
 struct MixArgs {
@@ -37,21 +39,29 @@ struct MixArgs {
   int causal;             // use_causal_conv
 };
 
-// block-wide sum of one float per thread; `slot` alternates so that consecutive
-// calls need a single barrier each.
-__device__ __forceinline__ float block_sum_256(float v, float (*red)[4], int slot) {
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) red[slot][threadIdx.x >> 6] = v;
-  __syncthreads();
-  return red[slot][0] + red[slot][1] + red[slot][2] + red[slot][3];
+// Row statistics by ONE wave: the lane holds channels [4*lane, 4*lane+4) and
+// [256+4*lane, 256+4*lane+4) of the row.
+__device__ __forceinline__ void wave_row_stats(const float4& u, const float4& v, float& mean,
+                                               float& rstd) {
+  mean = wave_sum((u.x + u.y) + (u.z + u.w) + (v.x + v.y) + (v.z + v.w)) * (1.0f / kHidden);
+  const float d0 = u.x - mean, d1 = u.y - mean, d2 = u.z - mean, d3 = u.w - mean;
+  const float d4 = v.x - mean, d5 = v.y - mean, d6 = v.z - mean, d7 = v.w - mean;
+  const float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
+  rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kHidden) + kLnEps);
 }
 
+// One workgroup = one track x one time chunk.  The chunk's input rows (with
+// halo) are staged in LDS by one fully parallel, coalesced pass, so that no
+// step of the temporal recurrence waits on global memory:
+//   0. rows [xlo, xhi] -> LDS                      (all loads in flight at once)
+//   1. LayerNorm-1 statistics, one wave per row    (shuffles only)
+//   2. temporal stream, 2 channels per thread      (registers; x_new written back into LDS)
+//   3. LayerNorm-2 + stores, one wave per row      (16-byte coalesced stores)
 template <typename TO>
 __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
-  __shared__ float s_part[MIX_MAX_TC + 8][4];
-  __shared__ float s_mean[MIX_MAX_TC + 8];
-  __shared__ float s_rstd[MIX_MAX_TC + 8];
-  __shared__ float s_red[4][4];
+  __shared__ float s_x[MIX_MAX_ROWS][kHidden];   // 40 KiB
+  __shared__ float s_mean[MIX_MAX_ROWS];
+  __shared__ float s_rstd[MIX_MAX_ROWS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -60,41 +70,46 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   const int t0 = blockIdx.x * a.TC;
   const int t1 = min(T, t0 + a.TC);
   const int off0 = a.causal ? -2 : -1;        // tap k reads frame t + off0 + k
-  const int c0 = tid * 2;                      // this thread's two channels
+  const int c0 = tid * 2;                      // this thread's two channels in phase 2
   const float* __restrict__ xin = a.x_in + (long)n * T * kHidden;
 
-  // ---- phase 1: LayerNorm statistics of every input row this chunk touches
+  // ---- phase 0: stage every input row this chunk touches
   const int xlo = max(0, t0 + 2 * off0);
   const int xhi = min(T - 1, t1 - 1 + 2 * off0 + 4);
   const int nrows = xhi - xlo + 1;
-  for (int r = 0; r < nrows; ++r) {
-    const float2 v = *reinterpret_cast<const float2*>(xin + (long)(xlo + r) * kHidden + c0);
-    const float s = wave_sum(v.x + v.y);
-    if (lane == 0) s_part[r][wave] = s;
+  {
+    const float4* src = reinterpret_cast<const float4*>(xin + (long)xlo * kHidden);
+    float4* dst = reinterpret_cast<float4*>(&s_x[0][0]);
+    const int total = nrows * (kHidden / 4);
+    float4 tmp[MIX_MAX_ROWS / 2];
+#pragma unroll
+    for (int k = 0; k < MIX_MAX_ROWS / 2; ++k) {
+      const int idx = tid + k * MIX_THREADS;
+      if (idx < total) tmp[k] = src[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < MIX_MAX_ROWS / 2; ++k) {
+      const int idx = tid + k * MIX_THREADS;
+      if (idx < total) dst[idx] = tmp[k];
+    }
   }
   __syncthreads();
-  if (tid < nrows)
-    s_mean[tid] = (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]) * (1.0f / kHidden);
-  __syncthreads();
-  for (int r = 0; r < nrows; ++r) {
-    const float2 v = *reinterpret_cast<const float2*>(xin + (long)(xlo + r) * kHidden + c0);
-    const float m = s_mean[r];
-    const float s = wave_sum((v.x - m) * (v.x - m) + (v.y - m) * (v.y - m));
-    if (lane == 0) s_part[r][wave] = s;
-  }
-  __syncthreads();
-  if (tid < nrows) {
-    const float var = (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]) * (1.0f / kHidden);
-    s_rstd[tid] = 1.0f / sqrtf(var + kLnEps);
+
+  // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
+  for (int r = wave; r < nrows; r += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
+    const float4 v = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
+    float mean, rstd;
+    wave_row_stats(u, v, mean, rstd);
+    if (lane == 0) { s_mean[r] = mean; s_rstd[r] = rstd; }
   }
   __syncthreads();
 
   // ---- per-thread weights (2 channels x 4 multipliers x 3 taps, twice)
-  float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2], sc2[2];
+  float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     sc1[ch] = a.ln1[c0 + ch];
-    sc2[ch] = a.ln2[c0 + ch];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int o = 4 * (c0 + ch) + m;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   // LN1(x)[tau, c0..c0+1]; outside the clip: causal context or zeros
   auto load_xn = [&](int tau, float& o0, float& o1) {
     if (tau >= 0 && tau < T) {
-      const float2 v = *reinterpret_cast<const float2*>(xin + (long)tau * kHidden + c0);
+      const float2 v = *reinterpret_cast<const float2*>(&s_x[tau - xlo][c0]);
       const float m = s_mean[tau - xlo], rs = s_rstd[tau - xlo];
       o0 = (v.x - m) * rs * sc1[0];
       o1 = (v.y - m) * rs * sc1[1];
@@ -135,9 +150,9 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   load_xn(g_lo + off0, xw[0][0], xw[1][0]);
   load_xn(g_lo + off0 + 1, xw[0][1], xw[1][1]);
 
+  // ---- phase 2: temporal stream
   for (int tau = g_lo; tau <= g_hi; ++tau) {
     load_xn(tau + off0 + 2, xw[0][2], xw[1][2]);
-    // g(tau): GELU(conv1(LN1 x)) inside the clip, causal context / zeros outside
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
         gw[ch][m][0] = gw[ch][m][1];
         gw[ch][m][1] = gw[ch][m][2];
       }
+    // g(tau): GELU(conv1(LN1 x)) inside the clip, causal context / zeros outside
     if (tau >= 0 && tau < T) {
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch)
@@ -171,9 +187,10 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) { xw[ch][0] = xw[ch][1]; xw[ch][1] = xw[ch][2]; }
 
-    // output frame whose last tap is g(tau)
+    // output frame whose last tap is g(tau): x_new = x + sum_m conv2(g)  (in place in LDS;
+    // this thread is the only reader/writer of its two channels during the stream)
     const int t = tau - off0 - 2;
-    if (t >= t0 && t < t1) {   // uniform over the workgroup
+    if (t >= t0 && t < t1) {
       float y[2];
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
@@ -188,19 +205,9 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
         }
         y[ch] = acc;
       }
-      const float2 xv = *reinterpret_cast<const float2*>(xin + (long)t * kHidden + c0);
-      const float x0 = xv.x + y[0], x1 = xv.y + y[1];
-      const long row = (long)n * T + t;
-      *reinterpret_cast<float2*>(a.x_out + row * kHidden + c0) = make_float2(x0, x1);
-      // LN2 over the 512 channels of this frame
-      const int slot = (t & 1) * 2;
-      const float mean = block_sum_256(x0 + x1, s_red, slot) * (1.0f / kHidden);
-      const float d0 = x0 - mean, d1 = x1 - mean;
-      const float var = block_sum_256(d0 * d0 + d1 * d1, s_red, slot + 1) * (1.0f / kHidden);
-      const float rs = 1.0f / sqrtf(var + kLnEps);
-      TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden + c0;
-      Elem<TO>::st(o, d0 * rs * sc2[0]);
-      Elem<TO>::st(o + 1, d1 * rs * sc2[1]);
+      float2* px = reinterpret_cast<float2*>(&s_x[t - xlo][c0]);
+      const float2 xv = *px;
+      *px = make_float2(xv.x + y[0], xv.y + y[1]);
     }
   }
 
@@ -216,6 +223,26 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
       *reinterpret_cast<float4*>(p) = make_float4(gw[0][0][1 + j], gw[0][1][1 + j], gw[0][2][1 + j], gw[0][3][1 + j]);
       *reinterpret_cast<float4*>(p + 4) = make_float4(gw[1][0][1 + j], gw[1][1][1 + j], gw[1][2][1 + j], gw[1][3][1 + j]);
     }
+  }
+  __syncthreads();
+
+  // ---- phase 3: LayerNorm-2 and stores, wave w takes output rows t0+w, t0+w+4, ...
+  const float4 s2a = *reinterpret_cast<const float4*>(a.ln2 + lane * 4);
+  const float4 s2b = *reinterpret_cast<const float4*>(a.ln2 + 256 + lane * 4);
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(&s_x[t - xlo][lane * 4]);
+    const float4 v = *reinterpret_cast<const float4*>(&s_x[t - xlo][256 + lane * 4]);
+    float mean, rs;
+    wave_row_stats(u, v, mean, rs);
+    const long row = (long)n * T + t;
+    float* xo = a.x_out + row * kHidden;
+    *reinterpret_cast<float4*>(xo + lane * 4) = u;
+    *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v;
+    TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
+    Store4<TO>::run(o + lane * 4, (u.x - mean) * rs * s2a.x, (u.y - mean) * rs * s2a.y,
+                    (u.z - mean) * rs * s2a.z, (u.w - mean) * rs * s2a.w);
+    Store4<TO>::run(o + 256 + lane * 4, (v.x - mean) * rs * s2b.x, (v.y - mean) * rs * s2b.y,
+                    (v.z - mean) * rs * s2b.z, (v.w - mean) * rs * s2b.w);
   }
 }
 

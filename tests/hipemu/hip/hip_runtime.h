@@ -425,6 +425,27 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(
   return out;
 }
 
+// ---------------------------------------------------------------- LDS DMA
+// global_load_lds: every lane copies `size` bytes to (first lane's LDS address + lane*size).
+// The emulator copies synchronously and CHECKS the addressing rule the hardware imposes.
+static inline void __builtin_amdgcn_global_load_lds(
+    const __attribute__((address_space(1))) void* gptr, __attribute__((address_space(3))) void* lptr,
+    unsigned size, int offset, unsigned aux) {
+  (void)aux;
+  uintptr_t l = (uintptr_t)lptr + (uintptr_t)offset;
+  uintptr_t g = (uintptr_t)gptr + (uintptr_t)offset;
+  uintptr_t base = 0;
+  hipemu::wave_collective(
+      [&](hipemu::WaveBuf& wb, unsigned lane) { memcpy(&wb.v[lane][0], &l, sizeof(l)); },
+      [&](hipemu::WaveBuf&) {},
+      [&](hipemu::WaveBuf& wb, unsigned lane) { (void)lane; memcpy(&base, &wb.v[0][0], sizeof(base)); });
+  if (l != base + (uintptr_t)hipemu_lane() * size) {
+    fprintf(stderr, "hipemu: global_load_lds destination is not wave-uniform base + lane*size\n");
+    abort();
+  }
+  memcpy((void*)l, (const void*)g, size);
+}
+
 // ---------------------------------------------------------------- misc device math
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
