@@ -172,6 +172,21 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 
+/* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
+ * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):
+ * A [M,lda], W [N,ldw] in the context's operand type (f32 or bf16 bits), bias [N] f32 or NULL;
+ * epi 0: C f32 = acc + bias;  1: C operand type = gelu_tanh(acc + bias);
+ * 2: C f32 = acc + bias + resid [M,ldr] f32.  tile: 0 = automatic, 1 = 192x128, 2 = 128x128,
+ * 3 = 192x64; bits 8.. of `tile`, when non-zero, cap the persistent grid (tests).  K must be a multiple of 64 (bf16) / 32 (f32); N, ldc multiples of 4. */
+int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, long ldw,
+                     const float* bias, const float* resid, long ldr, void* C, long ldc,
+                     int M, int N, int K, int epi, int tile, void* stream);
+/* One launch of the token-mixing kernel of mixer block `block` (LN, temporal depthwise
+ * convs, GELU, group sum, skip, LN): x_in [N,T,512] f32 -> x_out [N,T,512] f32 and
+ * xn [N*T,512] in the operand type.  Non-causal contexts only. */
+int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
+                    int N, int T, void* stream);
+
 /* RCCL all-gather of frame-sharded feature grids over xGMI is
  * done by the host layer with torch.distributed (backend "nccl" == RCCL); the
  * library itself has no collective. */

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_long, c_void_p
 
 TAPIR_OK = 0
 TAPIR_ERR_INVALID = -1
@@ -73,6 +73,11 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     'tapir_estimate_trajectories': (c_int, [c_void_p, POINTER(TapirTrajArgs), c_void_p]),
+    'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                                 c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    'tapir_debug_mix': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p]),
     'tapir_profile_enable': (c_int, [c_void_p, c_int]),
     'tapir_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }

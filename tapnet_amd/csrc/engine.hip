@@ -203,12 +203,12 @@ template <typename TA>
 int cost_volume_gemm(tapir_ctx* c, const void* qf, const void* grid, int Q, int T, int hw, int C,
                      float* vol, hipStream_t s) {
   GemmArgs g{};
-  g.A = qf; g.lda = C; g.strideA = 0;
-  g.W = grid; g.ldw = C; g.strideW = 0;
+  g.A = qf; g.lda = C;
+  g.W = grid; g.ldw = C;
   g.bias = nullptr; g.resid = nullptr; g.ldr = 0;
-  g.C = vol; g.ldc = (long)T * hw; g.strideC = 0;
+  g.C = vol; g.ldc = (long)T * hw;
   g.M = Q; g.N = T * hw; g.K = C;
-  { ProfScope ps(c, TAPIR_PROF_CV_GEMM, s); launch_gemm<TA, float, EPI_BIAS>(g, 1, s); }
+  { ProfScope ps(c, TAPIR_PROF_CV_GEMM, s); launch_gemm<TA, float, EPI_BIAS>(g, s); }
   return TAPIR_OK;
 }
 
@@ -291,7 +291,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g{};
     g.A = c->mlp_in.p; g.lda = c->k0_pad; g.W = c->W0; g.ldw = c->k0_pad; g.bias = c->b0;
     g.C = c->xa.p; g.ldc = kHidden; g.M = (int)R; g.N = kHidden; g.K = c->k0_pad;
-    launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+    launch_gemm<TA, float, EPI_BIAS>(g, s);
   }
   const int TC = pick_time_chunk(N, T);
   const int nch = (T + TC - 1) / TC;
@@ -310,19 +310,19 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, 1, s); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, s); }
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); launch_gemm<TA, float, EPI_BIAS_RESID>(g2, 1, s); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); launch_gemm<TA, float, EPI_BIAS_RESID>(g2, s); }
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
   GemmArgs g{};
   g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
   g.C = c->res.p; g.ldc = kMixOut; g.M = (int)R; g.N = kMixOut; g.K = kHidden;
-  launch_gemm<TA, float, EPI_BIAS>(g, 1, s);
+  launch_gemm<TA, float, EPI_BIAS>(g, s);
   return TAPIR_OK;
 }
 
@@ -782,6 +782,47 @@ int tapir_profile_read(tapir_ctx* c, int kind, double* total_ms, int64_t* launch
   *total_ms = tot;
   *launches = (int64_t)c->prof_ev[kind].size();
   c->prof_ev[kind].clear();
+  return TAPIR_OK;
+}
+
+int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long ldw,
+                     const float* bias, const float* resid, long ldr, void* C, long ldc, int M,
+                     int N, int K, int epi, int tile, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int kstep = c->cfg.dtype == TAPIR_BF16 ? 64 : 32;
+  if (!A || !W || !C || M < 1 || N < 4 || K < kstep || K % kstep || N % 4 || ldc % 4 || epi < 0 ||
+      epi > 2 || tile < 0 || (tile & 0xff) > 3 || (epi == 2 && !resid))
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  const int mg = tile >> 8;   // test hook: cap the persistent grid (forces several tiles per workgroup)
+  tile &= 0xff;
+  if (epi == 0) { if (bf) launch_gemm<bf16_t, float, EPI_BIAS>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS>(g, s, tile, mg); }
+  else if (epi == 1) { if (bf) launch_gemm<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_GELU>(g, s, tile, mg); }
+  else { if (bf) launch_gemm<bf16_t, float, EPI_BIAS_RESID>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_RESID>(g, s, tile, mg); }
+  return TAPIR_OK;
+}
+
+int tapir_debug_mix(tapir_ctx* c, int block, const float* x_in, float* x_out, void* xn, int N,
+                    int T, void* stream) {
+  REQUIRE_READY(c);
+  if (block < 0 || block >= (int)c->blocks.size() || !x_in || !x_out || !xn || N < 1 || T < 1 ||
+      x_in == x_out)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  const BlockW& bw = c->blocks[block];
+  MixArgs m{};
+  m.x_in = x_in; m.x_out = x_out; m.xn2 = xn;
+  m.ln1 = bw.ln1; m.w1 = bw.w1; m.b1 = bw.b1; m.w2 = bw.w2; m.b2 = bw.b2; m.ln2 = bw.ln2;
+  m.T = T; m.TC = pick_time_chunk(N, T); m.causal = c->cfg.use_causal_conv;
+  const int nch = (T + m.TC - 1) / m.TC;
+  if (c->cfg.dtype == TAPIR_BF16)
+    hipLaunchKernelGGL((mix_kernel<bf16_t>), dim3(nch, N), dim3(MIX_THREADS), 0, (hipStream_t)stream, m);
+  else
+    hipLaunchKernelGGL((mix_kernel<float>), dim3(nch, N), dim3(MIX_THREADS), 0, (hipStream_t)stream, m);
   return TAPIR_OK;
 }
 

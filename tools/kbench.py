@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on one MI355X: every hot kernel of the TAPIR path at the
+config-2 shapes (256 queries x 48 frames = 12288 token rows), timed with events on the
+launch stream, checked against a torch reference, reported against the roofline.
+
+    python tools/kbench.py [--what gemm,mix,mixer,backbone] [--reps 40] [--out gpurun_out/kbench.json]
+
+GEMM rows: every tile shape of gemm.hpp (tapir_debug_gemm hook) on the mixer shapes
+(up: [R,512]x[512,2048]+GELU -> bf16; down: [R,2048]x[2048,512]+skip -> f32), the first /
+last linear and the cost-volume einsum.  Buffers rotate over three sets so that inputs are
+not trivially L2-resident.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from tapnet_amd import _ffi, synthetic, tapir_model
+
+TILES = {1: '192x128', 2: '128x128', 3: '192x64'}
+R = 256 * 48
+
+
+def timeit(fn, reps, warm=5):
+  for _ in range(warm):
+    fn(0)
+  torch.cuda.synchronize()
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+  for i, (a, b) in enumerate(evs):
+    a.record()
+    fn(i)
+    b.record()
+  torch.cuda.synchronize()
+  t = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+  return dict(med_us=round(t[len(t) // 2], 2), min_us=round(t[0], 2), p90_us=round(t[int(len(t) * 0.9)], 2))
+
+
+def timeit_batch(fn, reps, warm=3):
+  """back-to-back launches between two events (no per-launch event overhead)"""
+  for _ in range(warm):
+    fn(0)
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  a.record()
+  for i in range(reps):
+    fn(i)
+  b.record()
+  torch.cuda.synchronize()
+  return round(a.elapsed_time(b) * 1e3 / reps, 2)
+
+
+def gelu_tanh(x):
+  return torch.nn.functional.gelu(x, approximate='tanh')
+
+
+def bench_gemm(model, reps, results):
+  lib, ctx = model._lib, model._ctx
+  bf = model.dtype == 'bfloat16'
+  tdt = torch.bfloat16 if bf else torch.float32
+  dev = model.device
+  stream = model._stream()
+  shapes = [('up', R, 2048, 512, 1), ('down', R, 512, 2048, 2), ('first', R, 512, 576, 0),
+            ('last', R, 388, 512, 0), ('costvol', 256, 49152, 256, 0)]
+  g = torch.Generator(device='cpu').manual_seed(0)
+  for name, M, N, K, epi in shapes:
+    nset = 3
+    A = [(torch.randn(M, K, generator=g) * 1.0).to(dev, tdt) for _ in range(nset)]
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev, tdt)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev) if epi == 2 else None
+    out_dt = tdt if epi == 1 else torch.float32
+    C = [torch.empty(M, N, device=dev, dtype=out_dt) for _ in range(nset)]
+    ref = A[0].float() @ W.float().t() + bias
+    if epi == 1:
+      ref = gelu_tanh(ref)
+    if epi == 2:
+      ref = ref + resid
+    flops = 2.0 * M * N * K
+    es = 2 if bf else 4
+    bytes_alg = M * K * es + N * K * es + M * N * (es if epi == 1 else 4) + (M * N * 4 if epi == 2 else 0)
+    for tile, tname in TILES.items():
+      def run(i, tile=tile):
+        k = i % nset
+        rc = lib.tapir_debug_gemm(ctx, A[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(),
+                                  resid.data_ptr() if resid is not None else None, N,
+                                  C[k].data_ptr(), N, M, N, K, epi, tile, stream)
+        assert rc == 0, lib.tapir_last_error(ctx)
+      run(0)
+      torch.cuda.synchronize()
+      err = float((C[0].float() - ref).abs().max())
+      t = timeit(run, reps)
+      tb = timeit_batch(run, reps)
+      row = dict(kernel=f'gemm_{name}', tile=tname, M=M, N=N, K=K, dtype=model.dtype, max_err=round(err, 5),
+                 **t, batch_us=tb, tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
+                 tflops_batch=round(flops / (tb * 1e-6) / 1e12, 1),
+                 alg_GBps=round(bytes_alg / (t['med_us'] * 1e-6) / 1e9, 1))
+      results.append(row)
+      print(json.dumps(row), flush=True)
+    del A, C
+
+
+def bench_mix(model, reps, results):
+  lib, ctx = model._lib, model._ctx
+  bf = model.dtype == 'bfloat16'
+  dev = model.device
+  stream = model._stream()
+  N, T = 256, 48
+  x = [torch.randn(N, T, 512, device=dev) for _ in range(3)]
+  xo = [torch.empty(N, T, 512, device=dev) for _ in range(3)]
+  xn = [torch.empty(N * T, 512, device=dev, dtype=torch.bfloat16 if bf else torch.float32) for _ in range(3)]
+
+  def run(i):
+    k = i % 3
+    rc = lib.tapir_debug_mix(ctx, 0, x[k].data_ptr(), xo[k].data_ptr(), xn[k].data_ptr(), N, T, stream)
+    assert rc == 0, lib.tapir_last_error(ctx)
+  t = timeit(run, reps)
+  tb = timeit_batch(run, reps)
+  byts = N * T * 512 * (4 + 4 + (2 if bf else 4))
+  row = dict(kernel='mix', dtype=model.dtype, **t, batch_us=tb,
+             alg_GBps=round(byts / (t['med_us'] * 1e-6) / 1e9, 1), alg_bytes=byts)
+  results.append(row)
+  print(json.dumps(row), flush=True)
+
+
+def bench_mixer(model, reps, results):
+  """whole PIPSMLPMixer (12 blocks) on 256 x 48 tokens through the public C ABI"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  N, T = 256, 48
+  cin = 388 + 49 * (2 + model.pyramid_level)
+  x = torch.randn(N, T, cin, device=dev)
+  out = torch.empty(N, T, 388, device=dev)
+  stream = model._stream()
+
+  def run(i):
+    rc = lib.tapir_pips_mixer(ctx, x.data_ptr(), N, T, out.data_ptr(), None, None, None, None, stream)
+    assert rc == 0, lib.tapir_last_error(ctx)
+  t = timeit(run, max(5, reps // 4), warm=2)
+  flops = 2.0 * N * T * (cin * 512 + 12 * 2 * 512 * 2048 + 512 * 388)
+  row = dict(kernel='pips_mixer_12blocks', dtype=model.dtype, **t,
+             tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1))
+  results.append(row)
+  print(json.dumps(row), flush=True)
+
+
+def bench_backbone(model, reps, results):
+  dev = model.device
+  video = torch.as_tensor(synthetic.make_video(1, 48, 256, 256), device=dev)
+  def run(i):
+    model.get_feature_grids(video)
+  t = timeit(run, max(3, reps // 8), warm=2)
+  row = dict(kernel='backbone_get_feature_grids', dtype=model.dtype, **t)
+  results.append(row)
+  print(json.dumps(row), flush=True)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--what', default='gemm,mix,mixer')
+  ap.add_argument('--reps', type=int, default=40)
+  ap.add_argument('--dtypes', default='bfloat16')
+  ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'kbench.json'))
+  args = ap.parse_args()
+  what = set(args.what.split(','))
+  results = []
+  for dtype in args.dtypes.split(','):
+    need_bb = 'backbone' in what
+    w = synthetic.make_weights(0, 0, False, backbone=need_bb)
+    model = tapir_model.TAPIR(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0')
+    if 'gemm' in what:
+      bench_gemm(model, args.reps, results)
+    if 'mix' in what:
+      bench_mix(model, args.reps, results)
+    if 'mixer' in what:
+      bench_mixer(model, args.reps, results)
+    if need_bb:
+      bench_backbone(model, args.reps, results)
+  os.makedirs(os.path.dirname(args.out), exist_ok=True)
+  with open(args.out, 'w') as f:
+    json.dump(results, f, indent=1)
+
+
+if __name__ == '__main__':
+  main()
