@@ -26,6 +26,18 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair (lo in bits 0..15), round-to-nearest-even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#ifdef TAPIR_HIPEMU
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+#else
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+  return __builtin_bit_cast(unsigned, r);
+#endif
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -36,13 +48,61 @@ template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
-// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The hardware writes to
-// M0 (the FIRST lane's LDS address) + lane * 16: `lds` must be wave-uniform base + lane*16;
-// the global address is free per lane.  Completion is tracked by vmcnt; __syncthreads() drains it.
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The hardware writes lane
+// l's 16 bytes to M0 + l * 16, M0 = the FIRST lane's `lds` argument: pass the wave's base address
+// (wave-uniform, so that it stays in an SGPR); the global address is free per lane.  Completion is
+// tracked by vmcnt.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+// constant address space: a wave-uniform load through it is a scalar (s_load) load
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;
 __device__ __forceinline__ void glds16(const void* gptr, void* lds) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)gptr, (lds_ptr_t)(uintptr_t)lds, 16, 0, 0);
+}
+
+// Waits until at most N of this wave's vector-memory operations (LDS-DMA copies included) are
+// outstanding.  Loads complete in order, so vmcnt(N) guarantees that every copy older than the
+// youngest N has landed; outstanding stores only make the wait longer, never shorter.
+template <int N> __device__ __forceinline__ void dma_wait() {
+#ifndef TAPIR_HIPEMU
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// dma_wait<N> plus lgkmcnt(0): additionally, every LDS read this wave has issued has returned
+// (used before a barrier after which another wave may overwrite what was read).
+template <int N> __device__ __forceinline__ void dma_lds_wait() {
+#ifndef TAPIR_HIPEMU
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#endif
+}
+// Value the optimiser cannot see through (blocks hoisting of what is derived from it).
+__device__ __forceinline__ int opaque(int v) {
+#ifndef TAPIR_HIPEMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+// Marks a use of v at this point (the compiler places the wait for a pending load of v here).
+__device__ __forceinline__ void consume(const f32x4& v) {
+#ifndef TAPIR_HIPEMU
+  asm volatile("" ::"v"(v));
+#endif
+}
+// Compiler scheduling fence: no instruction is moved across it (bounds live ranges).
+__device__ __forceinline__ void sched_fence() {
+#ifndef TAPIR_HIPEMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Workgroup barrier WITHOUT the memory fence of __syncthreads(): the fence would drain vmcnt and
+// with it every LDS-DMA copy in flight.  The caller orders what it needs with dma_wait<>; LDS
+// reads are complete before the MFMAs that consume them, i.e. before the barrier.
+__device__ __forceinline__ void block_barrier() {
+#ifdef TAPIR_HIPEMU
+  __syncthreads();
+#else
+  __builtin_amdgcn_s_barrier();
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -64,15 +124,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// e^x through the hardware exp2 (v_exp_f32); relative error ~|x|*1e-7.
-__device__ __forceinline__ float fast_exp(float x) { return exp2f(x * 1.4426950408889634f); }
+// Raw hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp): exp2f() and operator/ expand to
+// ~10-instruction sequences (denormal scaling, Newton steps, div_fixup) that made the GELU
+// epilogues VALU-bound.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// e^x; relative error ~|x|*1e-7.
+__device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * 1.4426950408889634f); }
 
 // jax.nn.gelu(approximate=True) == F.gelu(approximate='tanh') (tapir_model.py:67,96):
-// 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3); 0.5(1+tanh u) = 1/(1+e^{-2u}).
+// 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3); 0.5(1+tanh u) = 1/(1+e^{-2u})
+//   = 1 / (1 + 2^(x (c1 + c3 x^2))),  c1 = -2 sqrt(2/pi) log2(e),  c3 = 0.044715 c1.
+// 7 VALU instructions, two of them transcendental.  x -> -inf gives x * rcp(inf) = -0.
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float k = 0.7978845608028654f;
-  float u = k * (x + 0.044715f * x * x * x);
-  return x / (1.0f + fast_exp(-2.0f * u));
+  const float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  const float c3 = c1 * 0.044715f;
+  const float e = fast_exp2(x * fmaf(c3, x * x, c1));
+  return x * fast_rcp(1.0f + e);
 }
 
 }  // namespace tapir

@@ -792,14 +792,14 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
   HIP_TRY(c, hipSetDevice(c->device));
   const int kstep = c->cfg.dtype == TAPIR_BF16 ? 64 : 32;
   if (!A || !W || !C || M < 1 || N < 4 || K < kstep || K % kstep || N % 4 || ldc % 4 || epi < 0 ||
-      epi > 2 || tile < 0 || (tile & 0xff) > 3 || (epi == 2 && !resid))
+      epi > 2 || tile < 0 || (tile & 0xff) >= GEMM_TILE_COUNT || (epi == 2 && !resid))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = c->cfg.dtype == TAPIR_BF16;
-  const int mg = tile >> 8;   // test hook: cap the persistent grid (forces several tiles per workgroup)
+  const int mg = (tile >> 8) & 0xfff;   // test hook: cap the persistent grid (several tiles per workgroup)
   tile &= 0xff;
   if (epi == 0) { if (bf) launch_gemm<bf16_t, float, EPI_BIAS>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS>(g, s, tile, mg); }
   else if (epi == 1) { if (bf) launch_gemm<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_GELU>(g, s, tile, mg); }

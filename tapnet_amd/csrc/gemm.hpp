@@ -45,8 +45,6 @@ namespace tapir {
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
 
-constexpr int GEMM_THREADS = 256;
-
 struct GemmArgs {
   const void* A; long lda;                 // strides in elements
   const void* W; long ldw;
@@ -85,8 +83,8 @@ template <> struct Store4<float> {
 template <> struct Store4<bf16_t> {
   static __device__ __forceinline__ void run(bf16_t* p, float a, float b, float c, float d) {
     uint2 v;
-    v.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-    v.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
+    v.x = pack_bf16x2(a, b);
+    v.y = pack_bf16x2(c, d);
     *reinterpret_cast<uint2*>(p) = v;
   }
 };
@@ -101,92 +99,158 @@ template <> struct Store8<float> {
 template <> struct Store8<bf16_t> {
   static __device__ __forceinline__ void run(bf16_t* p, const float (&v)[8]) {
     uint4 o;
-    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = o;
   }
 };
 
-template <int FM, int FN> struct GemmTile {
-  static constexpr int BM = 32 * FM;             // 2 waves x FM fragments x 16 rows
-  static constexpr int BN = 32 * FN;
-  static constexpr int CH_A = BM * 8 / GEMM_THREADS;   // 16-byte chunks per thread and k-step
-  static constexpr int CH_W = BN * 8 / GEMM_THREADS;
-  static constexpr int LDS_CHUNKS = (BM + BN) * 8;     // one stage
-  static constexpr int LDS_BYTES = 2 * LDS_CHUNKS * 16;
+// Tile configuration: WM x WN waves, each FM x FN MFMA 16x16 fragments, NS LDS stages.
+template <int WM_, int WN_, int FM_, int FN_, int NS_, bool PREFETCH_ = false> struct GemmTile {
+  static constexpr int WM = WM_, WN = WN_, FM = FM_, FN = FN_, NS = NS_;
+  static constexpr bool PREFETCH = PREFETCH_ && NS_ >= 3;   // fragment prefetch across the barrier
+  static constexpr int THREADS = WM * WN * 64;
+  static constexpr int BM = WM * FM * 16;
+  static constexpr int BN = WN * FN * 16;
+  static constexpr int CH_A = BM * 8 / THREADS;   // 16-byte chunks per thread and k-step
+  static constexpr int CH_W = BN * 8 / THREADS;
+  static constexpr int CH = CH_A + CH_W;           // LDS-DMA instructions per thread and stage
+  static constexpr int STAGE_CHUNKS = (BM + BN) * 8;
+  static constexpr int LDS_BYTES = NS * STAGE_CHUNKS * 16;
+  static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "stage must split evenly");
+  static_assert(FN % 2 == 0 && NS >= 2 && NS <= 4, "unsupported tile");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   // swizzle of W row R (tile-local): the low 3 bits of the fragment row q of the lane that reads
   // it, q = 4 (R / (4 FN) % 4) + R % 4  ->  (R & 3) | bit (R / (4 FN)) & 1
   static __device__ __forceinline__ int swz_w(int R) { return (R & 3) | (((R / (4 * FN)) & 1) << 2); }
 };
 
-// Per-thread source offsets (in elements, relative to A / W) of the chunks this thread copies in
-// every k-step of one tile.  Rows past M / N are clamped to the last valid row (their products
-// are never stored).
-template <typename TA, int FM, int FN>
+// Walks the (tile, k-step) sequence of one persistent workgroup for the DMA side, which runs
+// NS-1 k-steps ahead of the MFMA side (and therefore crosses tile boundaries on its own).
+// Holds the per-thread source offsets (in elements, relative to A / W) of the chunks this thread
+// copies in every k-step of the current tile.  Rows past M / N are clamped to the last valid row
+// (their products are never stored).
+template <typename TA, typename TL>
 struct GemmStager {
-  using TL = GemmTile<FM, FN>;
   static constexpr int EPC = 16 / (int)sizeof(TA);
   long offA[TL::CH_A], offW[TL::CH_W];
+  int local, kt;        // tile (index within this XCD's range) and k-step of the next copy
   __device__ __forceinline__ void set_tile(const GemmArgs& g, int m0, int n0, int tid) {
+    tid = opaque(tid);   // recompute the per-thread row / chunk indices here instead of keeping
+                         // them in (spilled) registers for the whole kernel
 #pragma unroll
     for (int s = 0; s < TL::CH_A; ++s) {
-      const int id = tid + GEMM_THREADS * s;
+      const int id = tid + TL::THREADS * s;
       const int row = id >> 3, p = id & 7;
       offA[s] = (long)min(m0 + row, g.M - 1) * g.lda + (p ^ (row & 7)) * EPC;
     }
 #pragma unroll
     for (int s = 0; s < TL::CH_W; ++s) {
-      const int id = tid + GEMM_THREADS * s;
+      const int id = tid + TL::THREADS * s;
       const int row = id >> 3, p = id & 7;
       offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::swz_w(row)) * EPC;
     }
   }
   // LDS stage layout: A rows [0, BM), W rows [BM, BM+BN); chunk id = row*8 + p (lane-linear)
+  // wave_u: the wave index as a wave-uniform (scalar) value: the LDS destination of the DMA is
+  // M0 = the wave's base address; the hardware adds lane * 16 itself.
   __device__ __forceinline__ void issue(const TA* __restrict__ A, const TA* __restrict__ W, int k0,
-                                        int tid, uint4* lds) const {
+                                        int wave_u, uint4* lds) const {
 #pragma unroll
-    for (int s = 0; s < TL::CH_A; ++s) glds16(A + offA[s] + k0, lds + tid + GEMM_THREADS * s);
+    for (int s = 0; s < TL::CH_A; ++s) glds16(A + offA[s] + k0, lds + wave_u * 64 + TL::THREADS * s);
 #pragma unroll
     for (int s = 0; s < TL::CH_W; ++s)
-      glds16(W + offW[s] + k0, lds + TL::BM * 8 + tid + GEMM_THREADS * s);
+      glds16(W + offW[s] + k0, lds + TL::BM * 8 + wave_u * 64 + TL::THREADS * s);
   }
 };
 
-// MFMAs of one k-step from one staged tile.
-template <typename TA, int FM, int FN>
-__device__ __forceinline__ void gemm_compute_tile(const uint4* lds, int a_row, int w_row, int fr,
-                                                  int fg, f32x4 (&acc)[FM][FN]) {
-  using TL = GemmTile<FM, FN>;
+// Fragment reads of one half k-step (kk = 0 / 1: 16-byte chunks kk*4 .. kk*4+3 of every row).
+template <typename TL>
+__device__ __forceinline__ void gemm_load_frags(const uint4* lds, int a_row, int w_row, int fr, int fg,
+                                                int kk, uint4 (&fa)[TL::FM], uint4 (&fw)[TL::FN]) {
+  const int c = (kk * 4 + fg) ^ (fr & 7);
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const int c = (kk * 4 + fg) ^ (fr & 7);
-    uint4 fa[FM], fw[FN];
+  for (int i = 0; i < TL::FM; ++i) fa[i] = lds[(a_row + i * 16) * 8 + c];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) fa[i] = lds[(a_row + i * 16) * 8 + c];
+  for (int j = 0; j < TL::FN; ++j) fw[j] = lds[(TL::BM + w_row + j * 4) * 8 + c];
+}
+template <typename TA, typename TL>
+__device__ __forceinline__ void gemm_mfma_frags(const uint4 (&fa)[TL::FM], const uint4 (&fw)[TL::FN],
+                                                f32x4 (&acc)[TL::FM][TL::FN]) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) fw[j] = lds[(TL::BM + w_row + j * 4) * 8 + c];
+  for (int i = 0; i < TL::FM; ++i)
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < TL::FN; ++j) MfmaStep<TA>::run(fw[j], fa[i], acc[i][j]);
+}
+
+// Epilogue of one tile: lane holds C[m = mb + 16 i][n = nb + 4 j + 0..3].
+template <typename TO, int EPI, typename TL, bool INTERIOR>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict__ C,
+                                              const f32x4 (&acc)[TL::FM][TL::FN],
+                                              const f32x4 (&bias4)[TL::FN], int mb, int nb) {
+  constexpr int FM = TL::FM, FN = TL::FN;
 #pragma unroll
-      for (int j = 0; j < FN; ++j) MfmaStep<TA>::run(fw[j], fa[i], acc[i][j]);
+  for (int i = 0; i < FM; ++i) {
+    const int m = mb + i * 16;
+    const int mc = INTERIOR ? m : min(m, g.M - 1);
+    float4 res4[FN];
+    if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        res4[j] = *reinterpret_cast<const float4*>(
+            g.resid + (long)mc * g.ldr + (INTERIOR ? nb + j * 4 : min(nb + j * 4, g.N - 4)));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; j += 2) {
+      float v[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 b = bias4[j + h];
+        float v0 = acc[i][j + h][0] + b[0], v1 = acc[i][j + h][1] + b[1];
+        float v2 = acc[i][j + h][2] + b[2], v3 = acc[i][j + h][3] + b[3];
+        if (EPI == EPI_BIAS_GELU) {
+          v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+        }
+        if (EPI == EPI_BIAS_RESID) {
+          v0 += res4[j + h].x; v1 += res4[j + h].y; v2 += res4[j + h].z; v3 += res4[j + h].w;
+        }
+        v[4 * h + 0] = v0; v[4 * h + 1] = v1; v[4 * h + 2] = v2; v[4 * h + 3] = v3;
+      }
+      const int n = nb + j * 4;
+      TO* dst = C + (long)m * g.ldc + n;
+      if (INTERIOR) {
+        Store8<TO>::run(dst, v);
+      } else if (m < g.M) {
+        if (n + 4 <= g.N) Store4<TO>::run(dst, v[0], v[1], v[2], v[3]);
+        if (n + 8 <= g.N) Store4<TO>::run(dst + 4, v[4], v[5], v[6], v[7]);
+      }
+    }
   }
 }
 
+template <int S> struct StageTag { static constexpr int value = S; };
+
 // TA: operand element type (bf16_t or float); TO: output element type.
-template <typename TA, typename TO, int EPI, int FM, int FN>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
-  using TL = GemmTile<FM, FN>;
+template <typename TA, typename TO, int EPI, typename TL>
+__global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   constexpr int EPC = 16 / (int)sizeof(TA);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                 // elements per 128-byte k-step
-  __shared__ uint4 lds0[TL::LDS_CHUNKS];
-  __shared__ uint4 lds1[TL::LDS_CHUNKS];
+  constexpr int NS = TL::NS, FM = TL::FM, FN = TL::FN;
+  // One __shared__ object PER STAGE (see the header comment): the waitcnt pass then waits, before
+  // the fragment reads of stage s, only for the copies into stage s (a counted vmcnt).
+  __shared__ uint4 lds0[TL::STAGE_CHUNKS];
+  __shared__ uint4 lds1[TL::STAGE_CHUNKS];
+  __shared__ uint4 lds2[NS > 2 ? TL::STAGE_CHUNKS : 1];
+  __shared__ uint4 lds3[NS > 3 ? TL::STAGE_CHUNKS : 1];
+  uint4* const bufs[4] = {lds0, lds1, lds2, lds3};
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
   const int fr = lane & 15;   // fragment row handled by this lane
   const int fg = lane >> 4;   // k lane-group (operand reads) / column group (results)
   const int a_row = wm * FM * 16 + fr;
@@ -207,121 +271,157 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
   TO* __restrict__ C = reinterpret_cast<TO*>(g.C);
   const int nk = g.K / BK;
   const bool wide = (g.ldc * (long)sizeof(TO)) % 16 == 0;   // rows keep 16-byte alignment
+  const bool has_bias = g.bias != nullptr;
 
-  GemmStager<TA, FM, FN> st;
-  int local = slot;
-  int m0 = ((start + local) / tiles_n) * TL::BM;
-  int n0 = ((start + local) % tiles_n) * TL::BN;
-  st.set_tile(g, m0, n0, tid);
-  st.issue(A, W, 0, tid, lds0);
+  // ---- DMA side: issues k-step copies in (tile, k) order, NS-1 steps ahead of the MFMAs
+  GemmStager<TA, TL> st;
+  st.local = slot; st.kt = 0;
+  st.set_tile(g, ((start + slot) / tiles_n) * TL::BM, ((start + slot) % tiles_n) * TL::BN, tid);
+  auto issue_next = [&](uint4* dst) -> bool {   // false once every k-step of this workgroup is issued
+    if (st.local >= len) return false;
+    st.issue(A, W, st.kt * BK, wave_u, dst);
+    if (++st.kt == nk) {
+      st.kt = 0;
+      st.local += per_xcd;
+      if (st.local < len)
+        st.set_tile(g, ((start + st.local) / tiles_n) * TL::BM,
+                    ((start + st.local) % tiles_n) * TL::BN, tid);
+    }
+    return true;
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue_next(bufs[s]);
+  // bias of the first tile (requested after the first copies are under way)
+  int bias_n0 = ((start + slot) % tiles_n) * TL::BN;
+  f32x4 bias4[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias)
+      bias4[j] = *reinterpret_cast<const f32x4*>(
+          g.bias + min(bias_n0 + wn * FN * 16 + fg * (4 * FN) + j * 4, g.N - 4));
+  }
 
-  for (;;) {
-    f32x4 acc[FM][FN];
+  // Pipeline depth.  NS >= 3: the fragments of the first half of k-step t+1 are read (into
+  // registers) during k-step t, BEFORE the barrier that ends it, so the MFMAs restart right after
+  // the barrier instead of waiting for an LDS round trip of all eight waves at once.  That needs
+  // stage t+1 visible during step t: each step ends by waiting for the copies of stage t+2
+  // (AHEAD = 2), which leaves NS-3 stages in flight across the barrier.  NS == 2: plain double
+  // buffer (AHEAD = 1, nothing in flight across the barrier).
+  constexpr bool PREFETCH = TL::PREFETCH;
+  constexpr int AHEAD = PREFETCH ? 2 : 1;
+  constexpr int INFLIGHT = (NS - 1 - AHEAD) * TL::CH;
+  if (st.local < len) dma_wait<INFLIGHT>(); else dma_wait<0>();
+  // "use" the bias here so that the compiler's wait for it sits here and not in every epilogue
+#pragma unroll
+  for (int j = 0; j < FN; ++j) consume(bias4[j]);
+  block_barrier();
+
+  // ---- MFMA side.  One k-step: refill the stage read in the previous step, multiply from stage
+  // S, wait until this wave's copies of stage t+AHEAD have landed, barrier.
+  f32x4 acc[FM][FN];
+  uint4 fa0[FM], fw0[FN];   // first-half fragments of the current stage (NS >= 3: prefetched)
+  if (PREFETCH) gemm_load_frags<TL>(bufs[0], a_row, w_row, fr, fg, 0, fa0, fw0);
+  auto step = [&](auto tag) {
+    constexpr int S = decltype(tag)::value;
+    const bool issued = issue_next(bufs[(S + NS - 1) % NS]);
+    sched_fence();   // keep the copy's address arithmetic out of the fragment live ranges
+    uint4 fa1[FM], fw1[FN];
+    if (!PREFETCH) gemm_load_frags<TL>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
+    gemm_load_frags<TL>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+    gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
+    if (PREFETCH) gemm_load_frags<TL>(bufs[(S + 1) % NS], a_row, w_row, fr, fg, 0, fa0, fw0);
+    gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
+    sched_fence();
+    // every LDS read above has returned (lgkmcnt) before another wave may refill what it read
+    if (issued) dma_lds_wait<INFLIGHT>(); else dma_lds_wait<0>();
+    block_barrier();
+  };
+
+  int phase = 0;   // stage that holds the current k-step
+  for (int local = slot; local < len; local += per_xcd) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();   // k-step 0 of this tile has landed in lds0 (drains the DMA: vmcnt)
+    // this lane's output coordinates: C[m = mb + 16 i][n = nb + 4 j + 0..3]
+    const int m0 = ((start + local) / tiles_n) * TL::BM;
+    const int n0 = ((start + local) % tiles_n) * TL::BN;
+    const int mb = m0 + wm * FM * 16 + fr;
+    const int nb = n0 + wn * FN * 16 + fg * (4 * FN);
     int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {
-      st.issue(A, W, (kt + 1) * BK, tid, lds1);   // in flight during the MFMAs below
-      gemm_compute_tile<TA, FM, FN>(lds0, a_row, w_row, fr, fg, acc);
-      __syncthreads();                            // lds1 landed; everyone is done with lds0
-      if (kt + 2 < nk) st.issue(A, W, (kt + 2) * BK, tid, lds0);
-      gemm_compute_tile<TA, FM, FN>(lds1, a_row, w_row, fr, fg, acc);
-      __syncthreads();
-    }
-    if (kt < nk) {   // odd number of k-steps: the last one is in lds0
-      gemm_compute_tile<TA, FM, FN>(lds0, a_row, w_row, fr, fg, acc);
-      __syncthreads();
-    }
-
-    // next tile: start its first copy now, it lands while the epilogue below runs
-    const int cm0 = m0, cn0 = n0;
-    local += per_xcd;
-    const bool more = local < len;
-    if (more) {
-      m0 = ((start + local) / tiles_n) * TL::BM;
-      n0 = ((start + local) % tiles_n) * TL::BN;
-      st.set_tile(g, m0, n0, tid);
-      st.issue(A, W, 0, tid, lds0);
-    }
-
-    // epilogue: lane holds C[m = .. + 16 i + fr][n = .. + 4 FN fg + 4 j + 0..3]
-    const int mb = cm0 + wm * FM * 16 + fr;
-    const int nb = cn0 + wn * FN * 16 + fg * (4 * FN);
-    float4 bias4[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias != nullptr)
-        bias4[j] = *reinterpret_cast<const float4*>(g.bias + min(nb + j * 4, g.N - 4));
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = mb + i * 16;
-      const int mc = min(m, g.M - 1);
-      float4 res4[FN];
-      if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          res4[j] = *reinterpret_cast<const float4*>(g.resid + (long)mc * g.ldr + min(nb + j * 4, g.N - 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FN; j += 2) {
-        float v[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float4 b = bias4[j + h];
-          float v0 = acc[i][j + h][0] + b.x, v1 = acc[i][j + h][1] + b.y;
-          float v2 = acc[i][j + h][2] + b.z, v3 = acc[i][j + h][3] + b.w;
-          if (EPI == EPI_BIAS_GELU) {
-            v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+    while (kt < nk) {
+      switch (phase) {
+        case 0:
+          step(StageTag<0>{});
+          if (++kt == nk) { phase = 1 % NS; break; }
+          [[fallthrough]];
+        case 1:
+          step(StageTag<1>{});
+          if (NS == 2) { ++kt; phase = 0; break; }
+          if (++kt == nk) { phase = 2 % NS; break; }
+          [[fallthrough]];
+        case 2:
+          if constexpr (NS > 2) {
+            step(StageTag<2>{});
+            if (NS == 3) { ++kt; phase = 0; break; }
+            if (++kt == nk) { phase = 3 % NS; break; }
           }
-          if (EPI == EPI_BIAS_RESID) {
-            v0 += res4[j + h].x; v1 += res4[j + h].y; v2 += res4[j + h].z; v3 += res4[j + h].w;
+          [[fallthrough]];
+        default:
+          if constexpr (NS > 3) {
+            step(StageTag<3>{});
+            ++kt; phase = 0;
           }
-          v[4 * h + 0] = v0; v[4 * h + 1] = v1; v[4 * h + 2] = v2; v[4 * h + 3] = v3;
-        }
-        const int n = nb + j * 4;
-        TO* dst = C + (long)m * g.ldc + n;
-        if (m < g.M) {
-          if (wide && n + 8 <= g.N) {
-            Store8<TO>::run(dst, v);
-          } else {
-            if (n + 4 <= g.N) Store4<TO>::run(dst, v[0], v[1], v[2], v[3]);
-            if (n + 8 <= g.N) Store4<TO>::run(dst + 4, v[4], v[5], v[6], v[7]);
-          }
-        }
+          break;
       }
     }
-    if (!more) break;
+
+    // epilogue
+    // Bias: normally still in registers from the previous tile (the persistent schedule gives a
+    // workgroup tiles of ONE column block whenever tiles_n divides the per-XCD stride).  A reload
+    // is a VGPR-destination load whose first use makes the compiler drain vmcnt, i.e. also the
+    // copies in flight for the next tile -- correct, just slower, and rare.
+    if (n0 != bias_n0) {
+      bias_n0 = n0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        if (has_bias) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + min(nb + j * 4, g.N - 4));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) consume(bias4[j]);
+    }
+    // interior tiles with 16-byte aligned rows take a branch-free path (no per-lane predicates:
+    // the compiler otherwise sinks the GELU arithmetic into a maze of masked store blocks)
+    const bool interior = wide && m0 + TL::BM <= g.M && n0 + TL::BN <= g.N;
+    if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb);
+    else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb);
   }
 }
 
-// Shape-driven tile choice.  Slots = 2 workgroups per CU x 256 CUs.
-enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3 };
+// Tile shapes.  Slots = workgroups per CU (LDS-limited) x 256 CUs.
+enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3,
+       GEMM_TILE_192x128_S3 = 4, GEMM_TILE_COUNT = 5 };
+typedef GemmTile<4, 2, 3, 4, 4> GemmTileBig;     // 192x128, 8 waves, 4 stages = 160 KiB: 1 per CU
+typedef GemmTile<4, 2, 3, 4, 3> GemmTileBig3;    // same, 3 stages = 120 KiB
+typedef GemmTile<2, 2, 4, 4, 2> GemmTileSquare;  // 128x128, 4 waves, 64 KiB: 2 per CU
+typedef GemmTile<2, 2, 6, 2, 2> GemmTileTall;    // 192x64, 4 waves, 64 KiB: 2 per CU
 
+// Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/): wide outputs
+// (N = 2048, GELU epilogue) run best on 128x128 at two workgroups per CU; narrow outputs
+// (N <= 1024, long K) on 192x64, which gives 512 tiles = one per LDS slot.
 inline int gemm_pick_tile(int M, int N) {
-  // few wide tiles when they still fill the chip, narrower ones otherwise
-  const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128);
-  if (M % 192 == 0 || M >= 192 * 64) {
-    if (t192 >= 256 || (N % 128 != 0 && N > 64)) return GEMM_TILE_192x128;
-    return GEMM_TILE_192x64;
-  }
+  if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
   return GEMM_TILE_128x128;
 }
 
-template <typename TA, typename TO, int EPI, int FM, int FN>
+template <typename TA, typename TO, int EPI, typename TL>
 inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid) {
-  using TL = GemmTile<FM, FN>;
   const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / TL::LDS_BYTES));
   int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
-  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, FM, FN>), dim3(grid), dim3(GEMM_THREADS), 0,
-                     stream, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid), dim3(TL::THREADS), 0, stream, g);
 }
 
 template <typename TA, typename TO, int EPI>
@@ -329,9 +429,10 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
                         int max_grid = 0) {
   if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N);
   switch (tile) {
-    case GEMM_TILE_192x128: launch_gemm_tile<TA, TO, EPI, 6, 4>(g, stream, max_grid); break;
-    case GEMM_TILE_192x64: launch_gemm_tile<TA, TO, EPI, 6, 2>(g, stream, max_grid); break;
-    default: launch_gemm_tile<TA, TO, EPI, 4, 4>(g, stream, max_grid); break;
+    case GEMM_TILE_192x128: launch_gemm_tile<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
+    case GEMM_TILE_192x128_S3: launch_gemm_tile<TA, TO, EPI, GemmTileBig3>(g, stream, max_grid); break;
+    case GEMM_TILE_192x64: launch_gemm_tile<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
+    default: launch_gemm_tile<TA, TO, EPI, GemmTileSquare>(g, stream, max_grid); break;
   }
 }
 

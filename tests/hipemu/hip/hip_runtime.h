@@ -439,15 +439,19 @@ static inline void __builtin_amdgcn_global_load_lds(
       [&](hipemu::WaveBuf& wb, unsigned lane) { memcpy(&wb.v[lane][0], &l, sizeof(l)); },
       [&](hipemu::WaveBuf&) {},
       [&](hipemu::WaveBuf& wb, unsigned lane) { (void)lane; memcpy(&base, &wb.v[0][0], sizeof(base)); });
-  if (l != base + (uintptr_t)hipemu_lane() * size) {
-    fprintf(stderr, "hipemu: global_load_lds destination is not wave-uniform base + lane*size\n");
+  // the hardware uses M0 = the first lane's LDS address and adds lane * size itself: the argument
+  // must be wave-uniform (the base) or already base + lane * size
+  if (l != base && l != base + (uintptr_t)hipemu_lane() * size) {
+    fprintf(stderr, "hipemu: global_load_lds destination is neither wave-uniform nor base + lane*size\n");
     abort();
   }
-  memcpy((void*)l, (const void*)g, size);
+  memcpy((void*)(base + (uintptr_t)hipemu_lane() * size), (const void*)g, size);
 }
 
 // ---------------------------------------------------------------- misc device math
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

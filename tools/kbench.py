@@ -25,7 +25,7 @@ import torch
 
 from tapnet_amd import _ffi, synthetic, tapir_model
 
-TILES = {1: '192x128', 2: '128x128', 3: '192x64'}
+TILES = {1: '192x128s4', 2: '128x128', 3: '192x64', 4: '192x128s3'}
 R = 256 * 48
 
 
@@ -61,7 +61,7 @@ def gelu_tanh(x):
   return torch.nn.functional.gelu(x, approximate='tanh')
 
 
-def bench_gemm(model, reps, results):
+def bench_gemm(model, reps, results, ablate=False, only_shapes=None, only_tiles=None, dbg_list=None):
   lib, ctx = model._lib, model._ctx
   bf = model.dtype == 'bfloat16'
   tdt = torch.bfloat16 if bf else torch.float32
@@ -86,8 +86,17 @@ def bench_gemm(model, reps, results):
     flops = 2.0 * M * N * K
     es = 2 if bf else 4
     bytes_alg = M * K * es + N * K * es + M * N * (es if epi == 1 else 4) + (M * N * 4 if epi == 2 else 0)
-    for tile, tname in TILES.items():
-      def run(i, tile=tile):
+    if only_shapes and name not in only_shapes:
+      continue
+    variants = [(t, n, 0) for t, n in TILES.items() if not only_tiles or t in only_tiles]
+    if dbg_list:
+      variants = [(t, f'{n}/dbg{d}', d) for t, n, _ in variants for d in dbg_list]
+    if ablate and name in ('up', 'down'):
+      for dbg, dn in ((1, 'noDMA'), (2, 'noMFMA'), (4, 'noStore'), (8, 'noGELU'), (12, 'noStore+noGELU'),
+                      (3, 'noDMA+noMFMA'), (7, 'onlyBarriers+epi')):
+        variants += [(1, f'192x128s4/{dn}', dbg), (2, f'128x128/{dn}', dbg)]
+    for tile, tname, dbg in variants:
+      def run(i, tile=tile | (dbg << 20)):
         k = i % nset
         rc = lib.tapir_debug_gemm(ctx, A[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(),
                                   resid.data_ptr() if resid is not None else None, N,
@@ -95,7 +104,7 @@ def bench_gemm(model, reps, results):
         assert rc == 0, lib.tapir_last_error(ctx)
       run(0)
       torch.cuda.synchronize()
-      err = float((C[0].float() - ref).abs().max())
+      err = float((C[0].float() - ref).abs().max()) if dbg == 0 else -1.0
       t = timeit(run, reps)
       tb = timeit_batch(run, reps)
       row = dict(kernel=f'gemm_{name}', tile=tname, M=M, N=N, K=K, dtype=model.dtype, max_err=round(err, 5),
@@ -167,6 +176,10 @@ def main():
   ap.add_argument('--what', default='gemm,mix,mixer')
   ap.add_argument('--reps', type=int, default=40)
   ap.add_argument('--dtypes', default='bfloat16')
+  ap.add_argument('--ablate', action='store_true')
+  ap.add_argument('--shapes', default='')
+  ap.add_argument('--tiles', default='')
+  ap.add_argument('--dbg', default='')
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'kbench.json'))
   args = ap.parse_args()
   what = set(args.what.split(','))
@@ -176,7 +189,9 @@ def main():
     w = synthetic.make_weights(0, 0, False, backbone=need_bb)
     model = tapir_model.TAPIR(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0')
     if 'gemm' in what:
-      bench_gemm(model, args.reps, results)
+      bench_gemm(model, args.reps, results, args.ablate, set(args.shapes.split(',')) if args.shapes else None,
+                 set(int(t) for t in args.tiles.split(',')) if args.tiles else None,
+                 [int(d) for d in args.dbg.split(',')] if args.dbg else None)
     if 'mix' in what:
       bench_mix(model, args.reps, results)
     if 'mixer' in what:
