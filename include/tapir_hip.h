@@ -172,6 +172,30 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 
+/* Feature backbone, the memory-bound half (TAPIR.get_feature_grids, tapir_model.py:626-729; ResNet
+ * blocks, tapnet/models/resnet.py:152-257).  The convolutions stay on PyTorch-ROCm / MIOpen
+ * (north_star); these three entry points are everything between them.  Tensors are NHWC in the
+ * context's element type (f32, or bf16 bits for TAPIR_BF16); channel counts: C / (8 bf16 | 4 f32)
+ * must be a power of two <= 256 (<= 64 for tapir_l2_normalize).
+ *
+ * tapir_inorm_stats: per-(image, channel) statistics of hk.InstanceNorm (resnet.py:177-181) over
+ *   x = a [N,HW,C], or over x = a + b with the sum written to sum_out (the residual add that ends
+ *   a block, resnet.py:256, fused with the statistics of the next block's first norm; sum_out may
+ *   alias a or b).  part [N, slabs, C, 2] f32 receives one (mean, M2) summary per slab of pixels.
+ * tapir_inorm_relu: y = relu((x - mean) / sqrt(var + 1e-5) * gamma + beta) (resnet.py:241-249) from
+ *   those summaries.  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
+ *   H / W are not written (pass a zero-initialised buffer with out_h = H+1, out_w = W+1 to get the
+ *   XLA "SAME" padding of a stride-2 3x3 convolution, which pads on the high side only).
+ *   y_sub, if not NULL, [N, H/2, W/2, C] receives the pixels with even h and w (input of the
+ *   stride-2 1x1 projection, resnet.py:243).
+ * tapir_l2_normalize: out f32 [pixels, C] = x / sqrt(max(sum_c x^2, 1e-12)) (tapir_model.py:709-720). */
+int tapir_inorm_stats(tapir_ctx* ctx, const void* a, const void* b, void* sum_out, float* part,
+                      int N, int HW, int C, int slabs, void* stream);
+int tapir_inorm_relu(tapir_ctx* ctx, const void* x, const float* part, const float* gamma,
+                     const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
+                     int out_h, int out_w, void* stream);
+int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, int C, void* stream);
+
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):
  * A [M,lda], W [N,ldw] in the context's operand type (f32 or bf16 bits), bias [N] f32 or NULL;

@@ -73,6 +73,11 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     'tapir_estimate_trajectories': (c_int, [c_void_p, POINTER(TapirTrajArgs), c_void_p]),
+    'tapir_inorm_stats': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    'tapir_inorm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'tapir_l2_normalize': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),

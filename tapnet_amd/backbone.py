@@ -12,6 +12,14 @@ state_dict names (tapnet/torch/nets.py).
 
 Runs channels-last (NHWC) so that the feature grids leave in the
 [B,T,h,w,C] layout the HIP kernels read, with no transpose.
+
+On a GPU only the convolutions run in PyTorch (MIOpen implicit-GEMM, NHWC): everything
+between them -- InstanceNorm statistics, normalise + ReLU (+ the high-side zero border of XLA
+SAME padding and the 2x2 subsampling for the strided projections), the residual add and
+the final L2 normalisation -- are the HIP kernels of tapnet_amd/csrc/backbone.hpp, called
+through the C ABI (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  The plain
+PyTorch restatement below (`_features_torch`) is what runs on a CPU device: it is used by
+the CPU tests and by bench.py's cpu_baseline only.
 """
 from __future__ import annotations
 
@@ -36,8 +44,13 @@ class Backbone:
 
   def __init__(self, weights: Dict[str, torch.Tensor], extra_convs: bool, device,
                dtype: torch.dtype = torch.float32,
-               blocks_per_group: Sequence[int] = (2, 2, 2, 2)):
+               blocks_per_group: Sequence[int] = (2, 2, 2, 2), engine=None):
+    """engine: (ctypes library, context) of libtapir_hip.so -- required on a GPU device."""
     self.device = torch.device(device)
+    self.engine = engine
+    if self.device.type == 'cuda' and engine is None:
+      raise RuntimeError('the GPU backbone needs the HIP engine (libtapir_hip.so); no fallback')
+    self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
     self.blocks_per_group = tuple(blocks_per_group)
@@ -108,6 +121,100 @@ class Backbone:
     s = torch.sum(torch.square(x_nhwc), dim=-1, keepdim=True)
     return x_nhwc / torch.sqrt(torch.clamp_min(s, 1e-12))
 
+  # -- GPU path: MIOpen convolutions + HIP glue kernels ---------------------
+  def _buf(self, key, shape, dtype, zero=False):
+    """Stream-ordered scratch reused across layers and calls (a zero border stays zero: the
+    kernels never write it)."""
+    t = self._bufs.get(key)
+    if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+      t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+      self._bufs[key] = t
+    return t
+
+  def _check(self, rc, what):
+    from tapnet_amd import _ffi
+    _ffi.check(self.engine[0], self.engine[1], rc, what)
+
+  def _stream(self):
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  def _hip_stats(self, a: torch.Tensor, b: Optional[torch.Tensor] = None):
+    """InstanceNorm summaries of a (NHWC), or of a + b with the sum written over a."""
+    lib, ctx = self.engine
+    n, h, w, c = a.shape
+    slabs = max(1, min(h * w // 64, -(-1024 // n)))
+    part = self._buf(('part', n, slabs, c), (n, slabs, c, 2), torch.float32)
+    self._check(lib.tapir_inorm_stats(ctx, a.data_ptr(), b.data_ptr() if b is not None else None,
+                                      a.data_ptr() if b is not None else None, part.data_ptr(),
+                                      n, h * w, c, slabs, self._stream()), 'tapir_inorm_stats')
+    return part, slabs
+
+  def _hip_norm_relu(self, x, part, slabs, name, tag, pad=False, sub=False):
+    lib, ctx = self.engine
+    n, h, w, c = x.shape
+    oh, ow = (h + 1, w + 1) if pad else (h, w)
+    y = self._buf(('y', tag, n, oh, ow, c), (n, oh, ow, c), self.dtype, zero=pad)
+    ys = self._buf(('ysub', tag, n, h // 2, w // 2, c), (n, h // 2, w // 2, c), self.dtype) if sub else None
+    self._check(lib.tapir_inorm_relu(ctx, x.data_ptr(), part.data_ptr(),
+                                     self.w[name + '.weight'].data_ptr(), self.w[name + '.bias'].data_ptr(),
+                                     y.data_ptr(), ys.data_ptr() if sub else None, n, h, w, c, slabs,
+                                     oh, ow, self._stream()), 'tapir_inorm_relu')
+    return y, ys
+
+  def _hip_conv(self, x_nhwc, name, stride=1, padding=0):
+    """NHWC tensor -> NHWC tensor through MIOpen (channels-last view, no copies)."""
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), self.w[name + '.weight'], None, stride=stride,
+                 padding=padding)
+    return y.permute(0, 2, 3, 1).contiguous()   # no-op for a channels-last result
+
+  def _hip_block(self, x, part, slabs, p, stride, use_projection, tag):
+    strided = stride == 2
+    y, ysub = self._hip_norm_relu(x, part, slabs, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
+    shortcut = x
+    if use_projection:
+      shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
+    y = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
+    part1, slabs1 = self._hip_stats(y)
+    y, _ = self._hip_norm_relu(y, part1, slabs1, p + 'bn_1', tag + 'b')
+    y = self._hip_conv(y, p + 'conv_1', 1, 1)
+    part2, slabs2 = self._hip_stats(y, shortcut)   # y += shortcut, fused with the next norm's statistics
+    return y, part2, slabs2
+
+  def _hip_l2norm(self, x_nhwc):
+    lib, ctx = self.engine
+    n, h, w, c = x_nhwc.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+    self._check(lib.tapir_l2_normalize(ctx, x_nhwc.data_ptr(), out.data_ptr(), n * h * w, c,
+                                       self._stream()), 'tapir_l2_normalize')
+    return out
+
+  def _features_hip(self, frames_nhwc):
+    x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    w0 = self.w['resnet_torch.initial_conv.weight']
+    x = F.conv2d(_same_pad(x, w0.shape[-1], 2), w0, None, stride=2).permute(0, 2, 3, 1).contiguous()
+    part, slabs = self._hip_stats(x)
+    strides = (1, 2, 2, 1)
+    unit1 = None
+    for g in range(4):
+      for b in range(self.blocks_per_group[g]):
+        x, part, slabs = self._hip_block(x, part, slabs, f'resnet_torch.block_groups.{g}.blocks.{b}.',
+                                         strides[g] if b == 0 else 1, b == 0, f'g{g}')
+      if g == 1:
+        unit1 = x
+    if self.extra_convs:
+      x = self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    return self._hip_l2norm(x), self._hip_l2norm(unit1)
+
+  def _features_torch(self, frames_nhwc):
+    x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2)
+    x = x.contiguous(memory_format=torch.channels_last)
+    u3, u1 = self._resnet(x)
+    if self.extra_convs:
+      u3 = self._extra_convs(u3)
+    return (self._l2norm(u3.permute(0, 2, 3, 1).float()).contiguous(),
+            self._l2norm(u1.permute(0, 2, 3, 1).float()).contiguous())
+
   # -- public ---------------------------------------------------------------
   @torch.no_grad()
   def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None
@@ -116,15 +223,12 @@ class Backbone:
     L2-normalised, contiguous channels-last."""
     n = frames_nhwc.shape[0]
     chunk = n if not chunk else chunk
+    run = self._features_hip if self.device.type == 'cuda' else self._features_torch
     lows, his = [], []
     for s in range(0, n, chunk):
-      x = frames_nhwc[s:s + chunk].to(self.dtype).permute(0, 3, 1, 2)
-      x = x.contiguous(memory_format=torch.channels_last)
-      u3, u1 = self._resnet(x)
-      if self.extra_convs:
-        u3 = self._extra_convs(u3)
-      lows.append(self._l2norm(u3.permute(0, 2, 3, 1).float()).contiguous())
-      his.append(self._l2norm(u1.permute(0, 2, 3, 1).float()).contiguous())
+      lo, hi = run(frames_nhwc[s:s + chunk])
+      lows.append(lo)
+      his.append(hi)
     return (torch.cat(lows) if len(lows) > 1 else lows[0],
             torch.cat(his) if len(his) > 1 else his[0])
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "backbone.hpp"
 #include "common.hpp"
 #include "costvol.hpp"
 #include "gemm.hpp"
@@ -782,6 +783,65 @@ int tapir_profile_read(tapir_ctx* c, int kind, double* total_ms, int64_t* launch
   *total_ms = tot;
   *launches = (int64_t)c->prof_ev[kind].size();
   c->prof_ev[kind].clear();
+  return TAPIR_OK;
+}
+
+// ---- backbone glue kernels (between the PyTorch-ROCm convolutions)
+static bool norm_channels_ok(const tapir_ctx* c, int C, int max_group) {
+  const int ept = c->cfg.dtype == TAPIR_BF16 ? 8 : 4;
+  if (C < ept || C % ept) return false;
+  const int G = C / ept;
+  return G <= max_group && (G & (G - 1)) == 0;
+}
+
+int tapir_inorm_stats(tapir_ctx* c, const void* a, const void* b, void* sum_out, float* part, int N,
+                      int HW, int C, int slabs, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!a || !part || (b && !sum_out) || N < 1 || HW < 1 || slabs < 1 || slabs > HW)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  NormStatsArgs na{a, b, sum_out, part, HW, C, slabs};
+  if (c->cfg.dtype == TAPIR_BF16)
+    hipLaunchKernelGGL((inorm_stats_kernel<bf16_t>), dim3(slabs, N), dim3(NORM_THREADS), 0, (hipStream_t)stream, na);
+  else
+    hipLaunchKernelGGL((inorm_stats_kernel<float>), dim3(slabs, N), dim3(NORM_THREADS), 0, (hipStream_t)stream, na);
+  return TAPIR_OK;
+}
+
+int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float* gamma,
+                     const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
+                     int out_h, int out_w, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!x || !part || !gamma || !beta || !y || N < 1 || H < 1 || W < 1 || slabs < 1 || out_h < H ||
+      out_w < W || (y_sub && ((H | W) & 1)))
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  NormApplyArgs na{};
+  na.x = x; na.part = part; na.gamma = gamma; na.beta = beta; na.y = y; na.y_sub = y_sub;
+  na.H = H; na.W = W; na.C = C; na.slabs = slabs; na.oh = out_h; na.ow = out_w;
+  na.pix_slabs = std::max(1, std::min(H * W / 64, (2048 + N - 1) / N));
+  if (c->cfg.dtype == TAPIR_BF16)
+    hipLaunchKernelGGL((inorm_relu_kernel<bf16_t>), dim3(na.pix_slabs, N), dim3(NORM_THREADS), 0, (hipStream_t)stream, na);
+  else
+    hipLaunchKernelGGL((inorm_relu_kernel<float>), dim3(na.pix_slabs, N), dim3(NORM_THREADS), 0, (hipStream_t)stream, na);
+  return TAPIR_OK;
+}
+
+int tapir_l2_normalize(tapir_ctx* c, const void* x, float* out, long pixels, int C, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!x || !out || pixels < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!norm_channels_ok(c, C, 64)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  const int ept = c->cfg.dtype == TAPIR_BF16 ? 8 : 4;
+  const int PP = NORM_THREADS / (C / ept);
+  L2Args la{x, out, pixels, C};
+  const unsigned grid = (unsigned)std::min<long>((pixels + PP - 1) / PP, 8192);
+  if (c->cfg.dtype == TAPIR_BF16)
+    hipLaunchKernelGGL((l2norm_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+  else
+    hipLaunchKernelGGL((l2norm_kernel<float>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
   return TAPIR_OK;
 }
 

@@ -73,27 +73,18 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   const int c0 = tid * 2;                      // this thread's two channels in phase 2
   const float* __restrict__ xin = a.x_in + (long)n * T * kHidden;
 
-  // ---- phase 0: stage every input row this chunk touches
+  // ---- phase 0: stage every input row this chunk touches: the rows are contiguous in global
+  // memory (2 KiB each), so they go to LDS by DMA, 1 KiB (half a row) per wave instruction
   const int xlo = max(0, t0 + 2 * off0);
   const int xhi = min(T - 1, t1 - 1 + 2 * off0 + 4);
   const int nrows = xhi - xlo + 1;
   {
-    const float4* src = reinterpret_cast<const float4*>(xin + (long)xlo * kHidden);
-    float4* dst = reinterpret_cast<float4*>(&s_x[0][0]);
-    const int total = nrows * (kHidden / 4);
-    float4 tmp[MIX_MAX_ROWS / 2];
-#pragma unroll
-    for (int k = 0; k < MIX_MAX_ROWS / 2; ++k) {
-      const int idx = tid + k * MIX_THREADS;
-      if (idx < total) tmp[k] = src[idx];
-    }
-#pragma unroll
-    for (int k = 0; k < MIX_MAX_ROWS / 2; ++k) {
-      const int idx = tid + k * MIX_THREADS;
-      if (idx < total) dst[idx] = tmp[k];
-    }
+    const float* src = xin + (long)xlo * kHidden;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int k = wave_u; k < nrows * 2; k += MIX_THREADS / 64)
+      glds16(src + k * 256 + lane * 4, &s_x[0][0] + k * 256);
   }
-  __syncthreads();
+  __syncthreads();   // drains the DMA (vmcnt) and makes the rows visible
 
   // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
   for (int r = wave; r < nrows; r += 4) {

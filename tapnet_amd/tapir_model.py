@@ -201,7 +201,8 @@ class TAPIR:
     if any(k.startswith('resnet_torch.') for k in host):
       self._backbone = backbone_lib.Backbone(
           host, self.extra_convs, self.device,
-          torch.bfloat16 if self.dtype == 'bfloat16' else torch.float32, self.blocks_per_group)
+          torch.bfloat16 if self.dtype == 'bfloat16' else torch.float32, self.blocks_per_group,
+          engine=(self._lib, self._ctx))
     self._weights_loaded = True
 
   def reserve(self, batch: int, num_queries: int, num_frames: int, lowres_hw: Tuple[int, int]):

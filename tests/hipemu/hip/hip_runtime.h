@@ -231,15 +231,20 @@ inline void wave_collective(Dep dep, Comp comp, Rd rd) {
   wb.arrived++;
   unsigned wave_size = b->nthreads - (t / 64) * 64;
   if (wave_size > 64) wave_size = 64;
-  // lanes of this wave that already returned never arrive: count live lanes
-  unsigned live_lanes = 0;
-  for (unsigned l = 0; l < wave_size; ++l) live_lanes += !b->fibers[(t / 64) * 64 + l].done;
-  if (wb.arrived >= (int)live_lanes) {
-    comp(wb);
-    wb.arrived = 0;
-    w.seq = my + 1;
-  } else {
-    while (w.seq == my) yield();
+  // lanes of this wave that already returned never arrive: count live lanes.  A waiting lane
+  // re-counts every time it is scheduled: lanes that left a loop early finish (and stop being
+  // live) only after the others have started to wait -- the hardware analogue is the exec mask.
+  for (;;) {
+    if (w.seq != my) break;   // somebody completed the collective
+    unsigned live_lanes = 0;
+    for (unsigned l = 0; l < wave_size; ++l) live_lanes += !b->fibers[(t / 64) * 64 + l].done;
+    if (wb.arrived >= (int)live_lanes) {
+      comp(wb);
+      wb.arrived = 0;
+      w.seq = my + 1;
+      break;
+    }
+    yield();
   }
   rd(wb, lane);
 }

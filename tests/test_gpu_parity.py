@@ -153,10 +153,12 @@ def test_causal_streaming_golden():
 def test_backbone_golden_gpu(tag, extra):
   from tests.golden_util import GOLDEN_DIR
   import os
-  from tapnet_amd import backbone
+  from tapnet_amd import tapir_model
   g = np.load(os.path.join(GOLDEN_DIR, 'backbone.npz'))
   w = synthetic.make_weights(21, 1, extra)
-  bb = backbone.Backbone(w, extra, 'cuda:0')
+  # the GPU backbone = MIOpen convolutions + the HIP glue kernels of csrc/backbone.hpp
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=extra, weights=w, device='cuda:0')
+  bb = m._backbone   # (m owns the engine context the backbone calls into)
   v = torch.as_tensor(g['video']).cuda()
   low, hi = bb.features(v.reshape(-1, 64, 64, 3))
   np.testing.assert_allclose(low.cpu().numpy(), g[f'{tag}_lowres'][0], atol=2e-4)
