@@ -150,14 +150,38 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_stats_kernel(NormStatsArgs
   }
 }
 
-struct NormApplyArgs {
-  const void* x;        // [N, H, W, C]
+struct NormFinalizeArgs {
   const float* part;    // [N, slabs, C, 2] from inorm_stats_kernel
   const float* gamma;   // [C] scale
   const float* beta;    // [C] offset
+  float* ss;            // [N, C, 2]: (rstd * gamma, beta - mean * rstd * gamma)
+  int HW, C, slabs;
+};
+
+// grid (N), one thread per channel: merges the slab summaries once per (image, channel).
+__global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinalizeArgs a) {
+  const int n = blockIdx.x;
+  const int per_s = (a.HW + a.slabs - 1) / a.slabs;
+  for (int c = threadIdx.x; c < a.C; c += NORM_THREADS) {
+    float cn = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < a.slabs; ++s) {
+      const float nb = (float)max(0, min(a.HW, (s + 1) * per_s) - s * per_s);
+      const float* in = a.part + (((long)n * a.slabs + s) * a.C + c) * 2;
+      merge_stats(cn, mean, m2, nb, in[0], in[1]);
+    }
+    const float rstd = 1.0f / sqrtf(m2 / (float)a.HW + kInEps);
+    const float sc = rstd * a.gamma[c];
+    a.ss[((long)n * a.C + c) * 2] = sc;
+    a.ss[((long)n * a.C + c) * 2 + 1] = a.beta[c] - mean * sc;
+  }
+}
+
+struct NormApplyArgs {
+  const void* x;        // [N, H, W, C]
+  const float* ss;      // [N, C, 2] from inorm_finalize_kernel
   void* y;              // [N, oh, ow, C]: pixel (h, w) -> (h, w); rows/cols >= H / W are never written
   void* y_sub;          // null, or [N, H/2, W/2, C]: the pixels with even h and w
-  int H, W, C, slabs, oh, ow;
+  int H, W, C, oh, ow;
   int pix_slabs;        // gridDim.x
 };
 
@@ -170,30 +194,13 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_relu_kernel(NormApplyArgs 
   const int cg = tid % G, pl = tid / G;
   const int n = blockIdx.y;
   const int HW = a.H * a.W;
-  // merge the slab summaries of this thread's channels (slab s has length len(s))
-  const int per_s = (HW + a.slabs - 1) / a.slabs;
   float scale[EPT], shift[EPT];
   {
-    float mean[EPT], m2[EPT];
-    float cn = 0.f;
+    const float4* in = reinterpret_cast<const float4*>(a.ss + ((long)n * a.C + cg * EPT) * 2);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) { mean[e] = 0.f; m2[e] = 0.f; }
-    for (int s = 0; s < a.slabs; ++s) {
-      const float nb = (float)max(0, min(HW, (s + 1) * per_s) - s * per_s);
-      const float* in = a.part + (((long)n * a.slabs + s) * a.C + cg * EPT) * 2;
-      float ncur = cn;
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        ncur = cn;
-        merge_stats(ncur, mean[e], m2[e], nb, in[2 * e], in[2 * e + 1]);
-      }
-      cn = ncur;
-    }
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const float rstd = 1.0f / sqrtf(m2[e] / (float)HW + kInEps);
-      scale[e] = rstd * a.gamma[cg * EPT + e];
-      shift[e] = a.beta[cg * EPT + e] - mean[e] * scale[e];
+    for (int e = 0; e < EPT; e += 2) {
+      const float4 t = in[e / 2];
+      scale[e] = t.x; shift[e] = t.y; scale[e + 1] = t.z; shift[e + 1] = t.w;
     }
   }
   const int per = (HW + a.pix_slabs - 1) / a.pix_slabs;

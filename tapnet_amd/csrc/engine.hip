@@ -58,6 +58,7 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
+  DevBuf norm_ss;   // [N, C, 2] scale / shift of the InstanceNorm being applied
   // which caller grid each cast slot currently holds (valid within one call)
   const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
 
@@ -594,7 +595,7 @@ void tapir_destroy(tapir_ctx* c) {
   for (void* p : c->owned) (void)hipFree(p);
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
-                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled};
+                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->norm_ss};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
@@ -818,9 +819,12 @@ int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float
       out_w < W || (y_sub && ((H | W) & 1)))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  TRY(ensure(c, c->norm_ss, (size_t)N * C * 2 * sizeof(float)));
+  NormFinalizeArgs nf{part, gamma, beta, (float*)c->norm_ss.p, H * W, C, slabs};
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   NormApplyArgs na{};
-  na.x = x; na.part = part; na.gamma = gamma; na.beta = beta; na.y = y; na.y_sub = y_sub;
-  na.H = H; na.W = W; na.C = C; na.slabs = slabs; na.oh = out_h; na.ow = out_w;
+  na.x = x; na.ss = (const float*)c->norm_ss.p; na.y = y; na.y_sub = y_sub;
+  na.H = H; na.W = W; na.C = C; na.oh = out_h; na.ow = out_w;
   na.pix_slabs = std::max(1, std::min(H * W / 64, (2048 + N - 1) / N));
   if (c->cfg.dtype == TAPIR_BF16)
     hipLaunchKernelGGL((inorm_relu_kernel<bf16_t>), dim3(na.pix_slabs, N), dim3(NORM_THREADS), 0, (hipStream_t)stream, na);
