@@ -207,9 +207,10 @@ int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, lon
                      int M, int N, int K, int epi, int tile, void* stream);
 /* One launch of the token-mixing kernel of mixer block `block` (LN, temporal depthwise
  * convs, GELU, group sum, skip, LN): x_in [N,T,512] f32 -> x_out [N,T,512] f32 and
- * xn [N*T,512] in the operand type.  Non-causal contexts only. */
+ * xn [N*T,512] in the operand type.  Non-causal contexts only.  tc: 0 = automatic, 12 / 24 = force
+ * the streamed kernel with that many frames per workgroup. */
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
-                    int N, int T, void* stream);
+                    int N, int T, int tc, void* stream);
 
 /* RCCL all-gather of frame-sharded feature grids over xGMI is
  * done by the host layer with torch.distributed (backend "nccl" == RCCL); the

@@ -308,7 +308,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     m.ctx2_out = ctx2_out ? ctx2_out + (size_t)i * N * 2 * kHidden4 : nullptr;
     m.T = T; m.TC = TC; m.causal = c->cfg.use_causal_conv;
     { ProfScope ps(c, TAPIR_PROF_MIX, s);
-      hipLaunchKernelGGL((mix_kernel<TA>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m); }
+      launch_mix<TA>(m, N, s); }
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
@@ -872,21 +872,18 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 }
 
 int tapir_debug_mix(tapir_ctx* c, int block, const float* x_in, float* x_out, void* xn, int N,
-                    int T, void* stream) {
+                    int T, int tc, void* stream) {
   REQUIRE_READY(c);
   if (block < 0 || block >= (int)c->blocks.size() || !x_in || !x_out || !xn || N < 1 || T < 1 ||
-      x_in == x_out)
+      x_in == x_out || (tc != 0 && tc != 12 && tc != 24))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   const BlockW& bw = c->blocks[block];
   MixArgs m{};
   m.x_in = x_in; m.x_out = x_out; m.xn2 = xn;
   m.ln1 = bw.ln1; m.w1 = bw.w1; m.b1 = bw.b1; m.w2 = bw.w2; m.b2 = bw.b2; m.ln2 = bw.ln2;
   m.T = T; m.TC = pick_time_chunk(N, T); m.causal = c->cfg.use_causal_conv;
-  const int nch = (T + m.TC - 1) / m.TC;
-  if (c->cfg.dtype == TAPIR_BF16)
-    hipLaunchKernelGGL((mix_kernel<bf16_t>), dim3(nch, N), dim3(MIX_THREADS), 0, (hipStream_t)stream, m);
-  else
-    hipLaunchKernelGGL((mix_kernel<float>), dim3(nch, N), dim3(MIX_THREADS), 0, (hipStream_t)stream, m);
+  if (c->cfg.dtype == TAPIR_BF16) launch_mix<bf16_t>(m, N, (hipStream_t)stream, tc);
+  else launch_mix<float>(m, N, (hipStream_t)stream, tc);
   return TAPIR_OK;
 }
 

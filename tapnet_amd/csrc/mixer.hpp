@@ -237,6 +237,169 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mix_stream_kernel: the non-causal token-mixing kernel for whole clips (SAME padding).
+//
+// Same data flow as mix_kernel, restructured around what PMC counters showed it to be: VALU-bound
+// (2200 VALU instructions per wave at 4 cycles each, a third of them register-window moves,
+// branches and scalar selects).  Here the temporal stream is fully unrolled over a compile-time
+// chunk length TC, so the 3-frame windows are static registers (no moves); the LayerNorm-1 scale
+// is folded into the first convolution's weights and the second convolution's biases into one
+// constant; and every operation acts on the thread's TWO ADJACENT channels, so the compiler emits
+// packed f32 math (v_pk_fma_f32 / v_pk_mul_f32: 2 lanes-worth per issue on the SIMD-16 VALU).
+//   rows  r = 0 .. TC+3  <->  frames tau = t0 - 2 + r;  outputs o = t0 .. t0 + TC - 1
+//   xn_r            = LN1(x)[tau]            (0 outside the clip: SAME padding of conv 1)
+//   g_{r-1}[m]      = gelu(b1[m] + sum_k w1'[m][k] xn_{r-2+k})     (0 outside the clip)
+//   x'[o = tau - 2] = x[o] + B2 + sum_m sum_k w2[m][k] g_{o-1+k}[m]
+template <typename TO, int TC>
+__global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a) {
+  constexpr int ROWS = TC + 4;
+  __shared__ float s_x[ROWS][kHidden];
+  __shared__ float2 s_stat[ROWS];   // (mean, rstd) of LayerNorm-1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y;
+  const int T = a.T;
+  const int t0 = blockIdx.x * TC;
+  const int c0 = tid * 2;
+  const float* __restrict__ xin = a.x_in + (long)n * T * kHidden;
+
+  // ---- phase 0: rows tau = t0-2 .. t0+TC+1 that exist, by DMA (1 KiB = half a row per wave op);
+  // rows outside the clip are zero-filled, so that the stream below needs no branches
+  const int lo = max(0, t0 - 2), hi = min(T - 1, t0 + TC + 1);   // staged frames, LDS row = tau - (t0-2)
+  const int rlo = lo - (t0 - 2), rhi = hi - (t0 - 2);
+  {
+    const float* src = xin + (long)lo * kHidden;
+    float* dst = &s_x[rlo][0];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int k = wave_u; k < (hi - lo + 1) * 2; k += MIX_THREADS / 64)
+      glds16(src + k * 256 + lane * 4, dst + k * 256);
+    for (int r = 0; r < ROWS; ++r)
+      if (r < rlo || r > rhi) *reinterpret_cast<float2*>(&s_x[r][c0]) = make_float2(0.f, 0.f);
+    if (tid < ROWS && (tid < rlo || tid > rhi)) s_stat[tid] = make_float2(0.f, 0.f);
+  }
+  // per-thread weights while the rows are in flight: 2 channels x 4 multipliers x 3 taps, twice
+  float2 w1[4][3], b1[4], w2[4][3];
+  float2 B2 = make_float2(0.f, 0.f);
+  {
+    const float2 sc = *reinterpret_cast<const float2*>(a.ln1 + c0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int oa = 4 * c0 + m, ob = 4 * (c0 + 1) + m;
+      b1[m] = make_float2(a.b1[oa], a.b1[ob]);
+      B2.x += a.b2[oa]; B2.y += a.b2[ob];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        w1[m][k] = make_float2(a.w1[oa * 3 + k] * sc.x, a.w1[ob * 3 + k] * sc.y);
+        w2[m][k] = make_float2(a.w2[oa * 3 + k], a.w2[ob * 3 + k]);
+      }
+    }
+  }
+  __syncthreads();   // drains the DMA (vmcnt) and makes the rows visible
+
+  // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
+  for (int r = rlo + wave; r <= rhi; r += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
+    const float4 v = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
+    float mean, rstd;
+    wave_row_stats(u, v, mean, rstd);
+    if (lane == 0) s_stat[r] = make_float2(mean, rstd);
+  }
+  __syncthreads();
+
+  // ---- phase 2: the unrolled temporal stream (straight-line code: rows outside the clip were
+  // zero-filled with zero statistics, and g outside the clip is multiplied by 0)
+  float2 xn[3];          // LN1(x) of rows r-2, r-1, r
+  float2 g[3][4];        // GELU outputs of rows r-3, r-2, r-1
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    xn[k] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) g[k][m] = make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int tau = t0 - 2 + r;
+    {
+      const float2 v = *reinterpret_cast<const float2*>(&s_x[r][c0]);
+      const float2 st = s_stat[r];
+      xn[r % 3] = make_float2((v.x - st.x) * st.y, (v.y - st.x) * st.y);
+    }
+    if (r >= 2) {
+      // g of row r-1 (frame tau-1) from xn rows r-2, r-1, r; zero outside the clip
+      const float gm = (tau - 1 >= 0 && tau - 1 < T) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float2 u = b1[m];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float2 xv = xn[(r - 2 + k) % 3];
+          u.x = fmaf(w1[m][k].x, xv.x, u.x);
+          u.y = fmaf(w1[m][k].y, xv.y, u.y);
+        }
+        g[(r - 1) % 3][m] = make_float2(gelu_tanh(u.x) * gm, gelu_tanh(u.y) * gm);
+      }
+    }
+    if (r >= 4) {
+      // output frame o = tau - 2 (row r-2) from g rows r-3, r-2, r-1
+      float2 y = B2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float2 gv = g[(r - 3 + k) % 3][m];
+          y.x = fmaf(w2[m][k].x, gv.x, y.x);
+          y.y = fmaf(w2[m][k].y, gv.y, y.y);
+        }
+      float2* px = reinterpret_cast<float2*>(&s_x[r - 2][c0]);
+      const float2 xv = *px;
+      *px = make_float2(xv.x + y.x, xv.y + y.y);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: LayerNorm-2 and stores, wave w takes output frames t0+w, t0+w+4, ...
+  const float4 s2a = *reinterpret_cast<const float4*>(a.ln2 + lane * 4);
+  const float4 s2b = *reinterpret_cast<const float4*>(a.ln2 + 256 + lane * 4);
+  const int t1 = min(T, t0 + TC);
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][lane * 4]);
+    const float4 v = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][256 + lane * 4]);
+    float mean, rs;
+    wave_row_stats(u, v, mean, rs);
+    const long row = (long)n * T + t;
+    float* xo = a.x_out + row * kHidden;
+    *reinterpret_cast<float4*>(xo + lane * 4) = u;
+    *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v;
+    TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
+    Store4<TO>::run(o + lane * 4, (u.x - mean) * rs * s2a.x, (u.y - mean) * rs * s2a.y,
+                    (u.z - mean) * rs * s2a.z, (u.w - mean) * rs * s2a.w);
+    Store4<TO>::run(o + 256 + lane * 4, (v.x - mean) * rs * s2b.x, (v.y - mean) * rs * s2b.y,
+                    (v.z - mean) * rs * s2b.z, (v.w - mean) * rs * s2b.w);
+  }
+}
+
+// Launches the token-mixing kernel of one block: the streamed kernel for whole clips, the
+// general one (time chunks chosen at run time, causal padding and state) otherwise.
+template <typename TO>
+inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc = 0) {
+  MixArgs m = m_in;
+  const bool plain = !m.causal && !m.ctx1_in && !m.ctx2_in && !m.ctx1_out && !m.ctx2_out;
+  if (plain && m.T >= 12) {
+    // 24-frame chunks (2 workgroups of 56 KiB per CU, 17 % halo) once they still fill the chip
+    const bool big = force_tc ? force_tc == 24 : (long)N * ((m.T + 23) / 24) >= 512;
+    if (big) {
+      hipLaunchKernelGGL((mix_stream_kernel<TO, 24>), dim3((m.T + 23) / 24, N), dim3(MIX_THREADS), 0, s, m);
+    } else {
+      hipLaunchKernelGGL((mix_stream_kernel<TO, 12>), dim3((m.T + 11) / 12, N), dim3(MIX_THREADS), 0, s, m);
+    }
+    return;
+  }
+  const int nch = (m.T + m.TC - 1) / m.TC;
+  hipLaunchKernelGGL((mix_kernel<TO>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m);
+}
+
 // Row-wise LayerNorm (scale only) -> operand type; one wave per row of 512.
 struct LnArgs { const float* x; const float* scale; void* out; long rows; };
 template <typename TO>

@@ -192,3 +192,31 @@ def test_causal_streaming_golden():
   np.testing.assert_allclose(c1[-1, 0].reshape(1, Q, 2, 512), g['state_last_block_0_causal_1'], atol=1e-3)
   np.testing.assert_allclose(c2[-1, 11].reshape(1, Q, 2, 2048), g['state_last_block_11_causal_2'], atol=1e-3)
   e.close()
+
+
+@pytest.mark.parametrize('tc', [12, 24])
+def test_mix_stream_kernel(tc):
+  """The unrolled token-mixing kernel (both chunk lengths, partial last chunk) against the oracle's
+  first half of a PIPsConvBlock."""
+  import ctypes
+  w = synthetic.make_weights(8, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(64, 64))
+  rng = np.random.default_rng(tc)
+  N, T = 2, 31
+  x = rng.standard_normal((N, T, 512)).astype(np.float32)
+  xo = np.zeros_like(x)
+  xn = np.zeros((N * T, 512), np.float32)
+  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  rc = e.lib.tapir_debug_mix(e.ctx, 0, p(x), p(xo), p(xn), N, T, tc, None)
+  assert rc == 0
+  # first half of PIPsConvBlock (tapir_model.py:111-121), from the oracle's own pieces
+  pre = 'torch_pips_mixer.blocks.0.'
+  y = O.layernorm(x, w[pre + 'layer_norm.weight'])
+  y = O._depthwise_conv1d(y, w[pre + 'mlp1_up.weight'], w[pre + 'mlp1_up.bias'], 4, False)
+  y = O.gelu_tanh(y)
+  y = O._depthwise_conv1d(y, w[pre + 'mlp1_up_1.weight'], w[pre + 'mlp1_up_1.bias'], 1, False)
+  ref_x = y[..., 0::4] + y[..., 1::4] + y[..., 2::4] + y[..., 3::4] + x
+  ref_xn = O.layernorm(ref_x, w[pre + 'layer_norm_1.weight'])
+  np.testing.assert_allclose(xo, ref_x, atol=2e-5)
+  np.testing.assert_allclose(xn.reshape(N, T, 512), ref_xn, atol=2e-5)
+  e.close()

@@ -126,17 +126,18 @@ def bench_mix(model, reps, results):
   xo = [torch.empty(N, T, 512, device=dev) for _ in range(3)]
   xn = [torch.empty(N * T, 512, device=dev, dtype=torch.bfloat16 if bf else torch.float32) for _ in range(3)]
 
-  def run(i):
+  for tc in (0, 12, 24):
+   def run(i, tc=tc):
     k = i % 3
-    rc = lib.tapir_debug_mix(ctx, 0, x[k].data_ptr(), xo[k].data_ptr(), xn[k].data_ptr(), N, T, stream)
+    rc = lib.tapir_debug_mix(ctx, 0, x[k].data_ptr(), xo[k].data_ptr(), xn[k].data_ptr(), N, T, tc, stream)
     assert rc == 0, lib.tapir_last_error(ctx)
-  t = timeit(run, reps)
-  tb = timeit_batch(run, reps)
-  byts = N * T * 512 * (4 + 4 + (2 if bf else 4))
-  row = dict(kernel='mix', dtype=model.dtype, **t, batch_us=tb,
-             alg_GBps=round(byts / (t['med_us'] * 1e-6) / 1e9, 1), alg_bytes=byts)
-  results.append(row)
-  print(json.dumps(row), flush=True)
+   t = timeit(run, reps)
+   tb = timeit_batch(run, reps)
+   byts = N * T * 512 * (4 + 4 + (2 if bf else 4))
+   row = dict(kernel='mix', tile=f'tc{tc}', dtype=model.dtype, **t, batch_us=tb,
+              alg_GBps=round(byts / (t['med_us'] * 1e-6) / 1e9, 1), alg_bytes=byts)
+   results.append(row)
+   print(json.dumps(row), flush=True)
 
 
 def bench_mixer(model, reps, results):
