@@ -207,8 +207,11 @@ int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, lon
                      int M, int N, int K, int epi, int tile, void* stream);
 /* One launch of the token-mixing kernel of mixer block `block` (LN, temporal depthwise
  * convs, GELU, group sum, skip, LN): x_in [N,T,512] f32 -> x_out [N,T,512] f32 and
- * xn [N*T,512] in the operand type.  Non-causal contexts only.  tc: 0 = automatic, 12 / 24 = force
- * the streamed kernel with that many frames per workgroup. */
+ * xn [N*T,512] in the operand type.  Non-causal contexts only.  tc: 0 = automatic, > 0 caps the
+ * number of persistent workgroups (tests: several units per workgroup). */
+/* Phase tracing for tools/kbench.py: when a device buffer of int64 [units][6] is set, the next
+ * tapir_debug_mix launches write wall-clock stamps (100 MHz) per work unit; NULL turns it off. */
+int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

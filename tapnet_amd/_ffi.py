@@ -81,6 +81,7 @@ PROTOTYPES = {
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
+    'tapir_debug_set_trace': (c_int, [c_void_p, c_void_p]),
     'tapir_debug_mix': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p]),
     'tapir_profile_enable': (c_int, [c_void_p, c_int]),

@@ -88,6 +88,16 @@ __device__ __forceinline__ void consume(const f32x4& v) {
   asm volatile("" ::"v"(v));
 #endif
 }
+// Workgroup barrier that orders LDS traffic only (lgkmcnt), leaving vector-memory operations --
+// LDS-DMA copies, stores -- in flight.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef TAPIR_HIPEMU
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#endif
+}
 // Compiler scheduling fence: no instruction is moved across it (bounds live ranges).
 __device__ __forceinline__ void sched_fence() {
 #ifndef TAPIR_HIPEMU
@@ -105,7 +115,19 @@ __device__ __forceinline__ void block_barrier() {
 #endif
 }
 
+// Wave-wide (64 lanes) reductions on the DPP data path: four row-local steps (quad swaps, half-row
+// and row mirrors), two row broadcasts, then a v_readlane of lane 63.  Seven VALU instructions
+// with no LDS round trip -- __shfl_xor is a ds_bpermute per step (~60 cycles of dependent latency
+// each; the LayerNorm statistics spent 3 us per 16 rows in them).  The result is wave-uniform.
+#ifndef TAPIR_HIPEMU
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL,
+                                                    ROW_MASK, 0xf, false));
+}
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef TAPIR_HIPEMU
   v += __shfl_xor(v, 32);
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 8);
@@ -113,8 +135,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 2);
   v += __shfl_xor(v, 1);
   return v;
+#else
+  v += dpp_f32<0xB1, 0xf>(0.f, v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xf>(0.f, v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xf>(0.f, v);   // row_half_mirror
+  v += dpp_f32<0x140, 0xf>(0.f, v);   // row_mirror: every lane holds its row's sum
+  v += dpp_f32<0x142, 0xa>(0.f, v);   // row_bcast:15 -> rows 1, 3
+  v += dpp_f32<0x143, 0xc>(0.f, v);   // row_bcast:31 -> rows 2, 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef TAPIR_HIPEMU
   v = fmaxf(v, __shfl_xor(v, 32));
   v = fmaxf(v, __shfl_xor(v, 16));
   v = fmaxf(v, __shfl_xor(v, 8));
@@ -122,6 +154,15 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 2));
   v = fmaxf(v, __shfl_xor(v, 1));
   return v;
+#else
+  v = fmaxf(v, dpp_f32<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(v, v));   // lanes not written keep v (old = v)
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 
 // Raw hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp): exp2f() and operator/ expand to

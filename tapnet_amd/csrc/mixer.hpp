@@ -37,6 +37,7 @@ struct MixArgs {
   int T;                  // frames per track
   int TC;                 // frames per workgroup (<= MIX_MAX_TC)
   int causal;             // use_causal_conv
+  long long* dbg_times;   // null, or [units][6] wall-clock stamps (tools/kbench.py --mix-trace)
 };
 
 // Row statistics by ONE wave: the lane holds channels [4*lane, 4*lane+4) and
@@ -251,35 +252,57 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
 //   xn_r            = LN1(x)[tau]            (0 outside the clip: SAME padding of conv 1)
 //   g_{r-1}[m]      = gelu(b1[m] + sum_k w1'[m][k] xn_{r-2+k})     (0 outside the clip)
 //   x'[o = tau - 2] = x[o] + B2 + sum_m sum_k w2[m][k] g_{o-1+k}[m]
+// One (track, time chunk) unit of mix_stream_kernel, split into "stage the rows" and "process",
+// so that a persistent workgroup can copy the rows of its NEXT unit while it computes the current
+// one (two row buffers) and let the stores of a unit drain under the next unit's arithmetic: with
+// one unit per workgroup every workgroup of the chip is in the same phase at the same time
+// (all loading, then all computing, then all storing) and HBM idles two thirds of the time.
+template <int TC>
+struct MixUnit {
+  static constexpr int ROWS = TC + 4;
+  int n, t0, rlo, rhi;
+  __device__ __forceinline__ void set(int u, int nch, int T) {
+    n = u / nch;
+    t0 = (u - n * nch) * TC;
+    const int lo = max(0, t0 - 2), hi = min(T - 1, t0 + TC + 1);   // staged frames
+    rlo = lo - (t0 - 2); rhi = hi - (t0 - 2);                      // LDS row = tau - (t0 - 2)
+  }
+};
+
 template <typename TO, int TC>
-__global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a) {
+__global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int units, int nch) {
   constexpr int ROWS = TC + 4;
-  __shared__ float s_x[ROWS][kHidden];
-  __shared__ float2 s_stat[ROWS];   // (mean, rstd) of LayerNorm-1
+  // two separate objects: reads of one buffer must not wait for the DMA into the other
+  __shared__ float s_xa[ROWS][kHidden];
+  __shared__ float s_xb[ROWS][kHidden];
+  __shared__ float2 s_stata[ROWS];   // (mean, rstd) of LayerNorm-1
+  __shared__ float2 s_statb[ROWS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.y;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int T = a.T;
-  const int t0 = blockIdx.x * TC;
   const int c0 = tid * 2;
-  const float* __restrict__ xin = a.x_in + (long)n * T * kHidden;
+  int u = blockIdx.x;
+  if (u >= units) return;
 
-  // ---- phase 0: rows tau = t0-2 .. t0+TC+1 that exist, by DMA (1 KiB = half a row per wave op);
-  // rows outside the clip are zero-filled, so that the stream below needs no branches
-  const int lo = max(0, t0 - 2), hi = min(T - 1, t0 + TC + 1);   // staged frames, LDS row = tau - (t0-2)
-  const int rlo = lo - (t0 - 2), rhi = hi - (t0 - 2);
-  {
-    const float* src = xin + (long)lo * kHidden;
-    float* dst = &s_x[rlo][0];
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    for (int k = wave_u; k < (hi - lo + 1) * 2; k += MIX_THREADS / 64)
+  // rows tau = t0-2 .. t0+TC+1 that exist, by DMA (1 KiB = half a row per wave op); rows outside
+  // the clip are zero-filled with zero statistics, so that the stream needs no branches
+  auto stage = [&](const MixUnit<TC>& q, float (*sx)[kHidden], float2* sstat) {
+    const float* src = a.x_in + ((long)q.n * T + (q.t0 - 2 + q.rlo)) * kHidden;
+    float* dst = &sx[q.rlo][0];
+    for (int k = wave_u; k < (q.rhi - q.rlo + 1) * 2; k += MIX_THREADS / 64)
       glds16(src + k * 256 + lane * 4, dst + k * 256);
     for (int r = 0; r < ROWS; ++r)
-      if (r < rlo || r > rhi) *reinterpret_cast<float2*>(&s_x[r][c0]) = make_float2(0.f, 0.f);
-    if (tid < ROWS && (tid < rlo || tid > rhi)) s_stat[tid] = make_float2(0.f, 0.f);
-  }
-  // per-thread weights while the rows are in flight: 2 channels x 4 multipliers x 3 taps, twice
+      if (r < q.rlo || r > q.rhi) *reinterpret_cast<float2*>(&sx[r][c0]) = make_float2(0.f, 0.f);
+    if (tid < ROWS && (tid < q.rlo || tid > q.rhi)) sstat[tid] = make_float2(0.f, 0.f);
+  };
+
+  MixUnit<TC> cur, nxt;
+  cur.set(u, nch, T);
+  stage(cur, s_xa, s_stata);
+
+  // per-thread weights (once per workgroup): 2 channels x 4 multipliers x 3 taps, twice
   float2 w1[4][3], b1[4], w2[4][3];
   float2 B2 = make_float2(0.f, 0.f);
   {
@@ -296,104 +319,131 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a) {
       }
     }
   }
-  __syncthreads();   // drains the DMA (vmcnt) and makes the rows visible
-
-  // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
-  for (int r = rlo + wave; r <= rhi; r += 4) {
-    const float4 u = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
-    const float4 v = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
-    float mean, rstd;
-    wave_row_stats(u, v, mean, rstd);
-    if (lane == 0) s_stat[r] = make_float2(mean, rstd);
-  }
-  __syncthreads();
-
-  // ---- phase 2: the unrolled temporal stream (straight-line code: rows outside the clip were
-  // zero-filled with zero statistics, and g outside the clip is multiplied by 0)
-  float2 xn[3];          // LN1(x) of rows r-2, r-1, r
-  float2 g[3][4];        // GELU outputs of rows r-3, r-2, r-1
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    xn[k] = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) g[k][m] = make_float2(0.f, 0.f);
-  }
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    const int tau = t0 - 2 + r;
-    {
-      const float2 v = *reinterpret_cast<const float2*>(&s_x[r][c0]);
-      const float2 st = s_stat[r];
-      xn[r % 3] = make_float2((v.x - st.x) * st.y, (v.y - st.x) * st.y);
-    }
-    if (r >= 2) {
-      // g of row r-1 (frame tau-1) from xn rows r-2, r-1, r; zero outside the clip
-      const float gm = (tau - 1 >= 0 && tau - 1 < T) ? 1.0f : 0.0f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float2 u = b1[m];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float2 xv = xn[(r - 2 + k) % 3];
-          u.x = fmaf(w1[m][k].x, xv.x, u.x);
-          u.y = fmaf(w1[m][k].y, xv.y, u.y);
-        }
-        g[(r - 1) % 3][m] = make_float2(gelu_tanh(u.x) * gm, gelu_tanh(u.y) * gm);
-      }
-    }
-    if (r >= 4) {
-      // output frame o = tau - 2 (row r-2) from g rows r-3, r-2, r-1
-      float2 y = B2;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float2 gv = g[(r - 3 + k) % 3][m];
-          y.x = fmaf(w2[m][k].x, gv.x, y.x);
-          y.y = fmaf(w2[m][k].y, gv.y, y.y);
-        }
-      float2* px = reinterpret_cast<float2*>(&s_x[r - 2][c0]);
-      const float2 xv = *px;
-      *px = make_float2(xv.x + y.x, xv.y + y.y);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: LayerNorm-2 and stores, wave w takes output frames t0+w, t0+w+4, ...
   const float4 s2a = *reinterpret_cast<const float4*>(a.ln2 + lane * 4);
   const float4 s2b = *reinterpret_cast<const float4*>(a.ln2 + 256 + lane * 4);
-  const int t1 = min(T, t0 + TC);
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const float4 u = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][lane * 4]);
-    const float4 v = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][256 + lane * 4]);
-    float mean, rs;
-    wave_row_stats(u, v, mean, rs);
-    const long row = (long)n * T + t;
-    float* xo = a.x_out + row * kHidden;
-    *reinterpret_cast<float4*>(xo + lane * 4) = u;
-    *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v;
-    TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
-    Store4<TO>::run(o + lane * 4, (u.x - mean) * rs * s2a.x, (u.y - mean) * rs * s2a.y,
-                    (u.z - mean) * rs * s2a.z, (u.w - mean) * rs * s2a.w);
-    Store4<TO>::run(o + 256 + lane * 4, (v.x - mean) * rs * s2b.x, (v.y - mean) * rs * s2b.y,
-                    (v.z - mean) * rs * s2b.z, (v.w - mean) * rs * s2b.w);
+
+  auto stamp = [&](int unit, int k) {
+    if (a.dbg_times != nullptr && tid == 0) a.dbg_times[(long)unit * 6 + k] = wall_clock64();
+  };
+  stamp(u, 0);
+  auto process = [&](const MixUnit<TC>& q, float (*s_x)[kHidden], float2* s_stat, int unit) {
+    const int t0 = q.t0;
+    stamp(unit, 2);
+    // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
+    for (int r = q.rlo + wave; r <= q.rhi; r += 4) {
+      const float4 u4 = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
+      const float4 v4 = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
+      float mean, rstd;
+      wave_row_stats(u4, v4, mean, rstd);
+      if (lane == 0) s_stat[r] = make_float2(mean, rstd);
+    }
+    lds_barrier();
+    stamp(unit, 3);
+
+    // ---- phase 2: the unrolled temporal stream (straight-line code)
+    float2 xn[3];          // LN1(x) of rows r-2, r-1, r
+    float2 g[3][4];        // GELU outputs of rows r-3, r-2, r-1
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      xn[k] = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) g[k][m] = make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int tau = t0 - 2 + r;
+      {
+        const float2 v = *reinterpret_cast<const float2*>(&s_x[r][c0]);
+        const float2 st = s_stat[r];
+        xn[r % 3] = make_float2((v.x - st.x) * st.y, (v.y - st.x) * st.y);
+      }
+      if (r >= 2) {
+        // g of row r-1 (frame tau-1) from xn rows r-2, r-1, r; zero outside the clip
+        const float gm = (tau - 1 >= 0 && tau - 1 < T) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float2 uu = b1[m];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float2 xv = xn[(r - 2 + k) % 3];
+            uu.x = fmaf(w1[m][k].x, xv.x, uu.x);
+            uu.y = fmaf(w1[m][k].y, xv.y, uu.y);
+          }
+          g[(r - 1) % 3][m] = make_float2(gelu_tanh(uu.x) * gm, gelu_tanh(uu.y) * gm);
+        }
+      }
+      if (r >= 4) {
+        // output frame o = tau - 2 (row r-2) from g rows r-3, r-2, r-1
+        float2 y = B2;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float2 gv = g[(r - 3 + k) % 3][m];
+            y.x = fmaf(w2[m][k].x, gv.x, y.x);
+            y.y = fmaf(w2[m][k].y, gv.y, y.y);
+          }
+        float2* px = reinterpret_cast<float2*>(&s_x[r - 2][c0]);
+        const float2 xv = *px;
+        *px = make_float2(xv.x + y.x, xv.y + y.y);
+      }
+    }
+    lds_barrier();
+    stamp(unit, 4);
+
+    // ---- phase 3: LayerNorm-2 and stores, wave w takes output frames t0+w, t0+w+4, ...
+    const int t1 = min(T, t0 + TC);
+    for (int t = t0 + wave; t < t1; t += 4) {
+      const float4 u4 = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][lane * 4]);
+      const float4 v4 = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][256 + lane * 4]);
+      float mean, rs;
+      wave_row_stats(u4, v4, mean, rs);
+      const long row = (long)q.n * T + t;
+      float* xo = a.x_out + row * kHidden;
+      *reinterpret_cast<float4*>(xo + lane * 4) = u4;
+      *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v4;
+      TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
+      Store4<TO>::run(o + lane * 4, (u4.x - mean) * rs * s2a.x, (u4.y - mean) * rs * s2a.y,
+                      (u4.z - mean) * rs * s2a.z, (u4.w - mean) * rs * s2a.w);
+      Store4<TO>::run(o + 256 + lane * 4, (v4.x - mean) * rs * s2b.x, (v4.y - mean) * rs * s2b.y,
+                      (v4.z - mean) * rs * s2b.z, (v4.w - mean) * rs * s2b.w);
+    }
+    stamp(unit, 5);
+  };
+
+  for (;;) {
+    // the rows of `cur` have landed in buffer a (and the stores of the previous unit are done)
+    dma_lds_wait<0>();
+    block_barrier();
+    stamp(u, 1);
+    int un = u + gridDim.x;
+    if (un < units) { nxt.set(un, nch, T); stage(nxt, s_xb, s_statb); stamp(un, 0); }
+    process(cur, s_xa, s_stata, u);
+    if (un >= units) break;
+    u = un; cur = nxt;
+    dma_lds_wait<0>();
+    block_barrier();
+    stamp(u, 1);
+    un = u + gridDim.x;
+    if (un < units) { nxt.set(un, nch, T); stage(nxt, s_xa, s_stata); stamp(un, 0); }
+    process(cur, s_xb, s_statb, u);
+    if (un >= units) break;
+    u = un; cur = nxt;
   }
 }
 
 // Launches the token-mixing kernel of one block: the streamed kernel for whole clips, the
 // general one (time chunks chosen at run time, causal padding and state) otherwise.
 template <typename TO>
-inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc = 0) {
+inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc = 0) {   // force_tc: grid cap (tests)
   MixArgs m = m_in;
   const bool plain = !m.causal && !m.ctx1_in && !m.ctx2_in && !m.ctx1_out && !m.ctx2_out;
   if (plain && m.T >= 12) {
-    // 24-frame chunks (2 workgroups of 56 KiB per CU, 17 % halo) once they still fill the chip
-    const bool big = force_tc ? force_tc == 24 : (long)N * ((m.T + 23) / 24) >= 512;
-    if (big) {
-      hipLaunchKernelGGL((mix_stream_kernel<TO, 24>), dim3((m.T + 23) / 24, N), dim3(MIX_THREADS), 0, s, m);
-    } else {
-      hipLaunchKernelGGL((mix_stream_kernel<TO, 12>), dim3((m.T + 11) / 12, N), dim3(MIX_THREADS), 0, s, m);
-    }
+    // 12-frame chunks, two row buffers (64 KiB): two persistent workgroups per CU
+    const int nch = (m.T + 11) / 12;
+    const int units = N * nch;
+    const int grid = force_tc > 0 ? std::min(units, force_tc) : std::min(units, 512);
+    hipLaunchKernelGGL((mix_stream_kernel<TO, 12>), dim3(grid), dim3(MIX_THREADS), 0, s, m, units, nch);
     return;
   }
   const int nch = (m.T + m.TC - 1) / m.TC;

@@ -126,7 +126,7 @@ def bench_mix(model, reps, results):
   xo = [torch.empty(N, T, 512, device=dev) for _ in range(3)]
   xn = [torch.empty(N * T, 512, device=dev, dtype=torch.bfloat16 if bf else torch.float32) for _ in range(3)]
 
-  for tc in (0, 12, 24):
+  for tc in (0, 256, 1024):
    def run(i, tc=tc):
     k = i % 3
     rc = lib.tapir_debug_mix(ctx, 0, x[k].data_ptr(), xo[k].data_ptr(), xn[k].data_ptr(), N, T, tc, stream)
@@ -138,6 +138,35 @@ def bench_mix(model, reps, results):
               alg_GBps=round(byts / (t['med_us'] * 1e-6) / 1e9, 1), alg_bytes=byts)
    results.append(row)
    print(json.dumps(row), flush=True)
+
+
+def trace_mix(model):
+  """per-unit phase stamps of the mix kernel (100 MHz wall clock): where does the time go"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  N, T = 256, 48
+  units = N * 4
+  x = torch.randn(N, T, 512, device=dev); xo = torch.empty_like(x)
+  xn = torch.empty(N * T, 512, device=dev, dtype=torch.bfloat16 if model.dtype == 'bfloat16' else torch.float32)
+  tr = torch.zeros(units, 6, dtype=torch.int64, device=dev)
+  for tc in (0, 1024):
+    for _ in range(3):
+      lib.tapir_debug_mix(ctx, 0, x.data_ptr(), xo.data_ptr(), xn.data_ptr(), N, T, tc, model._stream())
+    torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, tr.data_ptr())
+    lib.tapir_debug_mix(ctx, 0, x.data_ptr(), xo.data_ptr(), xn.data_ptr(), N, T, tc, model._stream())
+    torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, None)
+    t = tr.cpu().numpy().astype(np.float64) * 0.01   # us
+    t0 = t[:, 0].min()
+    t -= t0
+    names = ['stage issued', 'rows landed', 'process start', 'stats done', 'stream done', 'stores issued']
+    print(f'mix trace grid cap {tc}: kernel span {t.max():.1f} us')
+    for k in range(6):
+      print(f'  {names[k]:14s} min {t[:, k].min():6.1f}  median {np.median(t[:, k]):6.1f}  max {t[:, k].max():6.1f}')
+    d = np.diff(t, axis=1)
+    for k in range(5):
+      print(f'  phase {names[k]} -> {names[k + 1]}: median {np.median(d[:, k]):6.2f} us  p90 {np.percentile(d[:, k], 90):6.2f}')
 
 
 def bench_mixer(model, reps, results):
@@ -195,6 +224,8 @@ def main():
                  [int(d) for d in args.dbg.split(',')] if args.dbg else None)
     if 'mix' in what:
       bench_mix(model, args.reps, results)
+    if 'mixtrace' in what:
+      trace_mix(model)
     if 'mixer' in what:
       bench_mixer(model, args.reps, results)
     if need_bb:
