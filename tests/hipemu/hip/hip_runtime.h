@@ -455,6 +455,7 @@ static inline void __builtin_amdgcn_global_load_lds(
 
 // ---------------------------------------------------------------- misc device math
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline long long wall_clock64() { return 0; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
