@@ -25,10 +25,10 @@
 //     covers all 64 banks.
 //   * Operand roles are swapped in the MFMA (W rows feed the "A" port,
 //     activation rows the "B" port), so a lane ends up with 4 consecutive output
-//     columns of one output row per fragment.  The W rows a lane feeds to
-//     fragment j are PERMUTED (row = 4 FN (q>>2) + 4 j + (q&3) for port row q) so
-//     that its FN fragments hold 4 FN CONSECUTIVE columns: the epilogue stores
-//     32 B (bf16) / 64 B (f32) per lane, 128 / 256 contiguous bytes per row.
+//     columns of one output row per fragment.  Which W row feeds which port row
+//     is a free permutation; it is chosen per output type so that every store
+//     instruction (16 B per lane) writes 64 contiguous bytes per output row --
+//     full 32-byte sectors (GemmTile::col).
 //   * Persistent workgroups: grid = min(tiles, 2 per CU); a workgroup walks its
 //     tiles and issues the first DMA of the next tile before the epilogue of the
 //     current one.  Hardware block b runs on XCD b % 8: every XCD gets a
@@ -122,9 +122,22 @@ template <int WM_, int WN_, int FM_, int FN_, int NS_, bool PREFETCH_ = false> s
   static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "stage must split evenly");
   static_assert(FN % 2 == 0 && NS >= 2 && NS <= 4, "unsupported tile");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  // swizzle of W row R (tile-local): the low 3 bits of the fragment row q of the lane that reads
-  // it, q = 4 (R / (4 FN) % 4) + R % 4  ->  (R & 3) | bit (R / (4 FN)) & 1
-  static __device__ __forceinline__ int swz_w(int R) { return (R & 3) | (((R / (4 * FN)) & 1) << 2); }
+  // Output-column maps.  The lane (fr = l & 15, fg = l >> 4) feeds MFMA port row fr of fragment j
+  // with W row w_row(j, fr) and receives the 4 columns col(j, fg) .. +3 of output row fr.  One
+  // store INSTRUCTION writes 16 bytes per lane, so the map is chosen per output type such that
+  // the four lanes fg = 0..3 of a row write 64 CONTIGUOUS bytes (two full 32-byte sectors):
+  //   f32  (PAIR = false): col = 16 j + 4 fg             (one float4 per fragment)
+  //   bf16 (PAIR = true) : col = 32 (j/2) + 8 fg + 4 (j%2) (one 8 x bf16 store per fragment pair)
+  // swz_w(R) must return the low 3 bits of the fragment row of the lane that READS LDS row R.
+  template <bool PAIR> static __device__ __forceinline__ int w_row(int j, int fr) {
+    return PAIR ? (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3) : j * 16 + fr;
+  }
+  template <bool PAIR> static __device__ __forceinline__ int col(int j, int fg) {
+    return PAIR ? (j >> 1) * 32 + fg * 8 + (j & 1) * 4 : j * 16 + fg * 4;
+  }
+  template <bool PAIR> static __device__ __forceinline__ int swz_w(int R) {
+    return PAIR ? (R & 3) | (((R >> 3) & 1) << 2) : (R & 7);
+  }
 };
 
 // Walks the (tile, k-step) sequence of one persistent workgroup for the DMA side, which runs
@@ -132,7 +145,7 @@ template <int WM_, int WN_, int FM_, int FN_, int NS_, bool PREFETCH_ = false> s
 // Holds the per-thread source offsets (in elements, relative to A / W) of the chunks this thread
 // copies in every k-step of the current tile.  Rows past M / N are clamped to the last valid row
 // (their products are never stored).
-template <typename TA, typename TL>
+template <typename TA, typename TL, bool PAIR>
 struct GemmStager {
   static constexpr int EPC = 16 / (int)sizeof(TA);
   long offA[TL::CH_A], offW[TL::CH_W];
@@ -150,7 +163,7 @@ struct GemmStager {
     for (int s = 0; s < TL::CH_W; ++s) {
       const int id = tid + TL::THREADS * s;
       const int row = id >> 3, p = id & 7;
-      offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::swz_w(row)) * EPC;
+      offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
     }
   }
   // LDS stage layout: A rows [0, BM), W rows [BM, BM+BN); chunk id = row*8 + p (lane-linear)
@@ -167,14 +180,15 @@ struct GemmStager {
 };
 
 // Fragment reads of one half k-step (kk = 0 / 1: 16-byte chunks kk*4 .. kk*4+3 of every row).
-template <typename TL>
-__device__ __forceinline__ void gemm_load_frags(const uint4* lds, int a_row, int w_row, int fr, int fg,
+template <typename TL, bool PAIR>
+__device__ __forceinline__ void gemm_load_frags(const uint4* lds, int a_row, int w_base, int fr, int fg,
                                                 int kk, uint4 (&fa)[TL::FM], uint4 (&fw)[TL::FN]) {
   const int c = (kk * 4 + fg) ^ (fr & 7);
 #pragma unroll
   for (int i = 0; i < TL::FM; ++i) fa[i] = lds[(a_row + i * 16) * 8 + c];
 #pragma unroll
-  for (int j = 0; j < TL::FN; ++j) fw[j] = lds[(TL::BM + w_row + j * 4) * 8 + c];
+  for (int j = 0; j < TL::FN; ++j)
+    fw[j] = lds[(TL::BM + w_base + TL::template w_row<PAIR>(j, fr)) * 8 + c];
 }
 template <typename TA, typename TL>
 __device__ __forceinline__ void gemm_mfma_frags(const uint4 (&fa)[TL::FM], const uint4 (&fw)[TL::FN],
@@ -185,12 +199,13 @@ __device__ __forceinline__ void gemm_mfma_frags(const uint4 (&fa)[TL::FM], const
     for (int j = 0; j < TL::FN; ++j) MfmaStep<TA>::run(fw[j], fa[i], acc[i][j]);
 }
 
-// Epilogue of one tile: lane holds C[m = mb + 16 i][n = nb + 4 j + 0..3].
+// Epilogue of one tile: lane holds C[m = mb + 16 i][n = nb + col(j, fg) + 0..3] (GemmTile::col).
 template <typename TO, int EPI, typename TL, bool INTERIOR>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict__ C,
                                               const f32x4 (&acc)[TL::FM][TL::FN],
-                                              const f32x4 (&bias4)[TL::FN], int mb, int nb) {
+                                              const f32x4 (&bias4)[TL::FN], int mb, int nb, int fg) {
   constexpr int FM = TL::FM, FN = TL::FN;
+  constexpr bool PAIR = sizeof(TO) == 2;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = mb + i * 16;
@@ -198,33 +213,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict_
     float4 res4[FN];
     if (EPI == EPI_BIAS_RESID) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        res4[j] = *reinterpret_cast<const float4*>(
-            g.resid + (long)mc * g.ldr + (INTERIOR ? nb + j * 4 : min(nb + j * 4, g.N - 4)));
-    }
-#pragma unroll
-    for (int j = 0; j < FN; j += 2) {
-      float v[8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 b = bias4[j + h];
-        float v0 = acc[i][j + h][0] + b[0], v1 = acc[i][j + h][1] + b[1];
-        float v2 = acc[i][j + h][2] + b[2], v3 = acc[i][j + h][3] + b[3];
-        if (EPI == EPI_BIAS_GELU) {
-          v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
-        }
-        if (EPI == EPI_BIAS_RESID) {
-          v0 += res4[j + h].x; v1 += res4[j + h].y; v2 += res4[j + h].z; v3 += res4[j + h].w;
-        }
-        v[4 * h + 0] = v0; v[4 * h + 1] = v1; v[4 * h + 2] = v2; v[4 * h + 3] = v3;
+      for (int j = 0; j < FN; ++j) {
+        const int n = nb + TL::template col<PAIR>(j, fg);
+        res4[j] = *reinterpret_cast<const float4*>(g.resid + (long)mc * g.ldr + (INTERIOR ? n : min(n, g.N - 4)));
       }
-      const int n = nb + j * 4;
-      TO* dst = C + (long)m * g.ldc + n;
-      if (INTERIOR) {
-        Store8<TO>::run(dst, v);
-      } else if (m < g.M) {
-        if (n + 4 <= g.N) Store4<TO>::run(dst, v[0], v[1], v[2], v[3]);
-        if (n + 8 <= g.N) Store4<TO>::run(dst + 4, v[4], v[5], v[6], v[7]);
+    }
+    float v[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const f32x4 b = bias4[j];
+      float v0 = acc[i][j][0] + b[0], v1 = acc[i][j][1] + b[1];
+      float v2 = acc[i][j][2] + b[2], v3 = acc[i][j][3] + b[3];
+      if (EPI == EPI_BIAS_GELU) {
+        v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+      }
+      if (EPI == EPI_BIAS_RESID) {
+        v0 += res4[j].x; v1 += res4[j].y; v2 += res4[j].z; v3 += res4[j].w;
+      }
+      v[j][0] = v0; v[j][1] = v1; v[j][2] = v2; v[j][3] = v3;
+    }
+    TO* row = C + (long)m * g.ldc;
+    if (PAIR) {
+#pragma unroll
+      for (int j = 0; j < FN; j += 2) {   // fragments j, j+1 are 8 consecutive columns
+        const int n = nb + TL::template col<PAIR>(j, fg);
+        const float w8[8] = {v[j][0], v[j][1], v[j][2], v[j][3], v[j + 1][0], v[j + 1][1], v[j + 1][2], v[j + 1][3]};
+        if (INTERIOR) {
+          Store8<TO>::run(row + n, w8);
+        } else if (m < g.M) {
+          if (n + 4 <= g.N) Store4<TO>::run(row + n, w8[0], w8[1], w8[2], w8[3]);
+          if (n + 8 <= g.N) Store4<TO>::run(row + n + 4, w8[4], w8[5], w8[6], w8[7]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = nb + TL::template col<PAIR>(j, fg);
+        if (INTERIOR || (m < g.M && n + 4 <= g.N)) Store4<TO>::run(row + n, v[j][0], v[j][1], v[j][2], v[j][3]);
       }
     }
   }
@@ -254,7 +279,8 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   const int fr = lane & 15;   // fragment row handled by this lane
   const int fg = lane >> 4;   // k lane-group (operand reads) / column group (results)
   const int a_row = wm * FM * 16 + fr;
-  const int w_row = wn * FN * 16 + (fr >> 2) * (4 * FN) + (fr & 3);
+  constexpr bool PAIR = sizeof(TO) == 2;   // output-column map, see GemmTile
+  const int w_row = wn * FN * 16;          // first W row of this wave
 
   // XCD-aware persistent schedule: XCD x owns logical tiles [start, start + len), N fastest.
   const int tiles_n = (g.N + TL::BN - 1) / TL::BN;
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   const bool has_bias = g.bias != nullptr;
 
   // ---- DMA side: issues k-step copies in (tile, k) order, NS-1 steps ahead of the MFMAs
-  GemmStager<TA, TL> st;
+  GemmStager<TA, TL, PAIR> st;
   st.local = slot; st.kt = 0;
   st.set_tile(g, ((start + slot) / tiles_n) * TL::BM, ((start + slot) % tiles_n) * TL::BN, tid);
   auto issue_next = [&](uint4* dst) -> bool {   // false once every k-step of this workgroup is issued
@@ -299,7 +325,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
     bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (has_bias)
       bias4[j] = *reinterpret_cast<const f32x4*>(
-          g.bias + min(bias_n0 + wn * FN * 16 + fg * (4 * FN) + j * 4, g.N - 4));
+          g.bias + min(bias_n0 + wn * FN * 16 + TL::template col<PAIR>(j, fg), g.N - 4));
   }
 
   // Pipeline depth.  NS >= 3: the fragments of the first half of k-step t+1 are read (into
@@ -321,16 +347,16 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   // S, wait until this wave's copies of stage t+AHEAD have landed, barrier.
   f32x4 acc[FM][FN];
   uint4 fa0[FM], fw0[FN];   // first-half fragments of the current stage (NS >= 3: prefetched)
-  if (PREFETCH) gemm_load_frags<TL>(bufs[0], a_row, w_row, fr, fg, 0, fa0, fw0);
+  if (PREFETCH) gemm_load_frags<TL, PAIR>(bufs[0], a_row, w_row, fr, fg, 0, fa0, fw0);
   auto step = [&](auto tag) {
     constexpr int S = decltype(tag)::value;
     const bool issued = issue_next(bufs[(S + NS - 1) % NS]);
     sched_fence();   // keep the copy's address arithmetic out of the fragment live ranges
     uint4 fa1[FM], fw1[FN];
-    if (!PREFETCH) gemm_load_frags<TL>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
-    gemm_load_frags<TL>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+    if (!PREFETCH) gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
+    gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
     gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
-    if (PREFETCH) gemm_load_frags<TL>(bufs[(S + 1) % NS], a_row, w_row, fr, fg, 0, fa0, fw0);
+    if (PREFETCH) gemm_load_frags<TL, PAIR>(bufs[(S + 1) % NS], a_row, w_row, fr, fg, 0, fa0, fw0);
     gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
     sched_fence();
     // every LDS read above has returned (lgkmcnt) before another wave may refill what it read
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
     const int m0 = ((start + local) / tiles_n) * TL::BM;
     const int n0 = ((start + local) % tiles_n) * TL::BN;
     const int mb = m0 + wm * FM * 16 + fr;
-    const int nb = n0 + wn * FN * 16 + fg * (4 * FN);
+    const int nb = n0 + wn * FN * 16;   // first column of this wave
     int kt = 0;
     while (kt < nk) {
       switch (phase) {
@@ -387,15 +413,16 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
       bias_n0 = n0;
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        if (has_bias) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + min(nb + j * 4, g.N - 4));
+        if (has_bias)
+          bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + min(nb + TL::template col<PAIR>(j, fg), g.N - 4));
 #pragma unroll
       for (int j = 0; j < FN; ++j) consume(bias4[j]);
     }
     // interior tiles with 16-byte aligned rows take a branch-free path (no per-lane predicates:
     // the compiler otherwise sinks the GELU arithmetic into a maze of masked store blocks)
     const bool interior = wide && m0 + TL::BM <= g.M && n0 + TL::BN <= g.N;
-    if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb);
-    else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb);
+    if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb, fg);
+    else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb, fg);
   }
 }
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""HBM traffic per launch of the dominant kernels from two rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE need 3 + 2 of the 4 TCC slots: separate runs), corrected as
+/opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes: both counters are in KiB; on gfx950
+FETCH_SIZE reports half the bytes of wide (16 B / lane) coalesced streaming reads, so it is
+doubled; WRITE_SIZE is taken as reported (uncalibrated in the guide).
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = {
+    'gemm_up': ('gemm_nt_kernel<unsigned short, unsigned short, 1', 'GemmTile<2, 2, 4, 4, 2'),
+    'gemm_down': ('gemm_nt_kernel<unsigned short, float, 2', 'GemmTile<2, 2, 6, 2, 2'),
+    'mix': ('mix_stream_kernel<unsigned short', ''),
+}
+
+
+def per_kernel(d, counter):
+  f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))[0]
+  acc = collections.defaultdict(list)
+  for r in csv.DictReader(open(f)):
+    if r['Counter_Name'] != counter:
+      continue
+    for key, (a, b) in KERNELS.items():
+      if a in r['Kernel_Name'] and b in r['Kernel_Name']:
+        acc[key].append(float(r['Counter_Value']))
+  return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+  fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
+  write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
+  out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on tools/kbench.py (config-2 shapes), '
+                   'FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes',
+         'kernels': {}}
+  for k in KERNELS:
+    if k not in fetch:
+      continue
+    fb = fetch[k] * 1024 * 2
+    wb = write.get(k, 0.0) * 1024
+    out['kernels'][k] = dict(fetch_bytes=round(fb), write_bytes=round(wb), hbm_bytes=round(fb + wb),
+                             fetch_kib_raw=round(fetch[k], 1), write_kib_raw=round(write.get(k, 0.0), 1),
+                             launches=nf[k])
+  if 'gemm_up' in out['kernels']:
+    out['gemm_up_hbm_bytes_per_launch'] = out['kernels']['gemm_up']['hbm_bytes']
+  json.dump(out, sys.stdout, indent=1)
+  print()
+
+
+if __name__ == '__main__':
+  main()
