@@ -31,6 +31,7 @@ struct CvHeadWeights {
   const float* b4;   // [16]
   const float* w5;   // [2][16]
   const float* b5;   // [2]
+  const uint4* w3b;  // bf16 build: conv-3 weights as MFMA B fragments [5 k-steps][2 n-tiles][64 lanes] x 8 bf16
 };
 
 struct CvHeadArgs {
@@ -41,6 +42,7 @@ struct CvHeadArgs {
   float* occ;             // [maps]
   float* expd;            // [maps]
   int T, h, w;
+  long maps;              // number of maps (cv_heads_mfma_kernel walks them persistently)
   float temperature;
   float img_h, img_w;     // initial_resolution
 };
@@ -231,6 +233,279 @@ __global__ __launch_bounds__(CV_THREADS) void cv_heads_kernel(CvHeadArgs a) {
     a.points[map * 2 + 0] = outx;
     a.points[map * 2 + 1] = outy;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv_heads_mfma_kernel: the same heads for the bf16 build, with the occlusion convolution
+// (16 -> 32 channels, 3x3, stride 2: 80 % of the arithmetic of the VALU kernel above, and one LDS
+// read per 32 FMAs) on the matrix cores as an implicit GEMM:
+//   M = oh*ow output pixels, N = 32 channels, K = 9 taps x 16 channels (padded to 160 = 5 x 32)
+//   A fragment (lane: pixel i = l & 15, k-group g = l >> 4) = 8 consecutive channels of ONE tap of
+//   one input pixel -> hid1 is kept in LDS pixel-major ([padded pixel][16] f32, 64 B per pixel): two
+//   ds_read_b128 + 4 v_cvt_pk_bf16_f32 per fragment; B fragments (weights) live in registers.
+// Everything that feeds the soft-argmax (conv 1->16, conv 16->1, softmax) stays f32 VALU: only
+// the occlusion / expected-distance logits see bf16 rounding.  The pixel-major layout also cuts the
+// LDS reads of the 16 -> 1 convolution from 144 x b32 to 36 x b128 per cell.
+template <int CV_MAX_PAD, int CV_PPT>
+__global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
+  __shared__ float s_cm[CV_MAX_PAD];             // cost map with zero halo
+  // relu(hid1) with zero halo, [pixel][4 channel quads]; quad c4 of pixel p sits at slot
+  // c4 ^ ((p >> 2) & 3): 16 consecutive pixels then cover all 64 banks for one quad index
+  // (64-byte pixel stride would otherwise be a 4-way conflict on every ds_read_b128)
+  __shared__ float4 s_h1[CV_MAX_PAD][4];
+  __shared__ float s_red[8][4];
+  __shared__ int s_redi[4];
+  __shared__ float s_vec[32 + 16];
+  __shared__ float s_occ[4][32];
+  // conv-1 / conv-2 weights as LDS broadcasts (as wave-uniform scalars they need 300 SGPRs and
+  // were spilled): s_w1[c] = {w1[c][0..8], b1[c], -, -}, s_w2[tap] = w2[0..15][tap]
+  __shared__ float4 s_w1[16][3];
+  __shared__ float4 s_w2[9][4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = a.h, w = a.w, hw = h * w;
+  const int pw = w + 2, ph = h + 2, pn = pw * ph;
+  constexpr int CM_PT = (CV_MAX_PAD + CV_THREADS - 1) / CV_THREADS;   // padded cells per thread
+
+  // B fragments of the occlusion convolution (10 KiB, L2-resident), in flight during phase A/B
+  uint4 wb[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wb[s][t] = a.wt.w3b[(s * 2 + t) * 64 + lane];
+
+  if (tid < 16) {
+    const float* wp = a.wt.w1 + tid * 9;
+    s_w1[tid][0] = make_float4(wp[0], wp[1], wp[2], wp[3]);
+    s_w1[tid][1] = make_float4(wp[4], wp[5], wp[6], wp[7]);
+    s_w1[tid][2] = make_float4(wp[8], a.wt.b1[tid], 0.f, 0.f);
+  } else if (tid >= 64 && tid < 64 + 36) {
+    const int tap = (tid - 64) >> 2, c4 = (tid - 64) & 3;
+    s_w2[tap][c4] = make_float4(a.wt.w2[(4 * c4 + 0) * 9 + tap], a.wt.w2[(4 * c4 + 1) * 9 + tap],
+                                a.wt.w2[(4 * c4 + 2) * 9 + tap], a.wt.w2[(4 * c4 + 3) * 9 + tap]);
+  }
+  // Persistent walk over the maps: the weights above are fetched once per workgroup, and the
+  // cost values of the NEXT map are requested (into registers) before the current one is
+  // processed, so their HBM latency hides under ~10 us of arithmetic.
+  float cmv[CM_PT];
+  auto fetch = [&](long m) {
+    const float* cvp = a.cv + m * hw;
+#pragma unroll
+    for (int s = 0; s < CM_PT; ++s) {
+      const int i = tid + s * CV_THREADS;
+      const int y = i / pw - 1, x = i % pw - 1;
+      const bool in = (i < pn) && (y >= 0) && (y < h) && (x >= 0) && (x < w);
+      cmv[s] = in ? cvp[y * w + x] : 0.f;
+    }
+  };
+  fetch(blockIdx.x);
+  // zero halos of hid1 (never written afterwards)
+  for (int i = tid; i < pn; i += CV_THREADS) {
+    const int y = i / pw - 1, x = i % pw - 1;
+    if (!((y >= 0) && (y < h) && (x >= 0) && (x < w))) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_h1[i][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (long map = blockIdx.x; map < a.maps; map += gridDim.x) {
+  __syncthreads();   // the previous map's readers of s_cm / s_h1 / s_vec are done
+#pragma unroll
+  for (int s = 0; s < CM_PT; ++s) {
+    const int i = tid + s * CV_THREADS;
+    if (i < pn) s_cm[i] = cmv[s];
+  }
+  if (map + gridDim.x < a.maps) fetch(map + gridDim.x);
+  __syncthreads();
+
+  // ---- hid1 = relu(conv3x3(cost) + b), pixel-major
+  for (int p = tid; p < hw; p += CV_THREADS) {
+    // (memory clobber: re-read the weight broadcasts per cell instead of pinning 200 VGPRs)
+#ifndef TAPIR_HIPEMU
+    asm volatile("" ::: "memory");
+#endif
+    const int y = p / w, x = p % w;
+    float v[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_cm[(y + dy) * pw + (x + dx)];
+    float o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 wa = s_w1[c][0], wb4 = s_w1[c][1], wc = s_w1[c][2];
+      float acc = wc.y;
+      acc = fmaf(wa.x, v[0], acc); acc = fmaf(wa.y, v[1], acc); acc = fmaf(wa.z, v[2], acc);
+      acc = fmaf(wa.w, v[3], acc); acc = fmaf(wb4.x, v[4], acc); acc = fmaf(wb4.y, v[5], acc);
+      acc = fmaf(wb4.z, v[6], acc); acc = fmaf(wb4.w, v[7], acc); acc = fmaf(wc.x, v[8], acc);
+      o[c] = fmaxf(acc, 0.f);
+    }
+    const int pp = (y + 1) * pw + (x + 1);
+    float4* dst = s_h1[pp];
+    const int sw = (pp >> 2) & 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c ^ sw] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+  }
+  __syncthreads();
+
+  // ---- logits = conv3x3(hid1) + b, scaled by the temperature (f32 VALU)
+  float z[CV_PPT];
+  float zmax = -3.0e38f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    z[s] = -3.0e38f;
+#ifndef TAPIR_HIPEMU
+    asm volatile("" ::: "memory");   // as above, for the conv-2 weights
+#endif
+    if (p < hw) {
+      const int y = p / w, x = p % w;
+      float acc = a.wt.b2[0];
+#pragma unroll 3
+      for (int k = 0; k < 9; ++k) {
+        const int pp = (y + k / 3) * pw + (x + k % 3);
+        const float4* hp = s_h1[pp];
+        const int sw = (pp >> 2) & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 hv = hp[c ^ sw], wv = s_w2[k][c];
+          acc = fmaf(wv.x, hv.x, acc);
+          acc = fmaf(wv.y, hv.y, acc);
+          acc = fmaf(wv.z, hv.z, acc);
+          acc = fmaf(wv.w, hv.w, acc);
+        }
+      }
+      z[s] = acc * a.temperature;
+      zmax = fmaxf(zmax, z[s]);
+    }
+  }
+  zmax = wave_max(zmax);
+  if (lane == 0) s_red[0][wave] = zmax;
+  __syncthreads();
+  zmax = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+  float esum = 0.f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    z[s] = (p < hw) ? fast_exp(z[s] - zmax) : 0.f;
+    esum += z[s];
+  }
+  esum = wave_sum(esum);
+  if (lane == 0) s_red[1][wave] = esum;
+  __syncthreads();
+  esum = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  // softmax values; argmax = FIRST maximum (jnp.argmax), model_utils.py:232
+  float best = -1.f;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    if (p < hw) {
+      z[s] = z[s] / esum;
+      if (z[s] > best) { best = z[s]; besti = p; }   // p increases with s: keeps the first
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(besti, off);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) { s_red[2][wave] = best; s_redi[wave] = besti; }
+  __syncthreads();
+  best = s_red[2][0]; besti = s_redi[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float ob = s_red[2][k]; const int oi = s_redi[k];
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
+  float sx = 0.f, sy = 0.f, sw = 0.f;
+#pragma unroll
+  for (int s = 0; s < CV_PPT; ++s) {
+    const int p = tid + s * CV_THREADS;
+    if (p < hw) {
+      const float cx = (float)(p % w) + 0.5f, cy = (float)(p / w) + 0.5f;
+      const float d2 = (cx - ax) * (cx - ax) + (cy - ay) * (cy - ay);
+      if (d2 < 25.0f) { sx += cx * z[s]; sy += cy * z[s]; sw += z[s]; }   // threshold 5, strict
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+  if (lane == 0) { s_red[3][wave] = sx; s_red[4][wave] = sy; s_red[5][wave] = sw; }
+
+  // ---- occlusion head: conv 16->32, 3x3, stride 2, XLA SAME (pad_lo = total/2), on the MFMAs
+  const int oh = (h + 1) / 2, ow = (w + 1) / 2, opix = oh * ow;
+  const int ply = max((oh - 1) * 2 + 3 - h, 0) / 2, plx = max((ow - 1) * 2 + 3 - w, 0) / 2;
+  const int fi = lane & 15, fgp = lane >> 4;
+  float osum[2] = {0.f, 0.f};   // sum over this lane's pixels of relu(conv + b), channels n and 16 + n
+  const float b3a = a.wt.b3[fi], b3b = a.wt.b3[16 + fi];
+  for (int mt = wave; mt * 16 < opix; mt += CV_THREADS / 64) {
+    const int P = min(mt * 16 + fi, opix - 1);          // this lane's A row (clamped: masked below)
+    const int oy = P / ow, ox = P - oy * ow;
+    const int base = (2 * oy - ply + 1) * pw + (2 * ox - plx + 1);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = min(2 * s + (fgp >> 1), 8);        // tap 9 has zero weights
+      const int pp = base + (tap / 3) * pw + (tap % 3);
+      const float4* hp = s_h1[pp];
+      const int sw = (pp >> 2) & 3;
+      const float4 u0 = hp[(2 * (fgp & 1)) ^ sw], u1 = hp[(2 * (fgp & 1) + 1) ^ sw];
+      uint4 af;
+      af.x = pack_bf16x2(u0.x, u0.y); af.y = pack_bf16x2(u0.z, u0.w);
+      af.z = pack_bf16x2(u1.x, u1.y); af.w = pack_bf16x2(u1.z, u1.w);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                     __builtin_bit_cast(bf16x8, wb[s][0]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                     __builtin_bit_cast(bf16x8, wb[s][1]), acc1, 0, 0, 0);
+    }
+    // D: lane holds channel n = fi, pixels mt*16 + 4*fgp + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (mt * 16 + 4 * fgp + r < opix) {
+        osum[0] += fmaxf(acc0[r] + b3a, 0.f);
+        osum[1] += fmaxf(acc1[r] + b3b, 0.f);
+      }
+    }
+  }
+  // reduce over the four pixel groups of the wave, then over the waves
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    osum[t] += __shfl_xor(osum[t], 16);
+    osum[t] += __shfl_xor(osum[t], 32);
+  }
+  if (lane < 16) { s_occ[wave][lane] = osum[0]; s_occ[wave][16 + lane] = osum[1]; }
+  __syncthreads();
+  if (tid < 32)
+    s_vec[tid] = (s_occ[0][tid] + s_occ[1][tid] + s_occ[2][tid] + s_occ[3][tid]) / (float)opix;
+  __syncthreads();
+  if (tid < 16) {
+    float acc = a.wt.b4[tid];
+    for (int k = 0; k < 32; ++k) acc = fmaf(a.wt.w4[tid * 32 + k], s_vec[k], acc);
+    s_vec[32 + tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < 2) {
+    float acc = a.wt.b5[tid];
+    for (int k = 0; k < 16; ++k) acc = fmaf(a.wt.w5[tid * 16 + k], s_vec[32 + k], acc);
+    if (tid == 0) a.occ[map] = acc; else a.expd[map] = acc;
+  }
+  if (tid == 0) {
+    const float fsx = s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3];
+    const float fsy = s_red[4][0] + s_red[4][1] + s_red[4][2] + s_red[4][3];
+    const float fsw = fmaxf(s_red[5][0] + s_red[5][1] + s_red[5][2] + s_red[5][3], 1e-12f);
+    float outx = (fsx / fsw) * a.img_w / (float)w;
+    float outy = (fsy / fsw) * a.img_h / (float)h;
+    if (a.qpts != nullptr) {
+      const long bq = map / a.T;
+      const int t = (int)(map % a.T);
+      const float* q = a.qpts + bq * 3;
+      if ((int)rintf(q[0]) == t) { outx = q[2]; outy = q[1]; }   // round-half-even like jnp.round
+    }
+    a.points[map * 2 + 0] = outx;
+    a.points[map * 2 + 1] = outy;
+  }
+  }   // maps
 }
 
 }  // namespace tapir

@@ -220,12 +220,16 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
   CvHeadArgs a{};
   a.cv = cv; a.wt = c->cvw; a.qpts = qpts_init;
   a.points = points; a.occ = occ; a.expd = expd;
-  a.T = T; a.h = h; a.w = w;
+  a.T = T; a.h = h; a.w = w; a.maps = maps;
   a.temperature = c->cfg.softmax_temperature;
   a.img_h = (float)c->cfg.initial_h; a.img_w = (float)c->cfg.initial_w;
   const int pn = (h + 2) * (w + 2), hw = h * w;
   ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
-  if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
+  if (c->cfg.dtype == TAPIR_BF16 && pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
+    // bf16 build: occlusion convolution on the matrix cores
+    hipLaunchKernelGGL((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)std::min<long>(maps, 512)),
+                       dim3(CV_THREADS), 0, s, a);
+  } else if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
     hipLaunchKernelGGL((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps),
                        dim3(CV_THREADS), 0, s, a);
   } else if (pn <= CV_LARGE_PAD && hw <= CV_LARGE_PPT * CV_THREADS) {
@@ -641,6 +645,21 @@ int tapir_finalize_weights(tapir_ctx* c) {
       for (int ci = 0; ci < 16; ++ci)
         for (int k = 0; k < 9; ++k) r[(ci * 9 + k) * 32 + co] = t->data[(co * 16 + ci) * 9 + k];
     TRY(upload_f32(c, r.data(), r.size(), &tmp)); c->cvw.w3 = tmp;
+    // bf16 build: the same weights as MFMA 16x16x32 B fragments, k = tap*16 + ci padded to 160:
+    // fragment (k-step s, n-tile nt), lane l: column n = l & 15, k = 32 s + 8 (l >> 4) + j
+    std::vector<uint16_t> fb((size_t)5 * 2 * 64 * 8, 0);
+    for (int s5 = 0; s5 < 5; ++s5)
+      for (int nt = 0; nt < 2; ++nt)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s5 + 8 * (l >> 4) + j, tap = k / 16, ci = k % 16, co = nt * 16 + (l & 15);
+            if (tap < 9) fb[(((size_t)s5 * 2 + nt) * 64 + l) * 8 + j] = host_f2bf(t->data[(co * 16 + ci) * 9 + tap]);
+          }
+    void* dfb = nullptr;
+    HIP_TRY(c, hipMalloc(&dfb, fb.size() * 2));
+    c->owned.push_back(dfb);
+    HIP_TRY(c, hipMemcpy(dfb, fb.data(), fb.size() * 2, hipMemcpyHostToDevice));
+    c->cvw.w3b = (const uint4*)dfb;
   }
   TRY(get_w(c, cv + "hid3.bias", {32}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); c->cvw.b3 = tmp;
   TRY(get_w(c, cv + "hid4.weight", {16, 32}, &t)); TRY(upload_f32(c, t->data.data(), 512, &tmp)); c->cvw.w4 = tmp;

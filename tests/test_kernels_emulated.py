@@ -221,3 +221,25 @@ def test_mix_stream_kernel(tc):
   np.testing.assert_allclose(xo, ref_x, atol=2e-5)
   np.testing.assert_allclose(xn.reshape(N, T, 512), ref_xn, atol=2e-5)
   e.close()
+
+
+def test_cost_volume_stage_bf16_mfma():
+  """bf16 build: cost-volume heads with the occlusion convolution on the MFMAs
+  (cv_heads_mfma_kernel) against the oracle on bf16-rounded operands; odd grid = ragged MFMA
+  tiles and the pad_lo = 1 case of the stride-2 XLA SAME padding."""
+  for (h, wd, seed) in ((8, 8, 11), (9, 5, 12)):
+    w = synthetic.make_weights(9, 1, False, num_mixer_blocks=1, backbone=False)
+    e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(8 * h, 8 * wd), dtype=_ffi.TAPIR_BF16)
+    rng = np.random.default_rng(seed)
+    grid = O.l2_normalize(rng.standard_normal((1, 4, h, wd, 256)).astype(np.float32))
+    qf = O.l2_normalize(rng.standard_normal((1, 5, 256)).astype(np.float32))
+    qp = np.stack([rng.integers(0, 4, (1, 5)), rng.uniform(0, 8 * h, (1, 5)),
+                   rng.uniform(0, 8 * wd, (1, 5))], -1).astype(np.float32)
+    pts, occ, expd = e.tracks_from_cost_volume(qf, grid, qp)
+    rp, ro, re, st = O.tracks_from_cost_volume(w, bf16_round(qf), bf16_round(grid), qp,
+                                               (8 * h, 8 * wd), 20.0, return_stages=True)
+    np.testing.assert_allclose(occ, ro, atol=3e-2)     # hid1 / conv-3 weights rounded to bf16
+    np.testing.assert_allclose(expd, re, atol=3e-2)
+    ok = st['top2_rel_gap'] > 1e-3
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=2e-3)   # the soft-argmax path stays f32
+    e.close()
