@@ -143,7 +143,7 @@ class Backbone:
     """InstanceNorm summaries of a (NHWC), or of a + b with the sum written over a."""
     lib, ctx = self.engine
     n, h, w, c = a.shape
-    slabs = max(1, min(h * w // 64, -(-1024 // n)))
+    slabs = max(1, min(h * w // 64, -(-1024 // n), 64))   # the finalize kernel walks them serially
     part = self._buf(('part', n, slabs, c), (n, slabs, c, 2), torch.float32)
     self._check(lib.tapir_inorm_stats(ctx, a.data_ptr(), b.data_ptr() if b is not None else None,
                                       a.data_ptr() if b is not None else None, part.data_ptr(),

@@ -243,3 +243,45 @@ def test_bf16_close_to_f32(config2):
   assert np.median(d) < 0.1, np.median(d)
   assert np.mean(d < 1.0) > 0.97
   assert np.median(np.abs(a['occlusion'] - b['occlusion'])) < 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_online_tracker_matches_streaming_api(use_graph):
+  """tapnet_amd.online.OnlineTracker (hipGraph-replayed per-frame step, packed ping-pong state)
+  against the reference-style loop through the public API (live_demo.py:51-77): same kernels
+  (the MIOpen convolutions of the backbone accumulate with atomics, hence 1e-4 and not bitwise);
+  also point replacement (update_query_features)."""
+  from tapnet_amd import online, tapir_model
+  w = synthetic.make_weights(13, pyramid_level=1, extra_convs=False)
+  m = tapir_model.TAPIR(pyramid_level=1, use_causal_conv=True, weights=w, device='cuda:0')
+  T, S, Q = 6, 64, 24
+  m2 = tapir_model.TAPIR(pyramid_level=1, use_causal_conv=True, weights=w, device='cuda:0',
+                         initial_resolution=(S, S))
+  video = torch.as_tensor(synthetic.make_video(5, T, S, S)).cuda()
+  qp = torch.as_tensor(synthetic.make_queries(6, Q, 1, S, S)).cuda()
+  del m
+  # reference-style loop
+  fg0 = m2.get_feature_grids(video[:, :1])
+  qf = m2.get_query_features(video[:, :1], False, qp, fg0)
+  state = m2.construct_initial_causal_state(Q, len(qf.resolutions) - 1)
+  ref = []
+  for t in range(T):
+    fg = m2.get_feature_grids(video[:, t:t + 1])
+    traj = m2.estimate_trajectories((S, S), False, fg, qf, None, causal_context=state,
+                                    get_causal_context=True)
+    state = traj['causal_context']
+    ref.append({k: traj[k][-1].clone() for k in ('tracks', 'occlusion', 'expected_dist')})
+  # session
+  trk = online.OnlineTracker(m2, Q, (S, S), use_graph=use_graph)
+  trk.init(video[:, :1], qp)
+  for t in range(T):
+    out = trk.step(video[:, t:t + 1])
+    for k in ref[t]:
+      torch.testing.assert_close(out[k], ref[t][k], atol=1e-3, rtol=0, msg=f'frame {t} {k}')
+  # replacing two points resets their state and features only
+  new_qp = torch.as_tensor(synthetic.make_queries(7, 2, 1, S, S)).cuda()
+  before = {k: v.clone() for k, v in trk.step(video[:, 2:3]).items()}
+  trk.update_points([3, 7], video[:, 2:3], new_qp)
+  after = trk.step(video[:, 3:4])
+  assert torch.isfinite(after['tracks']).all() and before['tracks'].shape == after['tracks'].shape

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Per-frame latency of the online (causal) tracker, BASELINE.json configs[3]: 256x256 frames,
+256 query points, 4 refinement iterations per frame; eager launches vs the hipGraph replay.
+
+    python tools/bench_online.py [--queries 256] [--frames 60] [--dtype bf16]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from tapnet_amd import online, synthetic, tapir_model
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--queries', type=int, default=256)
+  ap.add_argument('--frames', type=int, default=60)
+  ap.add_argument('--size', type=int, default=256)
+  ap.add_argument('--dtype', default='bf16')
+  args = ap.parse_args()
+  dtype = 'bfloat16' if args.dtype == 'bf16' else 'float32'
+  w = synthetic.make_weights(0, pyramid_level=1, extra_convs=True)   # the causal checkpoint's kwargs
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, use_causal_conv=True, weights=w,
+                        dtype=dtype, device='cuda:0')
+  S, Q = args.size, args.queries
+  video = torch.as_tensor(synthetic.make_video(1, 8, S, S)).cuda()
+  qp = torch.as_tensor(synthetic.make_queries(2, Q, 1, S, S)).cuda()
+  rows = []
+  for use_graph in (False, True):
+    trk = online.OnlineTracker(m, Q, (S, S), use_graph=use_graph)
+    trk.init(video[:, :1], qp)
+    for t in range(5):
+      trk.step(video[:, t % 8:t % 8 + 1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.frames):
+      out = trk.step(video[:, t % 8:t % 8 + 1])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.frames * 1e3
+    assert torch.isfinite(out['tracks']).all()
+    rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', ms_per_frame=round(ms, 3),
+                     frames_per_s=round(1e3 / ms, 1), points_frames_per_s=round(Q * 1e3 / ms, 1)))
+    print(json.dumps(dict(workload=f'online TAPIR {S}x{S}, Q={Q}, 4 iters/frame, {dtype}', **rows[-1])), flush=True)
+
+
+if __name__ == '__main__':
+  main()
