@@ -426,20 +426,185 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant: PW producer waves issue every LDS-DMA copy, the WM x WN consumer
+// waves only read fragments and issue MFMAs.  tools/mfma_probe.hip puts the price of the copies
+// at 20 % of the k-loop although the DMA itself runs at L2 speed: a global_load_lds costs the
+// issuing wave 60-180 cycles, during which it feeds no MFMA.  With the roles split, the consumer
+// stream holds no vector-memory instruction at all (so the stores of its epilogue cannot perturb
+// any vmcnt accounting either), and the producers run up to NS-1 stages ahead, through tile
+// boundaries and under the consumers' epilogue.  Every wave executes one s_barrier per k-step:
+//   producer, step t: copies of stage t+NS-1 (into the buffer read in step t-1), then wait until its
+//                     copies of stage t+1 have landed (vmcnt), barrier
+//   consumer, step t: fragments + MFMAs of stage t, LDS reads returned (lgkmcnt), barrier
+template <typename TA, typename TO, int EPI, typename TL, int PW>
+__global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs g) {
+  constexpr int EPC = 16 / (int)sizeof(TA);
+  constexpr int BK = 8 * EPC;
+  constexpr int NS = TL::NS, FM = TL::FM, FN = TL::FN;
+  constexpr int PT = PW * 64;                       // producer threads
+  constexpr int CH_A = TL::BM * 8 / PT, CH_W = TL::BN * 8 / PT;
+  static_assert(TL::BM * 8 % PT == 0 && TL::BN * 8 % PT == 0 && NS >= 3, "producer split");
+  constexpr bool PAIR = sizeof(TO) == 2;
+  __shared__ uint4 lds0[TL::STAGE_CHUNKS];
+  __shared__ uint4 lds1[TL::STAGE_CHUNKS];
+  __shared__ uint4 lds2[TL::STAGE_CHUNKS];
+  __shared__ uint4 lds3[NS > 3 ? TL::STAGE_CHUNKS : 1];
+  uint4* const bufs[4] = {lds0, lds1, lds2, lds3};
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave_u >= TL::WM * TL::WN;
+
+  const int tiles_n = (g.N + TL::BN - 1) / TL::BN;
+  const int ntiles = tiles_n * ((g.M + TL::BM - 1) / TL::BM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_xcd = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int len = q + (xcd < r ? 1 : 0);
+  if (slot >= len) return;
+  const int nk = g.K / BK;
+
+  if (producer) {
+    // ------------------------------------------------------------------ producer waves
+    const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+    const TA* __restrict__ W = reinterpret_cast<const TA*>(g.W);
+    const int pt = tid - TL::THREADS;                 // 0 .. PT-1
+    const int pw = wave_u - TL::WM * TL::WN;          // producer wave index
+    long offA[CH_A], offW[CH_W];
+    auto set_tile = [&](int local) {
+      const int m0 = ((start + local) / tiles_n) * TL::BM, n0 = ((start + local) % tiles_n) * TL::BN;
+      const int t = opaque(pt);
+#pragma unroll
+      for (int s = 0; s < CH_A; ++s) {
+        const int id = t + PT * s;
+        const int row = id >> 3, p = id & 7;
+        offA[s] = (long)min(m0 + row, g.M - 1) * g.lda + (p ^ (row & 7)) * EPC;
+      }
+#pragma unroll
+      for (int s = 0; s < CH_W; ++s) {
+        const int id = t + PT * s;
+        const int row = id >> 3, p = id & 7;
+        offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
+      }
+    };
+    int i_local = slot, i_kt = 0;
+    set_tile(i_local);
+    auto issue_next = [&](uint4* dst) -> bool {
+      if (i_local >= len) return false;
+      const int k0 = i_kt * BK;
+#pragma unroll
+      for (int s = 0; s < CH_A; ++s) glds16(A + offA[s] + k0, dst + pw * 64 + PT * s);
+#pragma unroll
+      for (int s = 0; s < CH_W; ++s) glds16(W + offW[s] + k0, dst + TL::BM * 8 + pw * 64 + PT * s);
+      if (++i_kt == nk) {
+        i_kt = 0;
+        i_local += per_xcd;
+        if (i_local < len) set_tile(i_local);
+      }
+      return true;
+    };
+    constexpr int INFLIGHT = (NS - 2) * (CH_A + CH_W);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_next(bufs[s]);
+    if (i_local < len) dma_wait<INFLIGHT>(); else dma_wait<0>();
+    block_barrier();
+    auto pstep = [&](auto tag) {
+      constexpr int S = decltype(tag)::value;
+      const bool issued = issue_next(bufs[(S + NS - 1) % NS]);
+      if (issued) dma_wait<INFLIGHT>(); else dma_wait<0>();
+      block_barrier();
+    };
+    long steps = 0;   // k-steps of this workgroup
+    for (int local = slot; local < len; local += per_xcd) steps += nk;
+    int phase = 0;
+    for (long t = 0; t < steps; ++t) {
+      switch (phase) {
+        case 0: pstep(StageTag<0>{}); break;
+        case 1: pstep(StageTag<1>{}); break;
+        case 2: pstep(StageTag<2>{}); break;
+        default: if constexpr (NS > 3) pstep(StageTag<3>{}); break;
+      }
+      phase = phase + 1 == NS ? 0 : phase + 1;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer waves
+  TO* __restrict__ C = reinterpret_cast<TO*>(g.C);
+  const int wm = wave_u / TL::WN, wn = wave_u % TL::WN;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_row = wm * FM * 16 + fr;
+  const int w_row = wn * FN * 16;
+  const bool wide = (g.ldc * (long)sizeof(TO)) % 16 == 0;
+  const bool has_bias = g.bias != nullptr;
+  f32x4 acc[FM][FN];
+  block_barrier();   // stage 0 has landed (pairs with the producers' first barrier)
+  auto cstep = [&](auto tag) {
+    constexpr int S = decltype(tag)::value;
+    uint4 fa0[FM], fw0[FN], fa1[FM], fw1[FN];
+    gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
+    gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+    gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
+    gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
+    lds_barrier();   // reads returned before a producer may refill this stage
+  };
+  int phase = 0;
+  for (int local = slot; local < len; local += per_xcd) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      switch (phase) {
+        case 0: cstep(StageTag<0>{}); break;
+        case 1: cstep(StageTag<1>{}); break;
+        case 2: cstep(StageTag<2>{}); break;
+        default: if constexpr (NS > 3) cstep(StageTag<3>{}); break;
+      }
+      phase = phase + 1 == NS ? 0 : phase + 1;
+    }
+    const int m0 = ((start + local) / tiles_n) * TL::BM;
+    const int n0 = ((start + local) % tiles_n) * TL::BN;
+    const int mb = m0 + wm * FM * 16 + fr;
+    const int nb = n0 + wn * FN * 16;
+    f32x4 bias4[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_bias)
+        bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + min(nb + TL::template col<PAIR>(j, fg), g.N - 4));
+    }
+    const bool interior = wide && m0 + TL::BM <= g.M && n0 + TL::BN <= g.N;
+    if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb, fg);
+    else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb, fg);
+  }
+}
+
 // Tile shapes.  Slots = workgroups per CU (LDS-limited) x 256 CUs.
 enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3,
-       GEMM_TILE_192x128_S3 = 4, GEMM_TILE_COUNT = 5 };
+       GEMM_TILE_192x128_S3 = 4, GEMM_TILE_192x128_WS = 5, GEMM_TILE_192x256 = 6, GEMM_TILE_256x128 = 7,
+       GEMM_TILE_128x128_W8 = 8, GEMM_TILE_COUNT = 9 };
 typedef GemmTile<4, 2, 3, 4, 4> GemmTileBig;     // 192x128, 8 waves, 4 stages = 160 KiB: 1 per CU
 typedef GemmTile<4, 2, 3, 4, 3> GemmTileBig3;    // same, 3 stages = 120 KiB
 typedef GemmTile<2, 2, 4, 4, 2> GemmTileSquare;  // 128x128, 4 waves, 64 KiB: 2 per CU
 typedef GemmTile<2, 2, 6, 2, 2> GemmTileTall;    // 192x64, 4 waves, 64 KiB: 2 per CU
+typedef GemmTile<2, 4, 6, 4, 2> GemmTileWide;    // 192x256, 8 waves, 2 stages = 112 KiB: least LDS fill per flop
+typedef GemmTile<4, 2, 4, 4, 3> GemmTileLong;    // 256x128, 8 waves, 3 stages = 144 KiB
+typedef GemmTile<2, 4, 4, 2, 2> GemmTileSquare8; // 128x128, 8 waves (64x32 each), 64 KiB: 2 per CU = 16 waves
 
-// Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/): wide outputs
-// (N = 2048, GELU epilogue) run best on 128x128 at two workgroups per CU; narrow outputs
-// (N <= 1024, long K) on 192x64, which gives 512 tiles = one per LDS slot.
+// Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/r01_kbench_gemm.log):
+// narrow outputs with a long K (N <= 1024) run best on 192x64 (512 tiles = one per LDS slot),
+// wide GELU outputs on 128x128 with EIGHT waves (64x32 per wave, two workgroups = 16 waves per
+// CU): every configuration with 8 waves per CU lands within 5 % of the others whatever its tile,
+// stage count or DMA / MFMA role split (192x128 4-stage, wave-specialised, 192x256 with half the
+// LDS fill, ...) -- the k-loop is latency-bound per workgroup, and more resident waves is what
+// moves it.
 inline int gemm_pick_tile(int M, int N) {
   if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
-  return GEMM_TILE_128x128;
+  return GEMM_TILE_128x128_W8;
 }
 
 template <typename TA, typename TO, int EPI, typename TL>
@@ -459,6 +624,17 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
     case GEMM_TILE_192x128: launch_gemm_tile<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_S3: launch_gemm_tile<TA, TO, EPI, GemmTileBig3>(g, stream, max_grid); break;
     case GEMM_TILE_192x64: launch_gemm_tile<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
+    case GEMM_TILE_192x256: launch_gemm_tile<TA, TO, EPI, GemmTileWide>(g, stream, max_grid); break;
+    case GEMM_TILE_256x128: launch_gemm_tile<TA, TO, EPI, GemmTileLong>(g, stream, max_grid); break;
+    case GEMM_TILE_128x128_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
+    case GEMM_TILE_192x128_WS: {   // 8 consumer + 4 producer waves, 4 stages, one workgroup per CU
+      using TL = GemmTileBig;
+      const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
+      int grid = std::min((ntiles + 7) / 8 * 8, 256);
+      if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
+      hipLaunchKernelGGL((gemm_ws_kernel<TA, TO, EPI, TL, 4>), dim3(grid), dim3(TL::THREADS + 256), 0, stream, g);
+      break;
+    }
     default: launch_gemm_tile<TA, TO, EPI, GemmTileSquare>(g, stream, max_grid); break;
   }
 }
