@@ -180,7 +180,7 @@ def main():
     flops = 2.0 * R * 2048 * 512
     ach = (flops / (up_ms / up_n * 1e-3) / 1e12) if up_n else None
     peak = PEAK_TFLOPS[dtype]
-    roof = dict(bound='mfma', kernel='gemm_nt_kernel<mlp2_up: [R,512]x[512,2048]+bias+GELU>',
+    roof = dict(bound='mfma', kernel='gemm_nt_kernel<mlp2_up: [R,512]x[512,2048]+bias+GELU, 128x128 tile, 8 waves>',
                 achieved=round(ach, 2) if ach else None, peak=peak, unit='TFLOP/s',
                 frac=round(ach / peak, 4) if ach else None, traffic=None,
                 launches=up_n, avg_us=round(up_ms / up_n * 1e3, 2) if up_n else None,
@@ -202,7 +202,8 @@ def main():
         dtype='bf16' if dtype == 'bfloat16' else 'f32', data='synthetic',
         config=dict(workload=f'TAPIR.__call__ ({args.model} kwargs), {S}x{S}x{T} clip, Q={Q}, '
                              f'4 refinement iters, random-init weights', clips=clips,
-                    shard=args.shard, backbone='PyTorch-ROCm', hot_path='HIP gfx950'),
+                    shard=args.shard, backbone='MIOpen convolutions + HIP norm/add/L2 kernels',
+                    hot_path='HIP gfx950'),
         hot_path_ms=round(hot_s * 1e3, 3), backbone_ms=round(bb_s * 1e3, 3),
         hot_path_points_per_s=round(Q / hot_s, 2),
         point_frames_per_s=round(value * T, 1),
