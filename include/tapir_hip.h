@@ -169,6 +169,7 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 #define TAPIR_PROF_CV_HEADS 4   /* cost-volume heads (cv_heads_kernel)                     */
 #define TAPIR_PROF_CV_GEMM 5    /* cost-volume einsum GEMM                                 */
 #define TAPIR_PROF_KINDS 6
+/* on: bit mask of kernel classes (1 << TAPIR_PROF_*) to bracket with events; -1 = all, 0 = off. */
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 

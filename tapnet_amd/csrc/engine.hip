@@ -64,7 +64,7 @@ struct tapir_ctx {
   const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
 
   // optional per-kernel-class timing with hipEvents on the caller's stream
-  bool prof = false;
+  unsigned prof = 0;   // bit k: kernel class k is bracketed by events
   struct ProfEv { hipEvent_t a, b; };
   std::vector<ProfEv> prof_ev[TAPIR_PROF_KINDS];   // recorded, not yet read
   std::vector<ProfEv> prof_free;                   // recycled event pairs
@@ -80,7 +80,7 @@ int fail(tapir_ctx* c, int code, const std::string& msg) {
 // brackets one kernel launch with events when profiling is on
 struct ProfScope {
   tapir_ctx* c; int kind; hipStream_t s; tapir_ctx::ProfEv ev; bool on;
-  ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_) : c(c_), kind(kind_), s(s_), on(c_->prof) {
+  ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_) : c(c_), kind(kind_), s(s_), on((c_->prof >> kind_) & 1u) {
     if (!on) return;
     if (!c->prof_free.empty()) { ev = c->prof_free.back(); c->prof_free.pop_back(); }
     else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
@@ -786,7 +786,7 @@ int tapir_refine_pips(tapir_ctx* c, const tapir_pyramid* pyr, int B, int Q, int 
 
 int tapir_profile_enable(tapir_ctx* c, int on) {
   if (!c) return TAPIR_ERR_INVALID;
-  c->prof = on != 0;
+  c->prof = on < 0 ? ~0u : (unsigned)on;
   return TAPIR_OK;
 }
 

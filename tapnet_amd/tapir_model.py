@@ -210,9 +210,18 @@ class TAPIR:
     self._check(self._lib.tapir_reserve(self._ctx, batch, num_queries, num_frames,
                                         lowres_hw[0], lowres_hw[1]), 'tapir_reserve')
 
-  def profile_enable(self, on: bool = True):
-    """hipEvent brackets around the hot kernels (include/tapir_hip.h, measurement support)."""
-    self._check(self._lib.tapir_profile_enable(self._ctx, int(on)), 'tapir_profile_enable')
+  def profile_enable(self, on=True):
+    """hipEvent brackets around the hot kernels (include/tapir_hip.h, measurement support).
+    on: True = every kernel class, False = off, or an iterable of class names (_ffi.PROF_KINDS)."""
+    if on is True:
+      mask = -1
+    elif not on:
+      mask = 0
+    else:
+      mask = 0
+      for name in on:
+        mask |= 1 << _ffi.PROF_KINDS[name]
+    self._check(self._lib.tapir_profile_enable(self._ctx, mask), 'tapir_profile_enable')
 
   def profile_read(self) -> Dict[str, Tuple[float, int]]:
     """{kernel class: (summed ms, launches)} since the last read; synchronises on the events."""

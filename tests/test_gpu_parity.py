@@ -285,3 +285,22 @@ def test_online_tracker_matches_streaming_api(use_graph):
   trk.update_points([3, 7], video[:, 2:3], new_qp)
   after = trk.step(video[:, 3:4])
   assert torch.isfinite(after['tracks']).all() and before['tracks'].shape == after['tracks'].shape
+
+
+@pytest.mark.gpu
+def test_batch_of_clips_equals_per_clip_runs(config2):
+  """BASELINE configs[2] shape in miniature: a batch of clips with their own query sets gives,
+  per clip, what a single-clip call gives (clips and queries are independent units; the token
+  rows of different clips only share GEMM tiles)."""
+  from tapnet_amd import tapir_model
+  w, video, qp = config2
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=synthetic.make_weights(3, 1, False),
+                        device='cuda:0')
+  v = np.concatenate([video[:, :12], video[:, 12:24], video[:, 24:36]], 0)        # [3,12,256,256,3]
+  q = np.stack([qp[0, :40], qp[0, 40:80], qp[0, 80:120]], 0).copy()
+  q[..., 0] = np.minimum(q[..., 0], 11)
+  both = m(v, False, q)
+  for b in range(3):
+    one = m(v[b:b + 1], False, q[b:b + 1])
+    np.testing.assert_allclose(both['tracks'][b], one['tracks'][0], atol=2e-3)
+    np.testing.assert_allclose(both['occlusion'][b], one['occlusion'][0], atol=2e-3)
