@@ -193,6 +193,8 @@ def bench_mixer(model, reps, results):
 
 
 def bench_backbone(model, reps, results):
+  if os.environ.get('TAPIR_CUDNN_BENCHMARK'):
+    torch.backends.cudnn.benchmark = os.environ['TAPIR_CUDNN_BENCHMARK'] == '1'
   dev = model.device
   video = torch.as_tensor(synthetic.make_video(1, 48, 256, 256), device=dev)
   def run(i):
