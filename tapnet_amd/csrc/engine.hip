@@ -59,6 +59,7 @@ struct tapir_ctx {
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
   DevBuf norm_ss;   // [N, C, 2] scale / shift of the InstanceNorm being applied
+  DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
   // which caller grid each cast slot currently holds (valid within one call)
   const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
@@ -283,6 +284,19 @@ int pick_time_chunk(int N, int T) {
   return (T + nch - 1) / nch;
 }
 
+// mixer GEMM: split-K for few rows (online model), the tiled persistent kernel otherwise
+template <typename TA, typename TO, int EPI>
+int mixer_gemm(tapir_ctx* c, const GemmArgs& g, hipStream_t s) {
+  const int splits = gemm_splits<TA>(g.M, g.K);
+  if (splits > 1 && g.N % 4 == 0) {
+    TRY(ensure(c, c->splitk, (size_t)splits * g.M * g.N * sizeof(float)));
+    launch_gemm_splitk<TA, TO, EPI>(g, splits, (float*)c->splitk.p, s);
+  } else {
+    launch_gemm<TA, TO, EPI>(g, s);
+  }
+  return TAPIR_OK;
+}
+
 // PIPSMLPMixer on R = N*T token rows already staged in c->mlp_in -> c->res [R,388]
 template <typename TA>
 int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
@@ -298,7 +312,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g{};
     g.A = c->mlp_in.p; g.lda = c->k0_pad; g.W = c->W0; g.ldw = c->k0_pad; g.bias = c->b0;
     g.C = c->xa.p; g.ldc = kHidden; g.M = (int)R; g.N = kHidden; g.K = c->k0_pad;
-    launch_gemm<TA, float, EPI_BIAS>(g, s);
+    TRY((mixer_gemm<TA, float, EPI_BIAS>(c, g, s)));
   }
   const int TC = pick_time_chunk(N, T);
   const int nch = (T + TC - 1) / TC;
@@ -317,19 +331,19 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); launch_gemm<TA, TA, EPI_BIAS_GELU>(g1, s); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); TRY((mixer_gemm<TA, TA, EPI_BIAS_GELU>(c, g1, s))); }
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); launch_gemm<TA, float, EPI_BIAS_RESID>(g2, s); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); TRY((mixer_gemm<TA, float, EPI_BIAS_RESID>(c, g2, s))); }
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
   GemmArgs g{};
   g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
   g.C = c->res.p; g.ldc = kMixOut; g.M = (int)R; g.N = kMixOut; g.K = kHidden;
-  launch_gemm<TA, float, EPI_BIAS>(g, s);
+  TRY((mixer_gemm<TA, float, EPI_BIAS>(c, g, s)));
   return TAPIR_OK;
 }
 
@@ -600,7 +614,7 @@ void tapir_destroy(tapir_ctx* c) {
   for (void* p : c->owned) (void)hipFree(p);
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
-                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->norm_ss};
+                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->norm_ss, &c->splitk};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
@@ -709,6 +723,7 @@ int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
   TRY(ensure(c, c->pos, R * 8)); TRY(ensure(c, c->occ, R * 4)); TRY(ensure(c, c->expd, R * 4));
   TRY(ensure(c, c->occ0, R * 4)); TRY(ensure(c, c->expd0, R * 4));
   TRY(ensure(c, c->feats, R * kFeatDim * 4)); TRY(ensure(c, c->qpts, BQ * 12));
+  if (R <= 512) TRY(ensure(c, c->splitk, (size_t)8 * R * kHidden4 * 4));
   long qc = (256L << 20) / ((long)T * mh * mw * 4);
   qc = std::max<long>(1, std::min<long>(qc, Q));
   TRY(ensure(c, c->cv, (size_t)qc * T * mh * mw * 4));

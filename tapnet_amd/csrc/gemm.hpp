@@ -292,9 +292,11 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   const int len = q + (xcd < r ? 1 : 0);
   if (slot >= len) return;
 
-  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
-  const TA* __restrict__ W = reinterpret_cast<const TA*>(g.W);
-  TO* __restrict__ C = reinterpret_cast<TO*>(g.C);
+  // split-K: slice blockIdx.y multiplies columns [y K, (y+1) K) of A and W into its own partial
+  // output [M, ldc] (g.K is the slice length; splitk_reduce_kernel sums the slices)
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A) + (long)blockIdx.y * g.K;
+  const TA* __restrict__ W = reinterpret_cast<const TA*>(g.W) + (long)blockIdx.y * g.K;
+  TO* __restrict__ C = reinterpret_cast<TO*>(g.C) + (long)blockIdx.y * g.M * g.ldc;
   const int nk = g.K / BK;
   const bool wide = (g.ldc * (long)sizeof(TO)) % 16 == 0;   // rows keep 16-byte alignment
   const bool has_bias = g.bias != nullptr;
@@ -609,12 +611,66 @@ inline int gemm_pick_tile(int M, int N) {
 }
 
 template <typename TA, typename TO, int EPI, typename TL>
-inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid) {
+inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid, int splits = 1) {
   const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / TL::LDS_BYTES));
   int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
-  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid), dim3(TL::THREADS), 0, stream, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid, splits), dim3(TL::THREADS), 0, stream, g);
+}
+
+// ---- split-K for few rows (the online model: M = points x 1 frame).  With M = 256 a mixer GEMM is
+// 8-32 tiles of up to 32 DEPENDENT k-steps on a 256-CU chip; slicing K puts 64 workgroups of 4 k-steps
+// each to work, and an element-wise pass adds the slices, the bias and the epilogue.
+struct SplitKReduceArgs {
+  const float* part;     // [splits, M, N]
+  const float* bias;     // [N] or null
+  const float* resid; long ldr;
+  void* C; long ldc;
+  int M, N, splits;
+};
+template <typename TO, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKReduceArgs a) {
+  const long total = (long)a.M * (a.N / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / (a.N / 4)), n = (int)(i % (a.N / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias != nullptr) v = *reinterpret_cast<const float4*>(a.bias + n);
+    for (int s = 0; s < a.splits; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(a.part + ((long)s * a.M + m) * a.N + n);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (EPI == EPI_BIAS_GELU) { v.x = gelu_tanh(v.x); v.y = gelu_tanh(v.y); v.z = gelu_tanh(v.z); v.w = gelu_tanh(v.w); }
+    if (EPI == EPI_BIAS_RESID) {
+      const float4 r = *reinterpret_cast<const float4*>(a.resid + (long)m * a.ldr + n);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    Store4<TO>::run(reinterpret_cast<TO*>(a.C) + (long)m * a.ldc + n, v.x, v.y, v.z, v.w);
+  }
+}
+
+// number of K slices for a GEMM of M rows (1 = no split): slices of >= 4 k-steps, <= 8 slices
+template <typename TA>
+inline int gemm_splits(int M, int K) {
+  const int kstep = 128 / (int)sizeof(TA);
+  if (M > 512) return 1;
+  int best = 1;
+  for (int s = 2; s <= 8; ++s)
+    if (K % (s * kstep) == 0 && K / (s * kstep) >= 3) best = s;
+  return best;
+}
+
+// C = epi(A W^T + bias) through `splits` K slices; part: f32 workspace [splits, M, N]
+template <typename TA, typename TO, int EPI>
+inline void launch_gemm_splitk(const GemmArgs& g, int splits, float* part, hipStream_t stream) {
+  GemmArgs p = g;
+  p.bias = nullptr; p.resid = nullptr;
+  p.C = part; p.ldc = g.N; p.K = g.K / splits;
+  launch_gemm_tile<TA, float, EPI_BIAS, GemmTileSquare8>(p, stream, 0, splits);
+  SplitKReduceArgs r{part, g.bias, g.resid, g.ldr, g.C, g.ldc, g.M, g.N, splits};
+  const long total = (long)g.M * (g.N / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<TO, EPI>), dim3((unsigned)std::min<long>((total + 255) / 256, 2048)),
+                     dim3(256), 0, stream, r);
 }
 
 template <typename TA, typename TO, int EPI>
