@@ -164,10 +164,21 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinali
   const int per_s = (a.HW + a.slabs - 1) / a.slabs;
   for (int c = threadIdx.x; c < a.C; c += NORM_THREADS) {
     float cn = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < a.slabs; ++s) {
-      const float nb = (float)max(0, min(a.HW, (s + 1) * per_s) - s * per_s);
-      const float* in = a.part + (((long)n * a.slabs + s) * a.C + c) * 2;
-      merge_stats(cn, mean, m2, nb, in[0], in[1]);
+    for (int s0 = 0; s0 < a.slabs; s0 += 8) {   // 8 summaries in flight per round trip
+      float2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = min(s0 + k, a.slabs - 1);
+        v[k] = *reinterpret_cast<const float2*>(a.part + (((long)n * a.slabs + s) * a.C + c) * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s0 + k;
+        if (s < a.slabs) {
+          const float nb = (float)max(0, min(a.HW, (s + 1) * per_s) - s * per_s);
+          merge_stats(cn, mean, m2, nb, v[k].x, v[k].y);
+        }
+      }
     }
     const float rstd = 1.0f / sqrtf(m2 / (float)a.HW + kInEps);
     const float sc = rstd * a.gamma[c];
