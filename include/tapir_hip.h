@@ -203,7 +203,8 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * epi 0: C f32 = acc + bias;  1: C operand type = gelu_tanh(acc + bias);
  * 2: C f32 = acc + bias + resid [M,ldr] f32.  tile: 0 = automatic, 1 = 192x128 (4 LDS stages), 2 = 128x128,
  * 3 = 192x64, 4 = 192x128 (3 stages), 5 = 192x128 wave-specialised (4 DMA + 8 MFMA waves),
- * 6 = 192x256, 7 = 256x128 (3 stages), 8 = 128x128 with 8 waves, 9 = 192x64 with 8 waves; bits 8..19 of `tile`, when non-zero, cap the persistent grid (tests).  K must be a multiple of 64 (bf16) / 32 (f32); N, ldc multiples of 4. */
+ * 6 = 192x256, 7 = 256x128 (3 stages), 8 = 128x128 with 8 waves, 9 = 192x64 with 8 waves,
+ * 10 = 128x64 with 8 waves (three workgroups per CU); bits 8..19 of `tile`, when non-zero, cap the persistent grid (tests).  K must be a multiple of 64 (bf16) / 32 (f32); N, ldc multiples of 4. */
 int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, long ldw,
                      const float* bias, const float* resid, long ldr, void* C, long ldc,
                      int M, int N, int K, int epi, int tile, void* stream);

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
 // Tile shapes.  Slots = workgroups per CU (LDS-limited) x 256 CUs.
 enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3,
        GEMM_TILE_192x128_S3 = 4, GEMM_TILE_192x128_WS = 5, GEMM_TILE_192x256 = 6, GEMM_TILE_256x128 = 7,
-       GEMM_TILE_128x128_W8 = 8, GEMM_TILE_192x64_W8 = 9, GEMM_TILE_COUNT = 10 };
+       GEMM_TILE_128x128_W8 = 8, GEMM_TILE_192x64_W8 = 9, GEMM_TILE_128x64_W8 = 10, GEMM_TILE_COUNT = 11 };
 typedef GemmTile<4, 2, 3, 4, 4> GemmTileBig;     // 192x128, 8 waves, 4 stages = 160 KiB: 1 per CU
 typedef GemmTile<4, 2, 3, 4, 3> GemmTileBig3;    // same, 3 stages = 120 KiB
 typedef GemmTile<2, 2, 4, 4, 2> GemmTileSquare;  // 128x128, 4 waves, 64 KiB: 2 per CU
@@ -597,6 +597,7 @@ typedef GemmTile<2, 4, 6, 4, 2> GemmTileWide;    // 192x256, 8 waves, 2 stages =
 typedef GemmTile<4, 2, 4, 4, 3> GemmTileLong;    // 256x128, 8 waves, 3 stages = 144 KiB
 typedef GemmTile<2, 4, 4, 2, 2> GemmTileSquare8; // 128x128, 8 waves (64x32 each), 64 KiB: 2 per CU = 16 waves
 typedef GemmTile<4, 2, 3, 2, 2> GemmTileTall8;   // 192x64, 8 waves (48x32 each), 64 KiB: 2 per CU = 16 waves
+typedef GemmTile<4, 2, 2, 2, 2> GemmTileSmall8;  // 128x64, 8 waves (32x32 each), 48 KiB: 3 per CU = 24 waves
 
 // Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/r01_kbench_gemm.log):
 // narrow outputs with a long K (N <= 1024) run best on 192x64 (512 tiles = one per LDS slot),
@@ -613,7 +614,7 @@ inline int gemm_pick_tile(int M, int N) {
 template <typename TA, typename TO, int EPI, typename TL>
 inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid, int splits = 1) {
   const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
-  const int per_cu = std::max(1, std::min(2, (160 * 1024) / TL::LDS_BYTES));
+  const int per_cu = std::max(1, std::min(3, (160 * 1024) / TL::LDS_BYTES));
   int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid, splits), dim3(TL::THREADS), 0, stream, g);
@@ -685,6 +686,7 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
     case GEMM_TILE_256x128: launch_gemm_tile<TA, TO, EPI, GemmTileLong>(g, stream, max_grid); break;
     case GEMM_TILE_128x128_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
     case GEMM_TILE_192x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileTall8>(g, stream, max_grid); break;
+    case GEMM_TILE_128x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSmall8>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_WS: {   // 8 consumer + 4 producer waves, 4 stages, one workgroup per CU
       using TL = GemmTileBig;
       const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);

@@ -46,7 +46,7 @@ def run_gemm(lib, dtype, A, W, bias, resid, epi, tile, max_grid=0):
 
 
 @pytest.mark.parametrize('dtype', [_ffi.TAPIR_F32, _ffi.TAPIR_BF16])
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm_tile_shapes(dtype, tile, epi):
   lib = emu_lib()
@@ -69,7 +69,7 @@ def test_gemm_tile_shapes(dtype, tile, epi):
   np.testing.assert_allclose(out, ref, atol=tol)
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_persistent_walk(tile):
   """8 workgroups walk 12..28 tiles: the next tile's first DMA is issued before the epilogue."""
   lib = emu_lib()
