@@ -10,12 +10,9 @@
 // same linear re-association).  Cells outside the grid contribute zero
 // (interp(mode='constant') :524).
 //
-// One workgroup per token (b, q, t); wave L handles pyramid level L: the 64
-// lanes split the C channels of one grid cell (coalesced 16-byte loads along
-// the channels-last feature grid), accumulate 64 per-cell partial dots in
-// registers, and a 63-shuffle transposed butterfly leaves the full dot product
-// of cell p in lane p.
+// One workgroup per token (b, q, t); wave L handles pyramid level L (see level_corr).
 #pragma once
+#include "backbone.hpp"   // Vec16
 #include "common.hpp"
 
 namespace tapir {
@@ -40,60 +37,59 @@ struct PatchArgs {
   float orig_h, orig_w; // initial_resolution
 };
 
-template <int CPL, typename TG>
-__device__ __forceinline__ float cell_dot(const TG* p, const float* qv);
-
-template <> __device__ __forceinline__ float cell_dot<4, float>(const float* p, const float* qv) {
-  const float4 v = *reinterpret_cast<const float4*>(p);
-  return v.x * qv[0] + v.y * qv[1] + v.z * qv[2] + v.w * qv[3];
-}
-template <> __device__ __forceinline__ float cell_dot<2, float>(const float* p, const float* qv) {
-  const float2 v = *reinterpret_cast<const float2*>(p);
-  return v.x * qv[0] + v.y * qv[1];
-}
-template <> __device__ __forceinline__ float cell_dot<4, bf16_t>(const bf16_t* p, const float* qv) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
-  return __uint_as_float(v.x << 16) * qv[0] + __uint_as_float(v.x & 0xffff0000u) * qv[1] +
-         __uint_as_float(v.y << 16) * qv[2] + __uint_as_float(v.y & 0xffff0000u) * qv[3];
-}
-template <> __device__ __forceinline__ float cell_dot<2, bf16_t>(const bf16_t* p, const float* qv) {
-  const unsigned v = *reinterpret_cast<const unsigned*>(p);
-  return __uint_as_float(v << 16) * qv[0] + __uint_as_float(v & 0xffff0000u) * qv[1];
-}
-
 // 8x8 window of dot products for one level; returns the 7x7 blended value for
 // lane (i=lane>>3, j=lane&7) (garbage for i==7 or j==7).
-template <int CPL, typename TG>
-__device__ __forceinline__ float level_corr(const PyrLevel& L, const float* qv, long frame,
+//
+// Lane (i = lane >> 3, cs = lane & 7) owns window row i and the channel slice
+// [cs*C/8, (cs+1)*C/8): for each of the 8 cells of its row it accumulates the partial dot
+// product over its slice (the 8 lanes of a row read one cell's C*sizeof(TG) contiguous bytes,
+// 16 B per load), then a transposed butterfly over the 3 low lane bits (7 shuffles) leaves the
+// full dot product of cell (i, j) in lane i*8 + j.  (The first version gave every lane 4
+// channels of all 64 cells: 63 shuffles per level.)
+template <int C, typename TG>
+__device__ __forceinline__ float level_corr(const PyrLevel& L, const float* __restrict__ qsrc, long frame,
                                             float px, float py, float orig_w, float orig_h,
                                             int lane) {
+  constexpr int SL = C / 8;                       // channels per lane
+  constexpr int EPL = 16 / (int)sizeof(TG);       // elements per 16-byte load
   // coords = pos * grid_size / orig_size (transforms.py:75-76), then -0.5 (model_utils.py:199)
   const float gx = px * (float)L.w / orig_w - 0.5f;
   const float gy = py * (float)L.h / orig_h - 0.5f;
   const float fx0 = floorf(gx), fy0 = floorf(gy);
   const float fx = gx - fx0, fy = gy - fy0;
   const int x0 = (int)fx0 - 3, y0 = (int)fy0 - 3;   // window origin (offset -3)
-  const TG* base = reinterpret_cast<const TG*>(L.grid) + frame * ((long)L.h * L.w * L.C) + lane * CPL;
-
-  float part[64];
+  const int i = lane >> 3, cs = lane & 7;
+  float qv[SL];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int y = y0 + i;
-    const bool vy = (y >= 0) && (y < L.h);
-    const int yc = min(max(y, 0), L.h - 1);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int x = x0 + j;
-      const bool v = vy && (x >= 0) && (x < L.w);
-      const int xc = min(max(x, 0), L.w - 1);
-      const float d = cell_dot<CPL, TG>(base + ((long)yc * L.w + xc) * L.C, qv);
-      part[i * 8 + j] = v ? d : 0.f;
-    }
+  for (int k = 0; k < SL; k += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(qsrc + cs * SL + k);
+    qv[k] = t.x; qv[k + 1] = t.y; qv[k + 2] = t.z; qv[k + 3] = t.w;
   }
-  // transposed butterfly: after the step with offset `off`, a lane keeps the
-  // half of its values whose cell index has bit `off` equal to the lane's.
+  const int y = y0 + i;
+  const bool vy = (y >= 0) && (y < L.h);
+  const int yc = min(max(y, 0), L.h - 1);
+  const TG* rowp = reinterpret_cast<const TG*>(L.grid) + (frame * L.h + yc) * ((long)L.w * C) + cs * SL;
+  float part[8];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
+  for (int j = 0; j < 8; ++j) {
+    const int x = x0 + j;
+    const bool v = vy && (x >= 0) && (x < L.w);
+    const int xc = min(max(x, 0), L.w - 1);
+    const TG* p = rowp + (long)xc * C;
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; k += EPL) {
+      float e[EPL];
+      Vec16<TG>::load(p + k, e);
+#pragma unroll
+      for (int u = 0; u < EPL; ++u) d = fmaf(e[u], qv[k + u], d);
+    }
+    part[j] = v ? d : 0.f;
+  }
+  // transposed butterfly over lane bits 2..0: after the step with offset `off`, a lane keeps
+  // the half of its values whose cell index j has bit `off` equal to the lane's
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
     const bool up = (lane & off) != 0;
 #pragma unroll
     for (int k = 0; k < off; ++k) {
@@ -141,22 +137,11 @@ __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
   const PyrLevel& L = a.lvl[wave];
   const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
   const long frame = (long)b * a.T + t;
+  // the query vector of this level: the refined per-token feature, or the (tiled) query feature
+  const float* qsrc = (a.feats != nullptr) ? a.feats + r * kFeatDim + L.feat_off : L.query + bq * L.C;
   float corr;
-  if (L.C == 256) {
-    float qv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      qv[k] = (a.feats != nullptr) ? a.feats[r * kFeatDim + L.feat_off + lane * 4 + k]
-                                   : L.query[bq * 256 + lane * 4 + k];
-    corr = level_corr<4, TG>(L, qv, frame, px, py, a.orig_w, a.orig_h, lane);
-  } else {   // C == 128
-    float qv[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-      qv[k] = (a.feats != nullptr) ? a.feats[r * kFeatDim + L.feat_off + lane * 2 + k]
-                                   : L.query[bq * 128 + lane * 2 + k];
-    corr = level_corr<2, TG>(L, qv, frame, px, py, a.orig_w, a.orig_h, lane);
-  }
+  if (L.C == 256) corr = level_corr<256, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
+  else corr = level_corr<128, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
   const int i = lane >> 3, j = lane & 7;
   if (i < 7 && j < 7) Elem<TO>::st(out + ncorr0 + kPatch * wave + i * 7 + j, corr);
 }
