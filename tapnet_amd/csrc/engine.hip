@@ -896,6 +896,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.dbg_times = (long long*)c->dbg_times;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   const int mg = (tile >> 8) & 0xfff;   // test hook: cap the persistent grid (several tiles per workgroup)

@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* resid; long ldr;            // EPI_BIAS_RESID: [M, ldr] f32
   void* C; long ldc;
   int M, N, K;                             // K multiple of (128 / sizeof(T)); N, ldc multiples of 4
+  long long* dbg_times;                    // null, or [workgroups][16] wall-clock stamps (tools/kbench.py --what gemmtrace)
 };
 
 template <typename T> struct MfmaStep;
@@ -302,6 +303,12 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   const bool has_bias = g.bias != nullptr;
 
   // ---- DMA side: issues k-step copies in (tile, k) order, NS-1 steps ahead of the MFMAs
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (g.dbg_times != nullptr && tid == 0 && stamp_i < 16) g.dbg_times[(long)blockIdx.x * 16 + stamp_i] = wall_clock64();
+    ++stamp_i;
+  };
+  stamp();   // 0: start
   GemmStager<TA, TL, PAIR> st;
   st.local = slot; st.kt = 0;
   st.set_tile(g, ((start + slot) / tiles_n) * TL::BM, ((start + slot) % tiles_n) * TL::BN, tid);
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) consume(bias4[j]);
   block_barrier();
+  stamp();   // 1: first stage landed
 
   // ---- MFMA side.  One k-step: refill the stage read in the previous step, multiply from stage
   // S, wait until this wave's copies of stage t+AHEAD have landed, barrier.
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
       }
     }
 
+    stamp();   // 2 + 2 i: k-loop of tile i done
     // epilogue
     // Bias: normally still in registers from the previous tile (the persistent schedule gives a
     // workgroup tiles of ONE column block whenever tiles_n divides the per-XCD stride).  A reload
@@ -425,6 +434,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
     const bool interior = wide && m0 + TL::BM <= g.M && n0 + TL::BN <= g.N;
     if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb, fg);
     else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb, fg);
+    stamp();   // 3 + 2 i: epilogue of tile i issued
   }
 }
 

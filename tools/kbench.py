@@ -171,6 +171,38 @@ def trace_mix(model):
       print(f'  phase {names[k]} -> {names[k + 1]}: median {np.median(d[:, k]):6.2f} us  p90 {np.percentile(d[:, k], 90):6.2f}')
 
 
+def trace_gemm(model):
+  """per-workgroup stamps of the mixer GEMMs: prologue, k-loop and epilogue of every tile"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  tdt = torch.bfloat16
+  for name, M, N, K, epi, tile in (('up', R, 2048, 512, 1, 8), ('up', R, 2048, 512, 1, 1), ('up', R, 2048, 512, 1, 6),
+                                   ('up', R, 2048, 512, 1, 2), ('down', R, 512, 2048, 2, 3), ('down', R, 512, 2048, 2, 1),
+                                   ('down', R, 512, 2048, 2, 7)):
+    A = torch.randn(M, K, device=dev).to(tdt); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(tdt)
+    bias = torch.randn(N, device=dev); resid = torch.randn(M, N, device=dev)
+    C = torch.empty(M, N, device=dev, dtype=tdt if epi == 1 else torch.float32)
+    tr = torch.zeros(512, 16, dtype=torch.int64, device=dev)
+    def run():
+      lib.tapir_debug_gemm(ctx, A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N,
+                           C.data_ptr(), N, M, N, K, epi, tile, model._stream())
+    for _ in range(3):
+      run()
+    torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, tr.data_ptr()); run(); torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, None)
+    t = tr.cpu().numpy().astype(np.float64) * 0.01
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    nst = int((t[0] > 0).sum())
+    print(f'gemm {name} tile {TILES[tile]}: {t.shape[0]} workgroups, {nst} stamps, span {(t[:, :nst].max() - t0):.1f} us')
+    print('  start spread (us): median', round(float(np.median(t[:, 0] - t0)), 2), 'max', round(float((t[:, 0] - t0).max()), 2))
+    d = np.diff(t[:, :nst], axis=1)
+    labels = ['prologue (first stage landed)'] + sum([[f'k-loop tile {i}', f'epilogue tile {i}'] for i in range(8)], [])
+    for k in range(nst - 1):
+      print(f'  {labels[k]:32s} median {np.median(d[:, k]):6.2f} us   p90 {np.percentile(d[:, k], 90):6.2f}')
+
+
 def bench_mixer(model, reps, results):
   """whole PIPSMLPMixer (12 blocks) on 256 x 48 tokens through the public C ABI"""
   lib, ctx = model._lib, model._ctx
@@ -228,6 +260,8 @@ def main():
                  [int(d) for d in args.dbg.split(',')] if args.dbg else None)
     if 'mix' in what:
       bench_mix(model, args.reps, results)
+    if 'gemmtrace' in what:
+      trace_gemm(model)
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
