@@ -200,6 +200,26 @@ __device__ __forceinline__ void gemm_mfma_frags(const uint4 (&fa)[TL::FM], const
     for (int j = 0; j < TL::FN; ++j) MfmaStep<TA>::run(fw[j], fa[i], acc[i][j]);
 }
 
+// Accumulators of a new tile: zero, or -- EPI_BIAS_RESID -- the residual tile itself (it has the
+// accumulator's layout, so "+ skip" costs no epilogue loads and no registers; the loads are waited for
+// together with the first stage of copies).
+template <typename TO, int EPI, typename TL>
+__device__ __forceinline__ void gemm_init_acc(const GemmArgs& g, f32x4 (&acc)[TL::FM][TL::FN], int mb,
+                                              int nb, int fg) {
+  constexpr bool PAIR = sizeof(TO) == 2;
+#pragma unroll
+  for (int i = 0; i < TL::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < TL::FN; ++j) {
+      if (EPI == EPI_BIAS_RESID) {
+        const int m = min(mb + i * 16, g.M - 1), n = min(nb + TL::template col<PAIR>(j, fg), g.N - 4);
+        acc[i][j] = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+      } else {
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+}
+
 // Epilogue of one tile: lane holds C[m = mb + 16 i][n = nb + col(j, fg) + 0..3] (GemmTile::col).
 template <typename TO, int EPI, typename TL, bool INTERIOR>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict__ C,
@@ -210,15 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict_
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = mb + i * 16;
-    const int mc = INTERIOR ? m : min(m, g.M - 1);
-    float4 res4[FN];
-    if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = nb + TL::template col<PAIR>(j, fg);
-        res4[j] = *reinterpret_cast<const float4*>(g.resid + (long)mc * g.ldr + (INTERIOR ? n : min(n, g.N - 4)));
-      }
-    }
+    // (EPI_BIAS_RESID: the accumulators were INITIALISED with the residual, see gemm_init_acc)
     float v[FN][4];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -227,9 +239,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict_
       float v2 = acc[i][j][2] + b[2], v3 = acc[i][j][3] + b[3];
       if (EPI == EPI_BIAS_GELU) {
         v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
-      }
-      if (EPI == EPI_BIAS_RESID) {
-        v0 += res4[j].x; v1 += res4[j].y; v2 += res4[j].z; v3 += res4[j].w;
       }
       v[j][0] = v0; v[j][1] = v1; v[j][2] = v2; v[j][3] = v3;
     }
@@ -346,6 +355,10 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   constexpr bool PREFETCH = TL::PREFETCH;
   constexpr int AHEAD = PREFETCH ? 2 : 1;
   constexpr int INFLIGHT = (NS - 1 - AHEAD) * TL::CH;
+  // accumulators of the first tile (EPI_BIAS_RESID: residual loads, in flight with the first copies)
+  f32x4 acc[FM][FN];
+  gemm_init_acc<TO, EPI, TL>(g, acc, ((start + slot) / tiles_n) * TL::BM + wm * FM * 16 + fr,
+                             ((start + slot) % tiles_n) * TL::BN + wn * FN * 16, fg);
   if (st.local < len) dma_wait<INFLIGHT>(); else dma_wait<0>();
   // "use" the bias here so that the compiler's wait for it sits here and not in every epilogue
 #pragma unroll
@@ -355,7 +368,6 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
 
   // ---- MFMA side.  One k-step: refill the stage read in the previous step, multiply from stage
   // S, wait until this wave's copies of stage t+AHEAD have landed, barrier.
-  f32x4 acc[FM][FN];
   uint4 fa0[FM], fw0[FN];   // first-half fragments of the current stage (NS >= 3: prefetched)
   if (PREFETCH) gemm_load_frags<TL, PAIR>(bufs[0], a_row, w_row, fr, fg, 0, fa0, fw0);
   auto step = [&](auto tag) {
@@ -376,12 +388,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
 
   int phase = 0;   // stage that holds the current k-step
   for (int local = slot; local < len; local += per_xcd) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // this lane's output coordinates: C[m = mb + 16 i][n = nb + 4 j + 0..3]
+    // this lane's output coordinates: C[m = mb + 16 i][n = nb + col(j, fg) + 0..3]
     const int m0 = ((start + local) / tiles_n) * TL::BM;
     const int n0 = ((start + local) % tiles_n) * TL::BN;
     const int mb = m0 + wm * FM * 16 + fr;
@@ -435,6 +442,11 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
     if (interior) gemm_epilogue<TO, EPI, TL, true>(g, C, acc, bias4, mb, nb, fg);
     else gemm_epilogue<TO, EPI, TL, false>(g, C, acc, bias4, mb, nb, fg);
     stamp();   // 3 + 2 i: epilogue of tile i issued
+    if (local + per_xcd < len) {   // accumulators of the next tile
+      const int nl = local + per_xcd;
+      gemm_init_acc<TO, EPI, TL>(g, acc, ((start + nl) / tiles_n) * TL::BM + wm * FM * 16 + fr,
+                                 ((start + nl) % tiles_n) * TL::BN + wn * FN * 16, fg);
+    }
   }
 }
 
@@ -565,10 +577,8 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
   };
   int phase = 0;
   for (int local = slot; local < len; local += per_xcd) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_init_acc<TO, EPI, TL>(g, acc, ((start + local) / tiles_n) * TL::BM + wm * FM * 16 + fr,
+                               ((start + local) % tiles_n) * TL::BN + wn * FN * 16, fg);
     for (int kt = 0; kt < nk; ++kt) {
       switch (phase) {
         case 0: cstep(StageTag<0>{}); break;
