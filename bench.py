@@ -62,8 +62,7 @@ def cpu_baseline(args, kw, weights, video, qpts):
   """The oracle (numpy port of the reference hot path) + the backbone restatement on torch-CPU,
   timed on this host's cores on a bounded sample and extrapolated linearly to the workload:
   backbone cost is per frame, hot-path cost per query (both are independent units)."""
-  from oracle import tapir_oracle as O
-  from tapnet_amd import backbone
+  from oracle import backbone_torch, tapir_oracle as O
   cores = min(os.cpu_count() or 1, 32)   # more threads only add contention for these sizes
   torch.set_num_threads(cores)
   try:
@@ -73,7 +72,7 @@ def cpu_baseline(args, kw, weights, video, qpts):
     pass
   T, Q = video.shape[1], qpts.shape[1]
   sf, sq = min(args.cpu_sample_frames, T), min(args.cpu_sample_queries, Q)
-  bb = backbone.Backbone(weights, kw['extra_convs'], 'cpu')
+  bb = backbone_torch.TorchBackbone(weights, kw['extra_convs'])
   frames = torch.as_tensor(video[0, :sf])
   t0 = time.perf_counter()
   bb.features(frames)

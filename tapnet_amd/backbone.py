@@ -13,13 +13,13 @@ state_dict names (tapnet/torch/nets.py).
 Runs channels-last (NHWC) so that the feature grids leave in the
 [B,T,h,w,C] layout the HIP kernels read, with no transpose.
 
-On a GPU only the convolutions run in PyTorch (MIOpen implicit-GEMM, NHWC): everything
+GPU only.  Only the convolutions run in PyTorch (MIOpen / CK implicit-GEMM, NHWC): everything
 between them -- InstanceNorm statistics, normalise + ReLU (+ the high-side zero border of XLA
 SAME padding and the 2x2 subsampling for the strided projections), the residual add and
 the final L2 normalisation -- are the HIP kernels of tapnet_amd/csrc/backbone.hpp, called
-through the C ABI (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  The plain
-PyTorch restatement below (`_features_torch`) is what runs on a CPU device: it is used by
-the CPU tests and by bench.py's cpu_baseline only.
+through the C ABI (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  There is no CPU
+path here; the plain PyTorch restatement used by the CPU tests and by bench.py's cpu_baseline
+lives in oracle/backbone_torch.py.
 """
 from __future__ import annotations
 
@@ -45,16 +45,16 @@ class Backbone:
   def __init__(self, weights: Dict[str, torch.Tensor], extra_convs: bool, device,
                dtype: torch.dtype = torch.float32,
                blocks_per_group: Sequence[int] = (2, 2, 2, 2), engine=None):
-    """engine: (ctypes library, context) of libtapir_hip.so -- required on a GPU device."""
+    """engine: (ctypes library, context) of libtapir_hip.so -- required."""
     self.device = torch.device(device)
     self.engine = engine
-    if self.device.type == 'cuda' and engine is None:
-      raise RuntimeError('the GPU backbone needs the HIP engine (libtapir_hip.so); no fallback')
-    if self.device.type == 'cuda':
-      # MIOpen exhaustive solver search per convolution shape (first call only): the default
-      # heuristic picks atomic split-K implicit-GEMM kernels that need a zero-fill pass per call;
-      # measured 3.12 -> 2.66 ms per 48-frame clip
-      torch.backends.cudnn.benchmark = True
+    if self.device.type != 'cuda' or engine is None:
+      raise RuntimeError('tapnet_amd.backbone.Backbone needs a ROCm GPU and the HIP engine '
+                         '(libtapir_hip.so); there is no CPU path')
+    # MIOpen exhaustive solver search per convolution shape (first call only): the default
+    # heuristic picks atomic split-K implicit-GEMM kernels that need a zero-fill pass per call;
+    # measured 3.12 -> 2.66 ms per 48-frame clip
+    torch.backends.cudnn.benchmark = True
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
@@ -76,38 +76,11 @@ class Backbone:
       if n not in self.w:
         raise KeyError(f'backbone weight missing: {n}')
 
-  # -- building blocks ------------------------------------------------------
+  # -- ExtraConvs (BootsTAPIR): small 32x32 maps, PyTorch ops on the GPU -----
   def _conv(self, x, name, stride=1, bias=False):
     w = self.w[name + '.weight']
     b = self.w[name + '.bias'].to(x.dtype) if bias else None
     return F.conv2d(_same_pad(x, w.shape[-1], stride), w, b, stride=stride)
-
-  def _inorm_relu(self, x, name):
-    # hk.InstanceNorm(create_scale, create_offset), eps 1e-5 (resnet.py:177-181); stats in f32
-    y = F.instance_norm(x.float(), weight=self.w[name + '.weight'], bias=self.w[name + '.bias'],
-                        eps=1e-5)
-    return torch.relu(y).to(x.dtype)
-
-  def _block(self, x, p, stride, use_projection):
-    shortcut = x
-    y = self._inorm_relu(x, p + 'bn_0')
-    if use_projection:
-      shortcut = self._conv(y, p + 'proj_conv', stride)
-    y = self._conv(y, p + 'conv_0', stride)
-    y = self._inorm_relu(y, p + 'bn_1')
-    y = self._conv(y, p + 'conv_1', 1)
-    return y + shortcut
-
-  def _resnet(self, x):
-    x = self._conv(x, 'resnet_torch.initial_conv', 2)
-    outs = {}
-    strides = (1, 2, 2, 1)
-    for g in range(4):
-      for b in range(self.blocks_per_group[g]):
-        x = self._block(x, f'resnet_torch.block_groups.{g}.blocks.{b}.',
-                        strides[g] if b == 0 else 1, b == 0)
-      outs[g] = x
-    return outs[3], outs[1]   # resnet_unit_3 (256 ch, /8), resnet_unit_1 (128 ch, /4)
 
   def _extra_convs(self, x):
     # x NCHW channels-last; LayerNorm over channels with scale+offset (tapir_model.py:176)
@@ -120,11 +93,6 @@ class Backbone:
       r = F.gelu(self._conv(x, p + 'conv', 1, bias=True), approximate='tanh')
       x = x + self._conv(r, p + 'conv_1', 1, bias=True)
     return x
-
-  @staticmethod
-  def _l2norm(x_nhwc):
-    s = torch.sum(torch.square(x_nhwc), dim=-1, keepdim=True)
-    return x_nhwc / torch.sqrt(torch.clamp_min(s, 1e-12))
 
   # -- GPU path: MIOpen convolutions + HIP glue kernels ---------------------
   def _buf(self, key, shape, dtype, zero=False):
@@ -211,15 +179,6 @@ class Backbone:
       x = self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
     return self._hip_l2norm(x), self._hip_l2norm(unit1)
 
-  def _features_torch(self, frames_nhwc):
-    x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2)
-    x = x.contiguous(memory_format=torch.channels_last)
-    u3, u1 = self._resnet(x)
-    if self.extra_convs:
-      u3 = self._extra_convs(u3)
-    return (self._l2norm(u3.permute(0, 2, 3, 1).float()).contiguous(),
-            self._l2norm(u1.permute(0, 2, 3, 1).float()).contiguous())
-
   # -- public ---------------------------------------------------------------
   @torch.no_grad()
   def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None
@@ -228,7 +187,7 @@ class Backbone:
     L2-normalised, contiguous channels-last."""
     n = frames_nhwc.shape[0]
     chunk = n if not chunk else chunk
-    run = self._features_hip if self.device.type == 'cuda' else self._features_torch
+    run = self._features_hip
     lows, his = [], []
     for s in range(0, n, chunk):
       lo, hi = run(frames_nhwc[s:s + chunk])

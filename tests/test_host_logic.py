@@ -58,7 +58,8 @@ def test_backbone_matches_reference_fixture(tag, extra):
   """R7 restatement (torch ops, CPU here) vs the reference's feature grids."""
   g = np.load(os.path.join(GOLDEN_DIR, 'backbone.npz'))
   w = synthetic.make_weights(21, 1, extra)
-  bb = backbone.Backbone(w, extra, 'cpu')
+  from oracle import backbone_torch
+  bb = backbone_torch.TorchBackbone(w, extra)
   low, hi = bb.features(torch.as_tensor(g['video']).reshape(-1, 64, 64, 3))
   np.testing.assert_allclose(low.numpy(), g[f'{tag}_lowres'][0], atol=2e-5)
   np.testing.assert_allclose(hi.numpy(), g[f'{tag}_hires'][0], atol=2e-5)
