@@ -88,6 +88,17 @@ __device__ __forceinline__ void consume(const f32x4& v) {
   asm volatile("" ::"v"(v));
 #endif
 }
+// "Arrival point" of an LDS read: the value is passed through an empty asm, so the compiler waits
+// for it HERE (with LDS-DMA in flight hipcc only ever emits lgkmcnt(0)) and treats every later
+// use as a plain register -- reads issued after this point stay in flight under those uses.
+__device__ __forceinline__ void arrive(uint4& v) {
+#ifndef TAPIR_HIPEMU
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t t = __builtin_bit_cast(u32x4_t, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(uint4, t);
+#endif
+}
 // Workgroup barrier that orders LDS traffic only (lgkmcnt), leaving vector-memory operations --
 // LDS-DMA copies, stores -- in flight.
 __device__ __forceinline__ void lds_barrier() {

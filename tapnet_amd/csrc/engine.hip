@@ -900,7 +900,14 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
   hipStream_t s = (hipStream_t)stream;
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   const int mg = (tile >> 8) & 0xfff;   // test hook: cap the persistent grid (several tiles per workgroup)
+  const bool traced = (tile >> 20) & 1;  // bf16 build: per-k-step cycle trace into the trace buffer
   tile &= 0xff;
+  if (traced) {
+    if (!bf || epi == 0 || !c->dbg_times) return fail(c, TAPIR_ERR_INVALID, "traced GEMM: bf16, epi 1|2, trace buffer set");
+    if (epi == 1) launch_gemm_traced<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg);
+    else launch_gemm_traced<bf16_t, float, EPI_BIAS_RESID>(g, s, tile, mg);
+    return TAPIR_OK;
+  }
   if (epi == 0) { if (bf) launch_gemm<bf16_t, float, EPI_BIAS>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS>(g, s, tile, mg); }
   else if (epi == 1) { if (bf) launch_gemm<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_GELU>(g, s, tile, mg); }
   else { if (bf) launch_gemm<bf16_t, float, EPI_BIAS_RESID>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_RESID>(g, s, tile, mg); }

@@ -185,11 +185,13 @@ template <typename TL, bool PAIR>
 __device__ __forceinline__ void gemm_load_frags(const uint4* lds, int a_row, int w_base, int fr, int fg,
                                                 int kk, uint4 (&fa)[TL::FM], uint4 (&fw)[TL::FN]) {
   const int c = (kk * 4 + fg) ^ (fr & 7);
-#pragma unroll
-  for (int i = 0; i < TL::FM; ++i) fa[i] = lds[(a_row + i * 16) * 8 + c];
+  // in the order the MFMAs consume them (LDS reads return in order: the first MFMA then waits
+  // for FN + 1 reads only, see the fence in the k-step)
 #pragma unroll
   for (int j = 0; j < TL::FN; ++j)
     fw[j] = lds[(TL::BM + w_base + TL::template w_row<PAIR>(j, fr)) * 8 + c];
+#pragma unroll
+  for (int i = 0; i < TL::FM; ++i) fa[i] = lds[(a_row + i * 16) * 8 + c];
 }
 template <typename TA, typename TL>
 __device__ __forceinline__ void gemm_mfma_frags(const uint4 (&fa)[TL::FM], const uint4 (&fw)[TL::FN],
@@ -268,7 +270,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict_
 template <int S> struct StageTag { static constexpr int value = S; };
 
 // TA: operand element type (bf16_t or float); TO: output element type.
-template <typename TA, typename TO, int EPI, typename TL>
+// TRACE (tools/kbench.py --what gemmsteps): every wave accumulates, over all its k-steps, the shader
+// cycles (s_memtime) spent in the four parts of a k-step -- issuing the copies, fragment reads +
+// MFMAs (until the last LDS read has returned), waiting for its own copies (vmcnt), waiting at the
+// barrier -- plus the epilogues, and lane 0 writes the six totals to g.dbg_times[(wg*16+wave)*8..].
+template <typename TA, typename TO, int EPI, typename TL, bool TRACE = false>
 __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   constexpr int EPC = 16 / (int)sizeof(TA);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                 // elements per 128-byte k-step
@@ -314,9 +320,23 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   // ---- DMA side: issues k-step copies in (tile, k) order, NS-1 steps ahead of the MFMAs
   int stamp_i = 0;
   auto stamp = [&]() {
-    if (g.dbg_times != nullptr && tid == 0 && stamp_i < 16) g.dbg_times[(long)blockIdx.x * 16 + stamp_i] = wall_clock64();
+    if (!TRACE && g.dbg_times != nullptr && tid == 0 && stamp_i < 16)
+      g.dbg_times[(long)blockIdx.x * 16 + stamp_i] = wall_clock64();
     ++stamp_i;
   };
+  unsigned long long tk[5] = {0, 0, 0, 0, 0}, tsum[5] = {0, 0, 0, 0, 0}, tstart = 0;
+  auto tick = [&](int k) {   // the value arrives asynchronously (SMEM): read it after tick_sync()
+#ifndef TAPIR_HIPEMU
+    if (TRACE) asm volatile("s_memtime %0" : "=s"(tk[k]) :: "memory");
+#endif
+  };
+  auto tick_sync = [&]() {
+#ifndef TAPIR_HIPEMU
+    if (TRACE)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tk[0]), "+s"(tk[1]), "+s"(tk[2]), "+s"(tk[3]), "+s"(tk[4]) :: "memory");
+#endif
+  };
+  if (TRACE) { tick(0); tick_sync(); tstart = tk[0]; }
   stamp();   // 0: start
   GemmStager<TA, TL, PAIR> st;
   st.local = slot; st.kt = 0;
@@ -372,18 +392,54 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   if (PREFETCH) gemm_load_frags<TL, PAIR>(bufs[0], a_row, w_row, fr, fg, 0, fa0, fw0);
   auto step = [&](auto tag) {
     constexpr int S = decltype(tag)::value;
-    const bool issued = issue_next(bufs[(S + NS - 1) % NS]);
-    sched_fence();   // keep the copy's address arithmetic out of the fragment live ranges
     uint4 fa1[FM], fw1[FN];
-    if (!PREFETCH) gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
-    gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
-    gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
-    if (PREFETCH) gemm_load_frags<TL, PAIR>(bufs[(S + 1) % NS], a_row, w_row, fr, fg, 0, fa0, fw0);
-    gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
+    bool issued;
+    if (PREFETCH) {
+      issued = issue_next(bufs[(S + NS - 1) % NS]);
+      tick(1);
+      sched_fence();   // keep the copy's address arithmetic out of the fragment live ranges
+      gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+      gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
+      gemm_load_frags<TL, PAIR>(bufs[(S + 1) % NS], a_row, w_row, fr, fg, 0, fa0, fw0);
+      gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
+    } else {
+      // Order of a k-step (every sched_fence pins it): first-half fragment reads; the copies of a
+      // later stage (their issue takes hundreds of cycles, the LDS round trip hides under it);
+      // arrival of the first half; second-half reads; first-half MFMAs (second half in flight);
+      // arrival of the second half; second-half MFMAs.  Without the arrival points the compiler
+      // interleaves pairs of reads with pairs of MFMAs and, because it answers LDS-DMA in flight
+      // with s_waitcnt lgkmcnt(0) only, exposes a full LDS round trip four times per k-step.
+      gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
+      sched_fence();
+      issued = issue_next(bufs[(S + NS - 1) % NS]);
+      tick(1);
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < FN; ++j) arrive(fw0[j]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) arrive(fa0[i]);
+      sched_fence();
+      gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+      sched_fence();
+      gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < FN; ++j) arrive(fw1[j]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) arrive(fa1[i]);
+      gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
+    }
     sched_fence();
     // every LDS read above has returned (lgkmcnt) before another wave may refill what it read
+    if (TRACE) { tick_sync(); tick(2); }
     if (issued) dma_lds_wait<INFLIGHT>(); else dma_lds_wait<0>();
+    if (TRACE) { tick(3); tick_sync(); }
     block_barrier();
+    if (TRACE) {
+      tick(4); tick_sync();
+      tsum[0] += tk[1] - tk[0]; tsum[1] += tk[2] - tk[1]; tsum[2] += tk[3] - tk[2]; tsum[3] += tk[4] - tk[3];
+      tk[0] = tk[4];
+    }
   };
 
   int phase = 0;   // stage that holds the current k-step
@@ -394,6 +450,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
     const int mb = m0 + wm * FM * 16 + fr;
     const int nb = n0 + wn * FN * 16;   // first column of this wave
     int kt = 0;
+    if (TRACE) { tick(0); tick_sync(); if (local != slot) tsum[4] += tk[0] - tk[4]; }
     while (kt < nk) {
       switch (phase) {
         case 0:
@@ -446,6 +503,15 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
       const int nl = local + per_xcd;
       gemm_init_acc<TO, EPI, TL>(g, acc, ((start + nl) / tiles_n) * TL::BM + wm * FM * 16 + fr,
                                  ((start + nl) % tiles_n) * TL::BN + wn * FN * 16, fg);
+    }
+  }
+  if (TRACE && g.dbg_times != nullptr) {
+    tick(0); tick_sync();
+    tsum[4] += tk[0] - tk[4];
+    if (lane == 0) {
+      long long* o = g.dbg_times + ((long)blockIdx.x * 16 + wave) * 8;
+      for (int k = 0; k < 5; ++k) o[k] = (long long)tsum[k];
+      o[5] = (long long)(tk[0] - tstart);
     }
   }
 }
@@ -571,6 +637,10 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
     uint4 fa0[FM], fw0[FN], fa1[FM], fw1[FN];
     gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 0, fa0, fw0);
     gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+    // ALL fragment reads of the k-step are issued before its first MFMA: left alone, the scheduler
+    // interleaves pairs of reads with pairs of MFMAs to save registers and the wave then sits
+    // through an LDS round trip (s_waitcnt lgkmcnt(0)) four times per k-step instead of once
+    sched_fence();
     gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
     gemm_mfma_frags<TA, TL>(fa1, fw1, acc);
     lds_barrier();   // reads returned before a producer may refill this stage
@@ -608,7 +678,9 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
 // Tile shapes.  Slots = workgroups per CU (LDS-limited) x 256 CUs.
 enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3,
        GEMM_TILE_192x128_S3 = 4, GEMM_TILE_192x128_WS = 5, GEMM_TILE_192x256 = 6, GEMM_TILE_256x128 = 7,
-       GEMM_TILE_128x128_W8 = 8, GEMM_TILE_192x64_W8 = 9, GEMM_TILE_128x64_W8 = 10, GEMM_TILE_COUNT = 11 };
+       GEMM_TILE_128x128_W8 = 8, GEMM_TILE_192x64_W8 = 9, GEMM_TILE_128x64_W8 = 10,
+       GEMM_TILE_256x128_W16_PF = 11, GEMM_TILE_128x128_W8_PF = 12, GEMM_TILE_256x128_W16 = 13,
+       GEMM_TILE_256x128_W16_S3 = 14, GEMM_TILE_128x128_W8_S3 = 15, GEMM_TILE_COUNT = 16 };
 typedef GemmTile<4, 2, 3, 4, 4> GemmTileBig;     // 192x128, 8 waves, 4 stages = 160 KiB: 1 per CU
 typedef GemmTile<4, 2, 3, 4, 3> GemmTileBig3;    // same, 3 stages = 120 KiB
 typedef GemmTile<2, 2, 4, 4, 2> GemmTileSquare;  // 128x128, 4 waves, 64 KiB: 2 per CU
@@ -618,14 +690,23 @@ typedef GemmTile<4, 2, 4, 4, 3> GemmTileLong;    // 256x128, 8 waves, 3 stages =
 typedef GemmTile<2, 4, 4, 2, 2> GemmTileSquare8; // 128x128, 8 waves (64x32 each), 64 KiB: 2 per CU = 16 waves
 typedef GemmTile<4, 2, 3, 2, 2> GemmTileTall8;   // 192x64, 8 waves (48x32 each), 64 KiB: 2 per CU = 16 waves
 typedef GemmTile<4, 2, 2, 2, 2> GemmTileSmall8;  // 128x64, 8 waves (32x32 each), 48 KiB: 3 per CU = 24 waves
+// sixteen waves in ONE workgroup per CU (4 per SIMD), 3 stages, fragments of step t+1 read during step t
+typedef GemmTile<4, 4, 4, 2, 3, true> GemmTileLong16P;    // 256x128, 144 KiB
+typedef GemmTile<2, 4, 4, 2, 3, true> GemmTileSquare8P;   // 128x128, 8 waves, 96 KiB
+typedef GemmTile<4, 4, 4, 2, 2> GemmTileLong16;           // 256x128, 2 stages = 96 KiB
+typedef GemmTile<4, 4, 4, 2, 3> GemmTileLong16S3;         // 256x128, 3 stages (one in flight across the barrier)
+typedef GemmTile<2, 4, 4, 2, 3> GemmTileSquare8S3;        // 128x128, 8 waves, 3 stages = 96 KiB: 1 per CU
 
-// Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/r01_kbench_gemm.log):
-// narrow outputs with a long K (N <= 1024) run best on 192x64 (512 tiles = one per LDS slot),
-// wide GELU outputs on 128x128 with EIGHT waves (64x32 per wave, two workgroups = 16 waves per
-// CU): every configuration with 8 waves per CU lands within 5 % of the others whatever its tile,
-// stage count or DMA / MFMA role split (192x128 4-stage, wave-specialised, 192x256 with half the
-// LDS fill, ...) -- the k-loop is latency-bound per workgroup, and more resident waves is what
-// moves it.
+// Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/r01_kbench_gemm.log,
+// profiles/r01_gemm_step_trace.txt): every configuration with 16 waves per CU lands within 5 % of
+// the others whatever its tile, stage count or DMA / MFMA role split (192x128 4-stage,
+// wave-specialised, 192x256 with half the LDS fill per flop, 256x128 with 16 waves and 3 stages,
+// fragment prefetch, copies interleaved with the MFMAs ...): the per-wave cycle trace shows a wave
+// spending 17 % of its life in fragment reads + MFMAs and the rest issuing copies, waiting for
+// them or at the barrier -- the k-loop runs at the rate the CU's vector-memory path delivers the
+// operands, and re-arranging the instructions only moves the waiting from one phase to another.
+// Narrow outputs with a long K (N <= 1024) run best on 192x64, wide GELU outputs on 128x128,
+// both with EIGHT waves and two workgroups per CU.
 inline int gemm_pick_tile(int M, int N) {
   if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
   return GEMM_TILE_128x128_W8;
@@ -638,6 +719,16 @@ inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid
   int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid, splits), dim3(TL::THREADS), 0, stream, g);
+}
+
+// the same launch with the per-k-step cycle trace compiled in (debug entry only)
+template <typename TA, typename TO, int EPI, typename TL>
+inline void launch_gemm_tile_traced(const GemmArgs& g, hipStream_t stream, int max_grid) {
+  const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
+  const int per_cu = std::max(1, std::min(3, (160 * 1024) / TL::LDS_BYTES));
+  int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
+  if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
+  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL, true>), dim3(grid), dim3(TL::THREADS), 0, stream, g);
 }
 
 // ---- split-K for few rows (the online model: M = points x 1 frame).  With M = 256 a mixer GEMM is
@@ -695,6 +786,17 @@ inline void launch_gemm_splitk(const GemmArgs& g, int splits, float* part, hipSt
 }
 
 template <typename TA, typename TO, int EPI>
+inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, int max_grid) {
+  if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N);
+  switch (tile) {
+    case GEMM_TILE_192x128: launch_gemm_tile_traced<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
+    case GEMM_TILE_192x64: launch_gemm_tile_traced<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
+    case GEMM_TILE_192x256: launch_gemm_tile_traced<TA, TO, EPI, GemmTileWide>(g, stream, max_grid); break;
+    default: launch_gemm_tile_traced<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
+  }
+}
+
+template <typename TA, typename TO, int EPI>
 inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_TILE_AUTO,
                         int max_grid = 0) {
   if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N);
@@ -707,6 +809,11 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
     case GEMM_TILE_128x128_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
     case GEMM_TILE_192x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileTall8>(g, stream, max_grid); break;
     case GEMM_TILE_128x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSmall8>(g, stream, max_grid); break;
+    case GEMM_TILE_256x128_W16_PF: launch_gemm_tile<TA, TO, EPI, GemmTileLong16P>(g, stream, max_grid); break;
+    case GEMM_TILE_128x128_W8_PF: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8P>(g, stream, max_grid); break;
+    case GEMM_TILE_256x128_W16: launch_gemm_tile<TA, TO, EPI, GemmTileLong16>(g, stream, max_grid); break;
+    case GEMM_TILE_256x128_W16_S3: launch_gemm_tile<TA, TO, EPI, GemmTileLong16S3>(g, stream, max_grid); break;
+    case GEMM_TILE_128x128_W8_S3: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8S3>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_WS: {   // 8 consumer + 4 producer waves, 4 stages, one workgroup per CU
       using TL = GemmTileBig;
       const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);

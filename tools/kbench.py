@@ -25,7 +25,7 @@ import torch
 
 from tapnet_amd import _ffi, synthetic, tapir_model
 
-TILES = {1: '192x128s4', 2: '128x128', 3: '192x64', 4: '192x128s3', 5: '192x128ws', 6: '192x256', 7: '256x128s3', 8: '128x128w8', 9: '192x64w8', 10: '128x64w8'}
+TILES = {1: '192x128s4', 2: '128x128', 3: '192x64', 4: '192x128s3', 5: '192x128ws', 6: '192x256', 7: '256x128s3', 8: '128x128w8', 9: '192x64w8', 10: '128x64w8', 11: '256x128w16pf', 12: '128x128w8pf', 13: '256x128w16', 14: '256x128w16s3', 15: '128x128w8s3'}
 R = 256 * 48
 
 
@@ -203,6 +203,51 @@ def trace_gemm(model):
       print(f'  {labels[k]:32s} median {np.median(d[:, k]):6.2f} us   p90 {np.percentile(d[:, k], 90):6.2f}')
 
 
+def trace_gemm_steps(model):
+  """where a k-step goes: per-wave shader-cycle totals (s_memtime) of copy issue / fragment reads +
+  MFMAs / wait for own copies / barrier / epilogue, from the TRACE build of gemm_nt_kernel"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  tdt = torch.bfloat16
+  for name, M, N, K, epi, tile in (('up', R, 2048, 512, 1, 8), ('up', R, 2048, 512, 1, 6), ('up', R, 2048, 512, 1, 1),
+                                   ('down', R, 512, 2048, 2, 3), ('down', R, 512, 2048, 2, 8), ('down', R, 512, 2048, 2, 1)):
+    A = torch.randn(M, K, device=dev).to(tdt); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(tdt)
+    bias = torch.randn(N, device=dev); resid = torch.randn(M, N, device=dev)
+    C = torch.empty(M, N, device=dev, dtype=tdt if epi == 1 else torch.float32)
+    tr = torch.zeros(768 * 16, 8, dtype=torch.int64, device=dev)
+    lib.tapir_debug_set_trace(ctx, tr.data_ptr())
+    def run(flag):
+      rc = lib.tapir_debug_gemm(ctx, A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N,
+                                C.data_ptr(), N, M, N, K, epi, tile | flag, model._stream())
+      assert rc == 0, lib.tapir_last_error(ctx)
+    for _ in range(3):
+      run(1 << 20)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tr.zero_()
+    e0.record(); run(1 << 20); e1.record(); torch.cuda.synchronize()
+    traced_us = e0.elapsed_time(e1) * 1e3
+    lib.tapir_debug_set_trace(ctx, None)
+    for _ in range(3):
+      run(0)
+    e0.record()
+    for _ in range(10):
+      run(0)
+    e1.record(); torch.cuda.synchronize()
+    plain_us = e0.elapsed_time(e1) * 1e2
+    t = tr.cpu().numpy().astype(np.float64)
+    t = t[t[:, 5] > 0]
+    tot = t[:, 5]
+    mhz = np.median(tot) / traced_us   # cycles per us of the traced run, if s_memtime counts shader cycles
+    print(f'gemm {name} tile {TILES[tile]}: plain {plain_us:.1f} us, traced {traced_us:.1f} us, {t.shape[0]} waves, '
+          f'median wave lifetime {np.median(tot):.0f} cycles (~{mhz:.0f} MHz if it spans the launch)')
+    for k, lab in enumerate(['copy issue', 'frag reads + MFMA', 'wait own copies (vmcnt)', 'barrier', 'epilogue + next acc init']):
+      print(f'  {lab:28s} median {np.median(t[:, k]):9.0f} cyc  {100 * np.median(t[:, k] / tot):5.1f} %   '
+            f'p10 {100 * np.percentile(t[:, k] / tot, 10):5.1f} %  p90 {100 * np.percentile(t[:, k] / tot, 90):5.1f} %')
+    rest = tot - t[:, :5].sum(axis=1)
+    print(f'  {"prologue / other":28s} median {np.median(rest):9.0f} cyc  {100 * np.median(rest / tot):5.1f} %')
+
+
 def bench_mixer(model, reps, results):
   """whole PIPSMLPMixer (12 blocks) on 256 x 48 tokens through the public C ABI"""
   lib, ctx = model._lib, model._ctx
@@ -262,6 +307,8 @@ def main():
       bench_mix(model, args.reps, results)
     if 'gemmtrace' in what:
       trace_gemm(model)
+    if 'gemmsteps' in what:
+      trace_gemm_steps(model)
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
