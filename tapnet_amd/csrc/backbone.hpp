@@ -97,16 +97,7 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_stats_kernel(NormStatsArgs
 #pragma unroll
   for (int e = 0; e < EPT; ++e) { K[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
   int cnt = 0;
-  for (int p = p0 + pl; p < p1; p += PP) {
-    float v[EPT];
-    Vec16<T>::load(pa + (long)p * a.C, v);
-    if (pb != nullptr) {
-      float w[EPT];
-      Vec16<T>::load(pb + (long)p * a.C, w);
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) v[e] = Vec16<T>::round(v[e] + w[e]);
-      Vec16<T>::store(po + (long)p * a.C, v);
-    }
+  auto accumulate = [&](float (&v)[EPT]) {
     if (cnt == 0) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) K[e] = v[e];
@@ -118,6 +109,40 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_stats_kernel(NormStatsArgs
       s2[e] = fmaf(d, d, s2[e]);
     }
     ++cnt;
+  };
+  // four pixels per thread and trip: four (eight with the residual operand) independent 16-byte
+  // loads in flight per thread -- one load per trip leaves HBM latency exposed (4 KiB per workgroup)
+  constexpr int U = 4;
+  int p = p0 + pl;
+  for (; p + (U - 1) * PP < p1; p += U * PP) {
+    float v[U][EPT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) Vec16<T>::load(pa + (long)(p + u * PP) * a.C, v[u]);
+    if (pb != nullptr) {
+      float w[U][EPT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) Vec16<T>::load(pb + (long)(p + u * PP) * a.C, w[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[u][e] = Vec16<T>::round(v[u][e] + w[u][e]);
+        Vec16<T>::store(po + (long)(p + u * PP) * a.C, v[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) accumulate(v[u]);
+  }
+  for (; p < p1; p += PP) {
+    float v[EPT];
+    Vec16<T>::load(pa + (long)p * a.C, v);
+    if (pb != nullptr) {
+      float w[EPT];
+      Vec16<T>::load(pb + (long)p * a.C, w);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) v[e] = Vec16<T>::round(v[e] + w[e]);
+      Vec16<T>::store(po + (long)p * a.C, v);
+    }
+    accumulate(v);
   }
   const float fc = (float)cnt;
   const float inv = cnt > 0 ? 1.0f / fc : 0.f;
@@ -128,25 +153,28 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_stats_kernel(NormStatsArgs
   }
   s_cnt[tid] = fc;
   __syncthreads();
-  // threads pl == 0 merge the PP summaries of their channel group
-  if (pl == 0) {
-    float cn = s_cnt[cg], mean[EPT], m2[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) { mean[e] = s_mean[cg][e]; m2[e] = s_m2[cg][e]; }
-    for (int k = 1; k < PP; ++k) {
-      const int o = k * G + cg;
+  // tree merge over the PP pixel lanes of each channel group (PP is a power of two): in round
+  // `half` the lanes pl < half fold in the summary of lane pl + half
+  for (int half = PP >> 1; half >= 1; half >>= 1) {
+    if (pl < half) {
+      const int o = tid + half * G;
       const float nb = s_cnt[o];
-      float ncur = cn;
+      float ncur = s_cnt[tid];
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        ncur = cn;
-        merge_stats(ncur, mean[e], m2[e], nb, s_mean[o][e], s_m2[o][e]);
+        ncur = s_cnt[tid];
+        float mean = s_mean[tid][e], m2 = s_m2[tid][e];
+        merge_stats(ncur, mean, m2, nb, s_mean[o][e], s_m2[o][e]);
+        s_mean[tid][e] = mean; s_m2[tid][e] = m2;
       }
-      cn = ncur;
+      s_cnt[tid] = ncur;
     }
+    __syncthreads();
+  }
+  if (pl == 0) {
     float* out = a.part + (((long)n * a.slabs + blockIdx.x) * a.C + cg * EPT) * 2;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) { out[2 * e] = mean[e]; out[2 * e + 1] = m2[e]; }
+    for (int e = 0; e < EPT; ++e) { out[2 * e] = s_mean[cg][e]; out[2 * e + 1] = s_m2[cg][e]; }
   }
 }
 
@@ -220,15 +248,27 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_relu_kernel(NormApplyArgs 
   T* py = reinterpret_cast<T*>(a.y) + (long)n * a.oh * a.ow * a.C + cg * EPT;
   T* ps = a.y_sub ? reinterpret_cast<T*>(a.y_sub) + (long)n * (a.H / 2) * (a.W / 2) * a.C + cg * EPT
                   : nullptr;
-  for (int p = p0 + pl; p < p1; p += PP) {
-    float v[EPT];
-    Vec16<T>::load(px + (long)p * a.C, v);
+  auto emit = [&](int p, float (&v)[EPT]) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) v[e] = fmaxf(fmaf(v[e], scale[e], shift[e]), 0.f);
     const int h = p / a.W, w = p - h * a.W;
     Vec16<T>::store(py + ((long)h * a.ow + w) * a.C, v);
     if (ps != nullptr && !(h & 1) && !(w & 1))
       Vec16<T>::store(ps + ((long)(h >> 1) * (a.W / 2) + (w >> 1)) * a.C, v);
+  };
+  constexpr int U = 4;   // independent loads in flight per thread
+  int p = p0 + pl;
+  for (; p + (U - 1) * PP < p1; p += U * PP) {
+    float v[U][EPT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) Vec16<T>::load(px + (long)(p + u * PP) * a.C, v[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) emit(p + u * PP, v[u]);
+  }
+  for (; p < p1; p += PP) {
+    float v[EPT];
+    Vec16<T>::load(px + (long)p * a.C, v);
+    emit(p, v);
   }
 }
 

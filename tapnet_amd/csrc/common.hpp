@@ -165,6 +165,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 #endif
 }
+// K independent wave sums, step by step side by side: a single DPP butterfly is a chain of seven
+// dependent instructions (with their DPP / readlane wait states); K rows interleaved fill them.
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+#ifdef TAPIR_HIPEMU
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], m);
+#else
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0xB1, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x4E, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x141, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x140, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x142, 0xa>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x143, 0xc>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #ifdef TAPIR_HIPEMU
   v = fmaxf(v, __shfl_xor(v, 32));

@@ -51,6 +51,28 @@ __device__ __forceinline__ void wave_row_stats(const float4& u, const float4& v,
   rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kHidden) + kLnEps);
 }
 
+// The same for K rows at once (independent reductions interleaved).
+template <int K>
+__device__ __forceinline__ void wave_row_stats_n(const float4 (&u)[K], const float4 (&v)[K],
+                                                 float (&mean)[K], float (&rstd)[K]) {
+  float s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    s[k] = (u[k].x + u[k].y) + (u[k].z + u[k].w) + (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  wave_sum_n<K>(s);
+  float q[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    mean[k] = s[k] * (1.0f / kHidden);
+    const float d0 = u[k].x - mean[k], d1 = u[k].y - mean[k], d2 = u[k].z - mean[k], d3 = u[k].w - mean[k];
+    const float d4 = v[k].x - mean[k], d5 = v[k].y - mean[k], d6 = v[k].z - mean[k], d7 = v[k].w - mean[k];
+    q[k] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + (d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7);
+  }
+  wave_sum_n<K>(q);
+#pragma unroll
+  for (int k = 0; k < K; ++k) rstd[k] = 1.0f / sqrtf(q[k] * (1.0f / kHidden) + kLnEps);
+}
+
 // One workgroup = one track x one time chunk.  The chunk's input rows (with
 // halo) are staged in LDS by one fully parallel, coalesced pass, so that no
 // step of the temporal recurrence waits on global memory:
@@ -269,14 +291,17 @@ struct MixUnit {
   }
 };
 
-template <typename TO, int TC>
+// DB = true: persistent workgroups with two row buffers (64 KiB: two workgroups = 8 waves per CU);
+// DB = false: one unit per workgroup, one row buffer (32 KiB: four workgroups = 16 waves per CU,
+// the loads of one workgroup overlap the arithmetic of the others).
+template <typename TO, int TC, bool DB = true>
 __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int units, int nch) {
   constexpr int ROWS = TC + 4;
   // two separate objects: reads of one buffer must not wait for the DMA into the other
   __shared__ float s_xa[ROWS][kHidden];
-  __shared__ float s_xb[ROWS][kHidden];
+  __shared__ float s_xb[DB ? ROWS : 1][DB ? kHidden : 2];
   __shared__ float2 s_stata[ROWS];   // (mean, rstd) of LayerNorm-1
-  __shared__ float2 s_statb[ROWS];
+  __shared__ float2 s_statb[DB ? ROWS : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -329,13 +354,24 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int 
   auto process = [&](const MixUnit<TC>& q, float (*s_x)[kHidden], float2* s_stat, int unit) {
     const int t0 = q.t0;
     stamp(unit, 2);
-    // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ...
-    for (int r = q.rlo + wave; r <= q.rhi; r += 4) {
-      const float4 u4 = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
-      const float4 v4 = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
-      float mean, rstd;
-      wave_row_stats(u4, v4, mean, rstd);
-      if (lane == 0) s_stat[r] = make_float2(mean, rstd);
+    // ---- phase 1: LayerNorm-1 statistics, wave w takes rows w, w+4, ... -- all of them at once
+    // (a row past the end repeats the last one and is not written)
+    {
+      constexpr int K1 = (ROWS + 3) / 4;
+      float4 u4[K1], v4[K1];
+      float mean[K1], rstd[K1];
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const int r = min(q.rlo + wave + 4 * k, q.rhi);
+        u4[k] = *reinterpret_cast<const float4*>(&s_x[r][lane * 4]);
+        v4[k] = *reinterpret_cast<const float4*>(&s_x[r][256 + lane * 4]);
+      }
+      wave_row_stats_n<K1>(u4, v4, mean, rstd);
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const int r = q.rlo + wave + 4 * k;
+        if (lane == 0 && r <= q.rhi) s_stat[r] = make_float2(mean[k], rstd[k]);
+      }
     }
     lds_barrier();
     stamp(unit, 3);
@@ -391,33 +427,53 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int 
     lds_barrier();
     stamp(unit, 4);
 
-    // ---- phase 3: LayerNorm-2 and stores, wave w takes output frames t0+w, t0+w+4, ...
+    // ---- phase 3: LayerNorm-2 and stores, wave w takes output frames t0+w, t0+w+4, ... at once
     const int t1 = min(T, t0 + TC);
-    for (int t = t0 + wave; t < t1; t += 4) {
-      const float4 u4 = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][lane * 4]);
-      const float4 v4 = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][256 + lane * 4]);
-      float mean, rs;
-      wave_row_stats(u4, v4, mean, rs);
-      const long row = (long)q.n * T + t;
-      float* xo = a.x_out + row * kHidden;
-      *reinterpret_cast<float4*>(xo + lane * 4) = u4;
-      *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v4;
-      TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
-      Store4<TO>::run(o + lane * 4, (u4.x - mean) * rs * s2a.x, (u4.y - mean) * rs * s2a.y,
-                      (u4.z - mean) * rs * s2a.z, (u4.w - mean) * rs * s2a.w);
-      Store4<TO>::run(o + 256 + lane * 4, (v4.x - mean) * rs * s2b.x, (v4.y - mean) * rs * s2b.y,
-                      (v4.z - mean) * rs * s2b.z, (v4.w - mean) * rs * s2b.w);
+    {
+      constexpr int K3 = (TC + 3) / 4;
+      float4 u4[K3], v4[K3];
+      float mean[K3], rs[K3];
+#pragma unroll
+      for (int k = 0; k < K3; ++k) {
+        const int t = min(t0 + wave + 4 * k, t1 - 1);
+        u4[k] = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][lane * 4]);
+        v4[k] = *reinterpret_cast<const float4*>(&s_x[t - t0 + 2][256 + lane * 4]);
+      }
+      wave_row_stats_n<K3>(u4, v4, mean, rs);
+#pragma unroll
+      for (int k = 0; k < K3; ++k) {
+        const int t = t0 + wave + 4 * k;
+        if (t < t1) {
+          const long row = (long)q.n * T + t;
+          float* xo = a.x_out + row * kHidden;
+          *reinterpret_cast<float4*>(xo + lane * 4) = u4[k];
+          *reinterpret_cast<float4*>(xo + 256 + lane * 4) = v4[k];
+          TO* o = reinterpret_cast<TO*>(a.xn2) + row * kHidden;
+          Store4<TO>::run(o + lane * 4, (u4[k].x - mean[k]) * rs[k] * s2a.x, (u4[k].y - mean[k]) * rs[k] * s2a.y,
+                          (u4[k].z - mean[k]) * rs[k] * s2a.z, (u4[k].w - mean[k]) * rs[k] * s2a.w);
+          Store4<TO>::run(o + 256 + lane * 4, (v4[k].x - mean[k]) * rs[k] * s2b.x, (v4[k].y - mean[k]) * rs[k] * s2b.y,
+                          (v4[k].z - mean[k]) * rs[k] * s2b.z, (v4[k].w - mean[k]) * rs[k] * s2b.w);
+        }
+      }
     }
     stamp(unit, 5);
   };
 
+  if (!DB) {
+    dma_lds_wait<0>();
+    block_barrier();
+    stamp(u, 1);
+    process(cur, s_xa, s_stata, u);
+    return;
+  }
+  auto s_xb2 = reinterpret_cast<float (*)[kHidden]>(&s_xb[0][0]);
   for (;;) {
     // the rows of `cur` have landed in buffer a (and the stores of the previous unit are done)
     dma_lds_wait<0>();
     block_barrier();
     stamp(u, 1);
     int un = u + gridDim.x;
-    if (un < units) { nxt.set(un, nch, T); stage(nxt, s_xb, s_statb); stamp(un, 0); }
+    if (un < units) { nxt.set(un, nch, T); stage(nxt, s_xb2, s_statb); stamp(un, 0); }
     process(cur, s_xa, s_stata, u);
     if (un >= units) break;
     u = un; cur = nxt;
@@ -426,7 +482,7 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int 
     stamp(u, 1);
     un = u + gridDim.x;
     if (un < units) { nxt.set(un, nch, T); stage(nxt, s_xa, s_stata); stamp(un, 0); }
-    process(cur, s_xb, s_statb, u);
+    process(cur, s_xb2, s_statb, u);
     if (un >= units) break;
     u = un; cur = nxt;
   }
@@ -439,10 +495,19 @@ inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc =
   MixArgs m = m_in;
   const bool plain = !m.causal && !m.ctx1_in && !m.ctx2_in && !m.ctx1_out && !m.ctx2_out;
   if (plain && m.T >= 12) {
-    // 12-frame chunks, two row buffers (64 KiB): two persistent workgroups per CU
+    // 12-frame chunks
     const int nch = (m.T + 11) / 12;
     const int units = N * nch;
-    const int grid = force_tc > 0 ? std::min(units, force_tc) : std::min(units, 512);
+    // Default: ONE unit per workgroup with a single row buffer (32 KiB -> four workgroups = 16 waves
+    // per CU).  Measured at config 2 (tools/kbench.py --what mix): 28.3 us against 31.6 us for the
+    // persistent double-buffered form (force_tc = grid cap, two workgroups = 8 waves per CU): the
+    // kernel is VALU-latency bound and the extra resident waves are worth more than the overlap of a
+    // workgroup's own loads with its arithmetic; chunk lengths 8 / 12 / 16 measure the same.
+    if (force_tc <= 0) {
+      hipLaunchKernelGGL((mix_stream_kernel<TO, 12, false>), dim3(units), dim3(MIX_THREADS), 0, s, m, units, nch);
+      return;
+    }
+    const int grid = std::min(units, force_tc);
     hipLaunchKernelGGL((mix_stream_kernel<TO, 12>), dim3(grid), dim3(MIX_THREADS), 0, s, m, units, nch);
     return;
   }

@@ -60,6 +60,14 @@ class OnlineTracker:
     m = self.model
     fg = m.get_feature_grids(m._dev(frames))
     qf = m.get_query_features(m._dev(frames), False, m._dev(query_points), fg)
+    return self.set_query_features(qf)
+
+  def set_query_features(self, qf: QueryFeatures) -> QueryFeatures:
+    """Track the points whose query features are `qf` (e.g. extracted from other frames or other
+    videos, tapir_clustering.py:1133-1140) from a zero causal state."""
+    m = self.model
+    qf = QueryFeatures(tuple(m._dev(t) for t in qf.lowres), tuple(m._dev(t) for t in qf.hires),
+                       qf.resolutions)
     if qf.lowres[0].shape[1] != self.n:
       raise ValueError(f'expected {self.n} query points')
     if self._qf is None:

@@ -306,3 +306,50 @@ def test_batch_of_clips_equals_per_clip_runs(config2):
     one = m(v[b:b + 1], False, q[b:b + 1])
     np.testing.assert_allclose(both['tracks'][b], one['tracks'][0], atol=2e-3)
     np.testing.assert_allclose(both['occlusion'][b], one['occlusion'][0], atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_track_many_points_matches_per_frame_api_loop():
+  """tapnet_amd.bulk_tracking.track_many_points (robotap/tapir_clustering.py:1029-1179: batched query
+  extraction + hipGraph-replayed online sessions) against the reference's own schedule written with
+  the public API: one init call per sampled frame, one estimate_trajectories call per frame."""
+  from tapnet_amd import bulk_tracking as bt, tapir_model
+  S = 64
+  w = synthetic.make_weights(21, pyramid_level=1, extra_convs=False)
+  m = tapir_model.TAPIR(pyramid_level=1, use_causal_conv=True, weights=w, device='cuda:0',
+                        initial_resolution=(S, S))
+  rng = np.random.default_rng(3)
+  videos = {7: ((synthetic.make_video(8, 5, S, S)[0] + 1) * 127.5).astype(np.uint8),
+            9: ((synthetic.make_video(9, 3, S, S)[0] + 1) * 127.5).astype(np.uint8)}
+  ids = [7, 9]
+  out = bt.track_many_points(videos, ids, m, frame_stride=2, points_per_frame=4, point_batch_size=8)
+  # 3 + 2 sampled frames x 4 points = 20 points -> batches 8, 8, 4 (+4 padded)
+  assert out['separation_tracks'][7].shape == (20, 5, 2) and out['separation_tracks'][9].shape == (20, 3, 2)
+  # reference schedule
+  samples = bt.sample_query_points([videos[k].shape for k in ids], 2, 4)
+  feats = []
+  for v, i, yx in samples:
+    frame = torch.as_tensor(bt.preprocess_frames(videos[ids[v]][None, None, i])).cuda()
+    qp = torch.as_tensor(np.concatenate([np.zeros((4, 1)), yx], axis=1)[None], dtype=torch.float32).cuda()
+    fg = m.get_feature_grids(frame)
+    qf = m.get_query_features(frame, False, qp, fg)
+    feats.append(tapir_model.QueryFeatures(tuple(t.clone() for t in qf.lowres), tuple(t.clone() for t in qf.hires),
+                                           qf.resolutions))
+  allf = bt.query_features_join(feats)
+  for a, b in zip(allf.lowres + allf.hires, out['query_features'].lowres + out['query_features'].hires):
+    np.testing.assert_allclose(a.cpu().numpy(), b, atol=2e-4, rtol=0)
+  for lo in (0, 8, 16):
+    hi = min(lo + 8, 20)
+    qf = bt.query_features_slice(allf, lo, hi)
+    for k in ids:
+      state = m.construct_initial_causal_state(hi - lo, len(qf.resolutions) - 1)
+      for t in range(videos[k].shape[0]):
+        frame = torch.as_tensor(bt.preprocess_frames(videos[k][None, None, t])).cuda()
+        traj = m.estimate_trajectories((S, S), False, m.get_feature_grids(frame), qf, None,
+                                       causal_context=state, get_causal_context=True)
+        state = traj['causal_context']
+        trk, vis = bt.predictions_to_tracks_visibility({n: traj[n][-1] for n in ('tracks', 'occlusion', 'expected_dist')})
+        np.testing.assert_allclose(out['separation_tracks'][k][lo:hi, t], trk.cpu().numpy(), atol=2e-3, rtol=0)
+        margin = (vis - 0.5).abs().cpu().numpy() > 1e-3
+        np.testing.assert_array_equal(out['separation_visibility'][k][lo:hi, t][margin],
+                                      (vis > 0.5).cpu().numpy()[margin])

@@ -128,7 +128,7 @@ def bench_mix(model, reps, results):
   xo = [torch.empty(N, T, 512, device=dev) for _ in range(3)]
   xn = [torch.empty(N * T, 512, device=dev, dtype=torch.bfloat16 if bf else torch.float32) for _ in range(3)]
 
-  for tc in (0, 256, 1024):
+  for tc in (0, 512, 1024):
    def run(i, tc=tc):
     k = i % 3
     rc = lib.tapir_debug_mix(ctx, 0, x[k].data_ptr(), xo[k].data_ptr(), xn[k].data_ptr(), N, T, tc, stream)
