@@ -372,7 +372,7 @@ int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const 
   pa.B = B; pa.Q = Q; pa.T = T;
   pa.orig_h = (float)orig_h; pa.orig_w = (float)orig_w;
   { ProfScope ps(c, TAPIR_PROF_PATCH, s);
-    hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3((unsigned)R), dim3(256), 0, s, pa); }
+    hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3(patch_corr_grid(B, Q, T)), dim3(256), 0, s, pa); }
   return TAPIR_OK;
 }
 

@@ -40,10 +40,10 @@ struct PatchArgs {
 // 8x8 window of dot products for one level; returns the 7x7 blended value for
 // lane (i=lane>>3, j=lane&7) (garbage for i==7 or j==7).
 //
-// Lane (i = lane >> 3, cs = lane & 7) owns window row i and the channel slice
-// [cs*C/8, (cs+1)*C/8): for each of the 8 cells of its row it accumulates the partial dot
-// product over its slice (the 8 lanes of a row read one cell's C*sizeof(TG) contiguous bytes,
-// 16 B per load), then a transposed butterfly over the 3 low lane bits (7 shuffles) leaves the
+// Lane (i = lane >> 3, cs = lane & 7) owns window row i and an eighth of the channels (16-byte
+// chunks cs, 8 + cs, ...): for each of the 8 cells of its row it accumulates the partial dot
+// product over its channels (the 8 lanes of a row read 128 contiguous bytes of the cell per load
+// instruction), then a transposed butterfly over the 3 low lane bits (7 shuffles) leaves the
 // full dot product of cell (i, j) in lane i*8 + j.  (The first version gave every lane 4
 // channels of all 64 cells: 63 shuffles per level.)
 template <int C, typename TG>
@@ -59,16 +59,22 @@ __device__ __forceinline__ float level_corr(const PyrLevel& L, const float* __re
   const float fx = gx - fx0, fy = gy - fy0;
   const int x0 = (int)fx0 - 3, y0 = (int)fy0 - 3;   // window origin (offset -3)
   const int i = lane >> 3, cs = lane & 7;
+  // channel slice of lane cs, INTERLEAVED in 16-byte chunks: chunk m of the lane = channels
+  // [(m*8 + cs) * EPL, +EPL), so that the 8 lanes of a window row read 128 CONTIGUOUS bytes per load
+  // instruction (one cache line per row; a contiguous slice per lane would touch 2-4 lines per row
+  // and instruction and use a quarter of each)
   float qv[SL];
 #pragma unroll
-  for (int k = 0; k < SL; k += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(qsrc + cs * SL + k);
-    qv[k] = t.x; qv[k + 1] = t.y; qv[k + 2] = t.z; qv[k + 3] = t.w;
-  }
+  for (int m = 0; m < SL / EPL; ++m)
+#pragma unroll
+    for (int u = 0; u < EPL; u += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(qsrc + (m * 8 + cs) * EPL + u);
+      qv[m * EPL + u] = t.x; qv[m * EPL + u + 1] = t.y; qv[m * EPL + u + 2] = t.z; qv[m * EPL + u + 3] = t.w;
+    }
   const int y = y0 + i;
   const bool vy = (y >= 0) && (y < L.h);
   const int yc = min(max(y, 0), L.h - 1);
-  const TG* rowp = reinterpret_cast<const TG*>(L.grid) + (frame * L.h + yc) * ((long)L.w * C) + cs * SL;
+  const TG* rowp = reinterpret_cast<const TG*>(L.grid) + (frame * L.h + yc) * ((long)L.w * C) + cs * EPL;
   float part[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -80,7 +86,7 @@ __device__ __forceinline__ float level_corr(const PyrLevel& L, const float* __re
 #pragma unroll
     for (int k = 0; k < SL; k += EPL) {
       float e[EPL];
-      Vec16<TG>::load(p + k, e);
+      Vec16<TG>::load(p + k * 8, e);   // chunk m = k / EPL sits (m * 8 + cs) * EPL channels in
 #pragma unroll
       for (int u = 0; u < EPL; ++u) d = fmaf(e[u], qv[k + u], d);
     }
@@ -106,11 +112,42 @@ __device__ __forceinline__ float level_corr(const PyrLevel& L, const float* __re
   return d00 * (wy0 * wx0) + d01 * (wy0 * fx) + d10 * (fy * wx0) + d11 * (fy * fx);
 }
 
+// One WAVE per token (b, q, t): it writes the token's mixer-input row (header, features, zero
+// tail) and the 7x7 correlations of every pyramid level.  Waves never synchronise, so a 256-thread
+// workgroup is just four independent tokens: 32 tokens in flight per CU.  (The first version gave a
+// token a whole workgroup with one wave per level and two idle ones: 8 tokens in flight per CU and
+// six dispatch rounds of dependent memory round trips -- position -> window addresses -> grid.)
+//
+// Wave -> token.  Workgroups are dealt to the 8 XCDs round robin, each XCD has its own 4 MiB L2 and
+// a frame's two grids are 1.5 MiB (bf16, config 2).  When the frame count divides by 8, XCD x owns
+// the frames fr = x (mod 8) and walks them one at a time, all queries of a frame back to back, so
+// a frame's grids are fetched into that L2 once; otherwise tokens are taken in memory order.
+constexpr int PATCH_TOKENS_PER_WG = 4;
+inline unsigned patch_corr_grid(long B, long Q, long T) {
+  const long frames = B * T;
+  if ((frames & 7) == 0) {
+    const long per_xcd = Q * (frames / 8);                                        // tokens of one XCD
+    return (unsigned)(8 * ((per_xcd + PATCH_TOKENS_PER_WG - 1) / PATCH_TOKENS_PER_WG));
+  }
+  return (unsigned)((B * Q * T + PATCH_TOKENS_PER_WG - 1) / PATCH_TOKENS_PER_WG);
+}
+
 template <typename TG, typename TO>
 __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
-  const long r = blockIdx.x;                 // token (b, q, t)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const long frames = (long)a.B * a.T;
+  long r;
+  if ((frames & 7) == 0) {
+    const long x = blockIdx.x & 7, s = (long)(blockIdx.x >> 3) * PATCH_TOKENS_PER_WG + wave;
+    if (s >= (long)a.Q * (frames >> 3)) return;
+    const long fr = (s / a.Q) * 8 + x, q = s % a.Q;
+    const long fb = fr / a.T, ft = fr - fb * a.T;
+    r = (fb * a.Q + q) * a.T + ft;
+  } else {
+    r = (long)blockIdx.x * PATCH_TOKENS_PER_WG + wave;
+    if (r >= frames * a.Q) return;
+  }
   const int t = (int)(r % a.T);
   const long bq = r / a.T;
   const int b = (int)(bq / a.Q);
@@ -118,7 +155,7 @@ __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
 
   // header + features + zero padding of the K tail
   const int ncorr0 = kMixOut;
-  for (int c = tid; c < a.ld; c += 256) {
+  for (int c = lane; c < a.ld; c += 64) {
     float v;
     if (c < 2) v = 0.f;                       // position channels are always zero (:583)
     else if (c == 2) v = a.occ[r];
@@ -133,17 +170,18 @@ __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
     Elem<TO>::st(out + c, v);
   }
 
-  if (wave >= a.n_levels) return;
-  const PyrLevel& L = a.lvl[wave];
   const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
   const long frame = (long)b * a.T + t;
-  // the query vector of this level: the refined per-token feature, or the (tiled) query feature
-  const float* qsrc = (a.feats != nullptr) ? a.feats + r * kFeatDim + L.feat_off : L.query + bq * L.C;
-  float corr;
-  if (L.C == 256) corr = level_corr<256, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
-  else corr = level_corr<128, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
   const int i = lane >> 3, j = lane & 7;
-  if (i < 7 && j < 7) Elem<TO>::st(out + ncorr0 + kPatch * wave + i * 7 + j, corr);
+  for (int l = 0; l < a.n_levels; ++l) {
+    const PyrLevel& L = a.lvl[l];
+    // the query vector of this level: the refined per-token feature, or the (tiled) query feature
+    const float* qsrc = (a.feats != nullptr) ? a.feats + r * kFeatDim + L.feat_off : L.query + bq * L.C;
+    float corr;
+    if (L.C == 256) corr = level_corr<256, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
+    else corr = level_corr<128, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
+    if (i < 7 && j < 7) Elem<TO>::st(out + ncorr0 + kPatch * l + i * 7 + j, corr);
+  }
 }
 
 // ---- query features: trilinear sample with index clamping

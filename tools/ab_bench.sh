@@ -11,7 +11,7 @@ import sys, json
 d = json.loads(sys.stdin.read())
 k = d['kernels']
 print('$v round $round: ms/step', d['ms_per_step'], 'hot', d['hot_path_ms'], 'bb', d['backbone_ms'],
-      'up', k['gemm_up']['avg_us'], 'down', k['gemm_down']['avg_us'], 'mix', k['mix']['avg_us'])"
+      'up', k['gemm_up']['avg_us'], 'down', k['gemm_down']['avg_us'], 'mix', k['mix']['avg_us'], 'patch', k['patch_corr']['avg_us'], 'cvh', k['cv_heads']['avg_us'])"
   done
 done
 cp /tmp/libtapir_saved.so tapnet_amd/csrc/libtapir_hip.so

@@ -248,6 +248,37 @@ def trace_gemm_steps(model):
     print(f'  {"prologue / other":28s} median {np.median(rest):9.0f} cyc  {100 * np.median(rest / tot):5.1f} %')
 
 
+def bench_norm(model, reps, results):
+  """backbone glue kernels (HBM-bound): InstanceNorm statistics (with / without the fused residual add)
+  and normalise + ReLU at the ResNet's activation shapes, over slab counts"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  for (n, h, w, c) in ((48, 128, 128, 64), (48, 64, 64, 128), (48, 32, 32, 256)):
+    x = [torch.randn(n, h, w, c, device=dev).to(torch.bfloat16) for _ in range(3)]
+    b = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+    y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    gamma = torch.ones(c, device=dev); beta = torch.zeros(c, device=dev)
+    nbytes = n * h * w * c * 2
+    for slabs in (11, 22, 43, 64, 128):
+      if slabs > h * w // 64:
+        continue
+      part = torch.empty(n, slabs, c, 2, device=dev)
+      def stats(i):
+        assert lib.tapir_inorm_stats(ctx, x[i % 3].data_ptr(), None, None, part.data_ptr(), n, h * w, c, slabs, stream) == 0
+      def stats_add(i):
+        assert lib.tapir_inorm_stats(ctx, x[i % 3].data_ptr(), b.data_ptr(), x[i % 3].data_ptr(), part.data_ptr(), n, h * w, c, slabs, stream) == 0
+      def relu(i):
+        assert lib.tapir_inorm_relu(ctx, x[i % 3].data_ptr(), part.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    y.data_ptr(), None, n, h, w, c, slabs, h, w, stream) == 0
+      for name, fn, passes in (('inorm_stats', stats, 1), ('inorm_stats_add', stats_add, 3), ('inorm_relu(+finalize)', relu, 2)):
+        t = timeit(fn, reps)
+        row = dict(kernel=name, shape=[n, h, w, c], slabs=slabs, **t,
+                   GBps=round(passes * nbytes / (t['med_us'] * 1e-6) / 1e9, 1))
+        results.append(row)
+        print(json.dumps(row), flush=True)
+
+
 def bench_mixer(model, reps, results):
   """whole PIPSMLPMixer (12 blocks) on 256 x 48 tokens through the public C ABI"""
   lib, ctx = model._lib, model._ctx
@@ -309,6 +340,8 @@ def main():
       trace_gemm(model)
     if 'gemmsteps' in what:
       trace_gemm_steps(model)
+    if 'norm' in what:
+      bench_norm(model, args.reps, results)
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
