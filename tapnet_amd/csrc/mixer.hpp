@@ -502,7 +502,8 @@ inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc =
     // per CU).  Measured at config 2 (tools/kbench.py --what mix): 28.3 us against 31.6 us for the
     // persistent double-buffered form (force_tc = grid cap, two workgroups = 8 waves per CU): the
     // kernel is VALU-latency bound and the extra resident waves are worth more than the overlap of a
-    // workgroup's own loads with its arithmetic; chunk lengths 8 / 12 / 16 measure the same.
+    // workgroup's own loads with its arithmetic; chunk lengths 8 / 12 / 16 measure the same, and so does
+    // starting half of the workgroups 1-2 us late (longer delays cost their length).
     if (force_tc <= 0) {
       hipLaunchKernelGGL((mix_stream_kernel<TO, 12, false>), dim3(units), dim3(MIX_THREADS), 0, s, m, units, nch);
       return;
