@@ -318,64 +318,89 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   if (map + gridDim.x < a.maps) fetch(map + gridDim.x);
   __syncthreads();
 
-  // ---- hid1 = relu(conv3x3(cost) + b), pixel-major
-  for (int p = tid; p < hw; p += CV_THREADS) {
-    // (memory clobber: re-read the weight broadcasts per cell instead of pinning 200 VGPRs)
-#ifndef TAPIR_HIPEMU
-    asm volatile("" ::: "memory");
-#endif
-    const int y = p / w, x = p % w;
-    float v[9];
+  // ---- hid1 = relu(conv3x3(cost) + b), pixel-major.  The thread's CV_PPT cells go through the 16
+  // channels TOGETHER: one set of weight broadcasts (3 x ds_read_b128) per channel serves all of
+  // them (per cell it was 48 LDS instructions for 144 FMAs; the weights cannot stay in registers:
+  // 160 + 144 values, and as wave-uniform scalars they spill).
+  // (Pairing the cells into v_pk_fma_f32 with splat weights measured SLOWER, 380 vs 344 us: the
+  // pairs have to be assembled from single ds_read_b32 values.)
+  {
+    float v[CV_PPT][9];
+    int pp[CV_PPT];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int s = 0; s < CV_PPT; ++s) {
+      const int p = min(tid + s * CV_THREADS, hw - 1);
+      const int y = p / w, x = p % w;
+      pp[s] = (y + 1) * pw + (x + 1);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_cm[(y + dy) * pw + (x + dx)];
-    float o[16];
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float4 wa = s_w1[c][0], wb4 = s_w1[c][1], wc = s_w1[c][2];
-      float acc = wc.y;
-      acc = fmaf(wa.x, v[0], acc); acc = fmaf(wa.y, v[1], acc); acc = fmaf(wa.z, v[2], acc);
-      acc = fmaf(wa.w, v[3], acc); acc = fmaf(wb4.x, v[4], acc); acc = fmaf(wb4.y, v[5], acc);
-      acc = fmaf(wb4.z, v[6], acc); acc = fmaf(wb4.w, v[7], acc); acc = fmaf(wc.x, v[8], acc);
-      o[c] = fmaxf(acc, 0.f);
+        for (int dx = 0; dx < 3; ++dx) v[s][dy * 3 + dx] = s_cm[(y + dy) * pw + (x + dx)];
     }
-    const int pp = (y + 1) * pw + (x + 1);
-    float4* dst = s_h1[pp];
-    const int sw = (pp >> 2) & 3;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c ^ sw] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+    for (int c4 = 0; c4 < 4; ++c4) {
+      float o[CV_PPT][4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * c4 + cc;
+#ifndef TAPIR_HIPEMU
+        asm volatile("" ::: "memory");   // re-read the weights per channel instead of pinning 160 VGPRs
+#endif
+        const float4 wa = s_w1[c][0], wb4 = s_w1[c][1], wc = s_w1[c][2];
+#pragma unroll
+        for (int s = 0; s < CV_PPT; ++s) {
+          float acc = wc.y;
+          acc = fmaf(wa.x, v[s][0], acc); acc = fmaf(wa.y, v[s][1], acc); acc = fmaf(wa.z, v[s][2], acc);
+          acc = fmaf(wa.w, v[s][3], acc); acc = fmaf(wb4.x, v[s][4], acc); acc = fmaf(wb4.y, v[s][5], acc);
+          acc = fmaf(wb4.z, v[s][6], acc); acc = fmaf(wb4.w, v[s][7], acc); acc = fmaf(wc.x, v[s][8], acc);
+          o[s][cc] = fmaxf(acc, 0.f);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < CV_PPT; ++s)
+        if (tid + s * CV_THREADS < hw)
+          s_h1[pp[s]][c4 ^ ((pp[s] >> 2) & 3)] = make_float4(o[s][0], o[s][1], o[s][2], o[s][3]);
+    }
   }
   __syncthreads();
 
-  // ---- logits = conv3x3(hid1) + b, scaled by the temperature (f32 VALU)
+  // ---- logits = conv3x3(hid1) + b, scaled by the temperature (f32 VALU); again all cells of the
+  // thread per weight read
   float z[CV_PPT];
   float zmax = -3.0e38f;
+  {
+    int base[CV_PPT];
+    float acc[CV_PPT];
 #pragma unroll
-  for (int s = 0; s < CV_PPT; ++s) {
-    const int p = tid + s * CV_THREADS;
-    z[s] = -3.0e38f;
-#ifndef TAPIR_HIPEMU
-    asm volatile("" ::: "memory");   // as above, for the conv-2 weights
-#endif
-    if (p < hw) {
-      const int y = p / w, x = p % w;
-      float acc = a.wt.b2[0];
+    for (int s = 0; s < CV_PPT; ++s) {
+      const int p = min(tid + s * CV_THREADS, hw - 1);
+      base[s] = (p / w) * pw + (p % w);
+      acc[s] = a.wt.b2[0];
+    }
 #pragma unroll 3
-      for (int k = 0; k < 9; ++k) {
-        const int pp = (y + k / 3) * pw + (x + k % 3);
-        const float4* hp = s_h1[pp];
-        const int sw = (pp >> 2) & 3;
+    for (int k = 0; k < 9; ++k) {
+#ifndef TAPIR_HIPEMU
+      asm volatile("" ::: "memory");   // as above, for the conv-2 weights
+#endif
+      const int koff = (k / 3) * pw + (k % 3);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 hv = hp[c ^ sw], wv = s_w2[k][c];
-          acc = fmaf(wv.x, hv.x, acc);
-          acc = fmaf(wv.y, hv.y, acc);
-          acc = fmaf(wv.z, hv.z, acc);
-          acc = fmaf(wv.w, hv.w, acc);
+      for (int c = 0; c < 4; ++c) {
+        const float4 wv = s_w2[k][c];
+#pragma unroll
+        for (int s = 0; s < CV_PPT; ++s) {
+          const int q = base[s] + koff;
+          const float4 hv = s_h1[q][c ^ ((q >> 2) & 3)];
+          acc[s] = fmaf(wv.x, hv.x, acc[s]);
+          acc[s] = fmaf(wv.y, hv.y, acc[s]);
+          acc[s] = fmaf(wv.z, hv.z, acc[s]);
+          acc[s] = fmaf(wv.w, hv.w, acc[s]);
         }
       }
-      z[s] = acc * a.temperature;
+    }
+#pragma unroll
+    for (int s = 0; s < CV_PPT; ++s) {
+      const bool in = tid + s * CV_THREADS < hw;
+      z[s] = in ? acc[s] * a.temperature : -3.0e38f;
       zmax = fmaxf(zmax, z[s]);
     }
   }
