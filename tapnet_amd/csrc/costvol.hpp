@@ -246,17 +246,21 @@ __global__ __launch_bounds__(CV_THREADS) void cv_heads_kernel(CvHeadArgs a) {
 // Everything that feeds the soft-argmax (conv 1->16, conv 16->1, softmax) stays f32 VALU: only
 // the occlusion / expected-distance logits see bf16 rounding.  The pixel-major layout also cuts the
 // LDS reads of the 16 -> 1 convolution from 144 x b32 to 36 x b128 per cell.
-template <int CV_MAX_PAD, int CV_PPT>
-__global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
+// NT threads per workgroup x CV_PPT cells per thread >= h*w.  Production: (256, 4): 256 VGPRs, 8
+// waves per CU.  (512, 2) capped at 128 VGPRs for 16 waves per CU (LDS holds two workgroups either
+// way) spills 48 registers and measured 405 us against 340.
+template <int CV_MAX_PAD, int CV_PPT, int NT>
+__global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
+  constexpr int NW = NT / 64;   // waves
   __shared__ float s_cm[CV_MAX_PAD];             // cost map with zero halo
   // relu(hid1) with zero halo, [pixel][4 channel quads]; quad c4 of pixel p sits at slot
   // c4 ^ ((p >> 2) & 3): 16 consecutive pixels then cover all 64 banks for one quad index
   // (64-byte pixel stride would otherwise be a 4-way conflict on every ds_read_b128)
   __shared__ float4 s_h1[CV_MAX_PAD][4];
-  __shared__ float s_red[8][4];
-  __shared__ int s_redi[4];
+  __shared__ float s_red[8][NW];
+  __shared__ int s_redi[NW];
   __shared__ float s_vec[32 + 16];
-  __shared__ float s_occ[4][32];
+  __shared__ float s_occ[NW][32];
   // conv-1 / conv-2 weights as LDS broadcasts (as wave-uniform scalars they need 300 SGPRs and
   // were spilled): s_w1[c] = {w1[c][0..8], b1[c], -, -}, s_w2[tap] = w2[0..15][tap]
   __shared__ float4 s_w1[16][3];
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   const int lane = tid & 63, wave = tid >> 6;
   const int h = a.h, w = a.w, hw = h * w;
   const int pw = w + 2, ph = h + 2, pn = pw * ph;
-  constexpr int CM_PT = (CV_MAX_PAD + CV_THREADS - 1) / CV_THREADS;   // padded cells per thread
+  constexpr int CM_PT = (CV_MAX_PAD + NT - 1) / NT;   // padded cells per thread
 
   // B fragments of the occlusion convolution (10 KiB, L2-resident), in flight during phase A/B
   uint4 wb[5][2];
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
     const float* cvp = a.cv + m * hw;
 #pragma unroll
     for (int s = 0; s < CM_PT; ++s) {
-      const int i = tid + s * CV_THREADS;
+      const int i = tid + s * NT;
       const int y = i / pw - 1, x = i % pw - 1;
       const bool in = (i < pn) && (y >= 0) && (y < h) && (x >= 0) && (x < w);
       cmv[s] = in ? cvp[y * w + x] : 0.f;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   };
   fetch(blockIdx.x);
   // zero halos of hid1 (never written afterwards)
-  for (int i = tid; i < pn; i += CV_THREADS) {
+  for (int i = tid; i < pn; i += NT) {
     const int y = i / pw - 1, x = i % pw - 1;
     if (!((y >= 0) && (y < h) && (x >= 0) && (x < w))) {
 #pragma unroll
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   __syncthreads();   // the previous map's readers of s_cm / s_h1 / s_vec are done
 #pragma unroll
   for (int s = 0; s < CM_PT; ++s) {
-    const int i = tid + s * CV_THREADS;
+    const int i = tid + s * NT;
     if (i < pn) s_cm[i] = cmv[s];
   }
   if (map + gridDim.x < a.maps) fetch(map + gridDim.x);
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
     int pp[CV_PPT];
 #pragma unroll
     for (int s = 0; s < CV_PPT; ++s) {
-      const int p = min(tid + s * CV_THREADS, hw - 1);
+      const int p = min(tid + s * NT, hw - 1);
       const int y = p / w, x = p % w;
       pp[s] = (y + 1) * pw + (x + 1);
 #pragma unroll
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
       }
 #pragma unroll
       for (int s = 0; s < CV_PPT; ++s)
-        if (tid + s * CV_THREADS < hw)
+        if (tid + s * NT < hw)
           s_h1[pp[s]][c4 ^ ((pp[s] >> 2) & 3)] = make_float4(o[s][0], o[s][1], o[s][2], o[s][3]);
     }
   }
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
     float acc[CV_PPT];
 #pragma unroll
     for (int s = 0; s < CV_PPT; ++s) {
-      const int p = min(tid + s * CV_THREADS, hw - 1);
+      const int p = min(tid + s * NT, hw - 1);
       base[s] = (p / w) * pw + (p % w);
       acc[s] = a.wt.b2[0];
     }
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
     }
 #pragma unroll
     for (int s = 0; s < CV_PPT; ++s) {
-      const bool in = tid + s * CV_THREADS < hw;
+      const bool in = tid + s * NT < hw;
       z[s] = in ? acc[s] * a.temperature : -3.0e38f;
       zmax = fmaxf(zmax, z[s]);
     }
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   int besti = 0x7fffffff;
 #pragma unroll
   for (int s = 0; s < CV_PPT; ++s) {
-    const int p = tid + s * CV_THREADS;
+    const int p = tid + s * NT;
     if (p < hw && z[s] > best) { best = z[s]; besti = p; }   // p increases with s: keeps the first
   }
 #pragma unroll
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   __syncthreads();
   best = s_red[0][0]; besti = s_redi[0];
 #pragma unroll
-  for (int k = 1; k < 4; ++k) {
+  for (int k = 1; k < NW; ++k) {
     const float ob = s_red[0][k]; const int oi = s_redi[k];
     if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   float esum = 0.f, sx = 0.f, sy = 0.f, sw = 0.f;
 #pragma unroll
   for (int s = 0; s < CV_PPT; ++s) {
-    const int p = tid + s * CV_THREADS;
+    const int p = tid + s * NT;
     if (p < hw) {
       const float e = fast_exp(z[s] - zmax);
       esum += e;
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   const int fi = lane & 15, fgp = lane >> 4;
   float osum[2] = {0.f, 0.f};   // sum over this lane's pixels of relu(conv + b), channels n and 16 + n
   const float b3a = a.wt.b3[fi], b3b = a.wt.b3[16 + fi];
-  for (int mt = wave; mt * 16 < opix; mt += CV_THREADS / 64) {
+  for (int mt = wave; mt * 16 < opix; mt += NT / 64) {
     const int P = min(mt * 16 + fi, opix - 1);          // this lane's A row (clamped: masked below)
     const int oy = P / ow, ox = P - oy * ow;
     const int base = (2 * oy - ply + 1) * pw + (2 * ox - plx + 1);
@@ -492,7 +496,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
   // the tail runs in ONE wave: LDS operations of a wave execute in order, no further barriers
   if (wave == 0) {
     if (lane < 32)
-      s_vec[lane] = (s_occ[0][lane] + s_occ[1][lane] + s_occ[2][lane] + s_occ[3][lane]) / (float)opix;
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) t += s_occ[k][lane & 31];
+      if (lane < 32) s_vec[lane] = t / (float)opix;
+    }
     wave_sync();
     if (lane < 16) {
       float acc = a.wt.b4[lane];
@@ -506,10 +515,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void cv_heads_mfma_kernel(CvHeadArgs
       if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;
     }
     if (lane == 0) {
-      const float tot = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-      const float fsx = (s_red[3][0] + s_red[3][1] + s_red[3][2] + s_red[3][3]) / tot;
-      const float fsy = (s_red[4][0] + s_red[4][1] + s_red[4][2] + s_red[4][3]) / tot;
-      const float fsw = fmaxf((s_red[5][0] + s_red[5][1] + s_red[5][2] + s_red[5][3]) / tot, 1e-12f);
+      float tot = 0.f, tsx = 0.f, tsy = 0.f, tsw = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { tot += s_red[1][k]; tsx += s_red[3][k]; tsy += s_red[4][k]; tsw += s_red[5][k]; }
+      const float fsx = tsx / tot;
+      const float fsy = tsy / tot;
+      const float fsw = fmaxf(tsw / tot, 1e-12f);
       float outx = (fsx / fsw) * a.img_w / (float)w;
       float outy = (fsy / fsw) * a.img_h / (float)h;
       if (a.qpts != nullptr) {

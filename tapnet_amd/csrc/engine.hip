@@ -228,8 +228,8 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
   ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
   if (c->cfg.dtype == TAPIR_BF16 && pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
     // bf16 build: occlusion convolution on the matrix cores
-    hipLaunchKernelGGL((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)std::min<long>(maps, 512)),
-                       dim3(CV_THREADS), 0, s, a);
+    hipLaunchKernelGGL((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT, CV_THREADS>),
+                       dim3((unsigned)std::min<long>(maps, 512)), dim3(CV_THREADS), 0, s, a);
   } else if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
     hipLaunchKernelGGL((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps),
                        dim3(CV_THREADS), 0, s, a);
