@@ -45,6 +45,7 @@ struct CvHeadArgs {
   long maps;              // number of maps (cv_heads_mfma_kernel walks them persistently)
   float temperature;
   float img_h, img_w;     // initial_resolution
+  long long* dbg_times;   // null, or [workgroups][8] wall-clock phase totals (tools/kbench.py --what cvtrace)
 };
 
 template <int CV_MAX_PAD, int CV_PPT>
@@ -249,7 +250,9 @@ __global__ __launch_bounds__(CV_THREADS) void cv_heads_kernel(CvHeadArgs a) {
 // NT threads per workgroup x CV_PPT cells per thread >= h*w.  Production: (256, 4): 256 VGPRs, 8
 // waves per CU.  (512, 2) capped at 128 VGPRs for 16 waves per CU (LDS holds two workgroups either
 // way) spills 48 registers and measured 405 us against 340.
-template <int CV_MAX_PAD, int CV_PPT, int NT>
+// TRACE: thread 0 accumulates wall-clock phase totals into a.dbg_times (tools/kbench.py --what cvtrace);
+// a separate instantiation, the run-time test alone cost the production kernel 10 %.
+template <int CV_MAX_PAD, int CV_PPT, int NT, bool TRACE = false>
 __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   constexpr int NW = NT / 64;   // waves
   __shared__ float s_cm[CV_MAX_PAD];             // cost map with zero halo
@@ -312,8 +315,14 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
       for (int c = 0; c < 4; ++c) s_h1[i][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int k) {   // phase k ends here (thread 0 only; no effect unless tracing)
+    if (TRACE && tid == 0) { const long long t = wall_clock64(); tph[k] += t - tlast; tlast = t; }
+  };
+  if (TRACE && tid == 0) tlast = wall_clock64();
   for (long map = blockIdx.x; map < a.maps; map += gridDim.x) {
   __syncthreads();   // the previous map's readers of s_cm / s_h1 / s_vec are done
+  stamp(0);
 #pragma unroll
   for (int s = 0; s < CM_PT; ++s) {
     const int i = tid + s * NT;
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   }
   if (map + gridDim.x < a.maps) fetch(map + gridDim.x);
   __syncthreads();
+  stamp(1);
 
   // ---- hid1 = relu(conv3x3(cost) + b), pixel-major.  The thread's CV_PPT cells go through the 16
   // channels TOGETHER: one set of weight broadcasts (3 x ds_read_b128) per channel serves all of
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   }
   __syncthreads();
 
+  stamp(2);
   // ---- logits = conv3x3(hid1) + b, scaled by the temperature (f32 VALU); again all cells of the
   // thread per weight read
   float z[CV_PPT];
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
       zmax = fmaxf(zmax, z[s]);
     }
   }
+  stamp(3);
   // block maximum AND its first position in one reduction: argmax(softmax) = argmax(logits)
   // (monotonic), ties -> the smallest index as jnp.argmax (model_utils.py:232)
   float best = -3.0e38f;
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   esum = wave_sum(esum); sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
   if (lane == 0) { s_red[1][wave] = esum; s_red[3][wave] = sx; s_red[4][wave] = sy; s_red[5][wave] = sw; }
 
+  stamp(4);
   // ---- occlusion head: conv 16->32, 3x3, stride 2, XLA SAME (pad_lo = total/2), on the MFMAs
   const int oh = (h + 1) / 2, ow = (w + 1) / 2, opix = oh * ow;
   const int ply = max((oh - 1) * 2 + 3 - h, 0) / 2, plx = max((ow - 1) * 2 + 3 - w, 0) / 2;
@@ -493,6 +506,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   }
   if (lane < 16) { s_occ[wave][lane] = osum[0]; s_occ[wave][16 + lane] = osum[1]; }
   __syncthreads();
+  stamp(5);
   // the tail runs in ONE wave: LDS operations of a wave execute in order, no further barriers
   if (wave == 0) {
     if (lane < 32)
@@ -533,7 +547,10 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
       a.points[map * 2 + 1] = outy;
     }
   }
+  stamp(6);
   }   // maps
+  if (TRACE && tid == 0)
+    for (int k = 0; k < 7; ++k) a.dbg_times[(long)blockIdx.x * 8 + k] = tph[k];
 }
 
 }  // namespace tapir

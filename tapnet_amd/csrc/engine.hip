@@ -78,18 +78,29 @@ int fail(tapir_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
-// brackets one kernel launch with events when profiling is on
+// times one kernel class when profiling is on.  single = the scope holds exactly one launch that goes
+// through TAPIR_LAUNCH: the dispatch then writes the kernel's own start / stop timestamps into the
+// two events (LaunchTimer, common.hpp); otherwise the scope is bracketed by two event markers.
 struct ProfScope {
-  tapir_ctx* c; int kind; hipStream_t s; tapir_ctx::ProfEv ev; bool on;
-  ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_) : c(c_), kind(kind_), s(s_), on((c_->prof >> kind_) & 1u) {
+  tapir_ctx* c; int kind; hipStream_t s; tapir_ctx::ProfEv ev; bool on, single;
+  ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_, bool single_ = true)
+      : c(c_), kind(kind_), s(s_), on((c_->prof >> kind_) & 1u), single(single_) {
     if (!on) return;
     if (!c->prof_free.empty()) { ev = c->prof_free.back(); c->prof_free.pop_back(); }
     else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(ev.a, s);
+    if (single) { LaunchTimer& t = launch_timer(); t.start = ev.a; t.stop = ev.b; t.used = false; }
+    else (void)hipEventRecord(ev.a, s);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(ev.b, s);
+    if (single) {
+      LaunchTimer& t = launch_timer();
+      const bool used = t.used;
+      t = LaunchTimer{};
+      if (!used) { (void)hipEventRecord(ev.a, s); (void)hipEventRecord(ev.b, s); }   // no launch: empty interval
+    } else {
+      (void)hipEventRecord(ev.b, s);
+    }
     c->prof_ev[kind].push_back(ev);
   }
 };
@@ -224,18 +235,21 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
   a.T = T; a.h = h; a.w = w; a.maps = maps;
   a.temperature = c->cfg.softmax_temperature;
   a.img_h = (float)c->cfg.initial_h; a.img_w = (float)c->cfg.initial_w;
+  a.dbg_times = (long long*)c->dbg_times;
   const int pn = (h + 2) * (w + 2), hw = h * w;
   ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
   if (c->cfg.dtype == TAPIR_BF16 && pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
     // bf16 build: occlusion convolution on the matrix cores
-    hipLaunchKernelGGL((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT, CV_THREADS>),
-                       dim3((unsigned)std::min<long>(maps, 512)), dim3(CV_THREADS), 0, s, a);
+    if (a.dbg_times != nullptr)
+      TAPIR_LAUNCH((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT, CV_THREADS, true>),
+                   dim3((unsigned)std::min<long>(maps, 512)), dim3(CV_THREADS), s, a);
+    else
+      TAPIR_LAUNCH((cv_heads_mfma_kernel<CV_SMALL_PAD, CV_SMALL_PPT, CV_THREADS>),
+                   dim3((unsigned)std::min<long>(maps, 512)), dim3(CV_THREADS), s, a);
   } else if (pn <= CV_SMALL_PAD && hw <= CV_SMALL_PPT * CV_THREADS) {
-    hipLaunchKernelGGL((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps),
-                       dim3(CV_THREADS), 0, s, a);
+    TAPIR_LAUNCH((cv_heads_kernel<CV_SMALL_PAD, CV_SMALL_PPT>), dim3((unsigned)maps), dim3(CV_THREADS), s, a);
   } else if (pn <= CV_LARGE_PAD && hw <= CV_LARGE_PPT * CV_THREADS) {
-    hipLaunchKernelGGL((cv_heads_kernel<CV_LARGE_PAD, CV_LARGE_PPT>), dim3((unsigned)maps),
-                       dim3(CV_THREADS), 0, s, a);
+    TAPIR_LAUNCH((cv_heads_kernel<CV_LARGE_PAD, CV_LARGE_PPT>), dim3((unsigned)maps), dim3(CV_THREADS), s, a);
   } else {
     return fail(c, TAPIR_ERR_UNSUPPORTED, "cost-volume grid larger than 1600 cells");
   }
@@ -331,12 +345,14 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s); TRY((mixer_gemm<TA, TA, EPI_BIAS_GELU>(c, g1, s))); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s, gemm_splits<TA>(g1.M, g1.K) <= 1);
+      TRY((mixer_gemm<TA, TA, EPI_BIAS_GELU>(c, g1, s))); }
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s); TRY((mixer_gemm<TA, float, EPI_BIAS_RESID>(c, g2, s))); }
+    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s, gemm_splits<TA>(g2.M, g2.K) <= 1);
+      TRY((mixer_gemm<TA, float, EPI_BIAS_RESID>(c, g2, s))); }
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
@@ -372,7 +388,7 @@ int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const 
   pa.B = B; pa.Q = Q; pa.T = T;
   pa.orig_h = (float)orig_h; pa.orig_w = (float)orig_w;
   { ProfScope ps(c, TAPIR_PROF_PATCH, s);
-    hipLaunchKernelGGL((patch_corr_kernel<TA, TA>), dim3(patch_corr_grid(B, Q, T)), dim3(256), 0, s, pa); }
+    TAPIR_LAUNCH((patch_corr_kernel<TA, TA>), dim3(patch_corr_grid(B, Q, T)), dim3(256), s, pa); }
   return TAPIR_OK;
 }
 

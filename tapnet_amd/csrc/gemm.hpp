@@ -320,9 +320,11 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
   // ---- DMA side: issues k-step copies in (tile, k) order, NS-1 steps ahead of the MFMAs
   int stamp_i = 0;
   auto stamp = [&]() {
+#ifndef TAPIR_NO_STAMPS
     if (!TRACE && g.dbg_times != nullptr && tid == 0 && stamp_i < 16)
       g.dbg_times[(long)blockIdx.x * 16 + stamp_i] = wall_clock64();
     ++stamp_i;
+#endif
   };
   unsigned long long tk[5] = {0, 0, 0, 0, 0}, tsum[5] = {0, 0, 0, 0, 0}, tstart = 0;
   auto tick = [&](int k) {   // the value arrives asynchronously (SMEM): read it after tick_sync()
@@ -718,7 +720,7 @@ inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid
   const int per_cu = std::max(1, std::min(3, (160 * 1024) / TL::LDS_BYTES));
   int grid = std::min((ntiles + 7) / 8 * 8, 256 * per_cu);
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
-  hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid, splits), dim3(TL::THREADS), 0, stream, g);
+  TAPIR_LAUNCH((gemm_nt_kernel<TA, TO, EPI, TL>), dim3(grid, splits), dim3(TL::THREADS), stream, g);
 }
 
 // the same launch with the per-k-step cycle trace compiled in (debug entry only)
@@ -819,7 +821,7 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
       const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
       int grid = std::min((ntiles + 7) / 8 * 8, 256);
       if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
-      hipLaunchKernelGGL((gemm_ws_kernel<TA, TO, EPI, TL, 4>), dim3(grid), dim3(TL::THREADS + 256), 0, stream, g);
+      TAPIR_LAUNCH((gemm_ws_kernel<TA, TO, EPI, TL, 4>), dim3(grid), dim3(TL::THREADS + 256), stream, g);
       break;
     }
     default: launch_gemm_tile<TA, TO, EPI, GemmTileSquare>(g, stream, max_grid); break;

@@ -348,7 +348,9 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_stream_kernel(MixArgs a, int 
   const float4 s2b = *reinterpret_cast<const float4*>(a.ln2 + 256 + lane * 4);
 
   auto stamp = [&](int unit, int k) {
+#ifndef TAPIR_NO_STAMPS
     if (a.dbg_times != nullptr && tid == 0) a.dbg_times[(long)unit * 6 + k] = wall_clock64();
+#endif
   };
   stamp(u, 0);
   auto process = [&](const MixUnit<TC>& q, float (*s_x)[kHidden], float2* s_stat, int unit) {
@@ -505,15 +507,15 @@ inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc =
     // workgroup's own loads with its arithmetic; chunk lengths 8 / 12 / 16 measure the same, and so does
     // starting half of the workgroups 1-2 us late (longer delays cost their length).
     if (force_tc <= 0) {
-      hipLaunchKernelGGL((mix_stream_kernel<TO, 12, false>), dim3(units), dim3(MIX_THREADS), 0, s, m, units, nch);
+      TAPIR_LAUNCH((mix_stream_kernel<TO, 12, false>), dim3(units), dim3(MIX_THREADS), s, m, units, nch);
       return;
     }
     const int grid = std::min(units, force_tc);
-    hipLaunchKernelGGL((mix_stream_kernel<TO, 12>), dim3(grid), dim3(MIX_THREADS), 0, s, m, units, nch);
+    TAPIR_LAUNCH((mix_stream_kernel<TO, 12>), dim3(grid), dim3(MIX_THREADS), s, m, units, nch);
     return;
   }
   const int nch = (m.T + m.TC - 1) / m.TC;
-  hipLaunchKernelGGL((mix_kernel<TO>), dim3(nch, N), dim3(MIX_THREADS), 0, s, m);
+  TAPIR_LAUNCH((mix_kernel<TO>), dim3(nch, N), dim3(MIX_THREADS), s, m);
 }
 
 // Row-wise LayerNorm (scale only) -> operand type; one wave per row of 512.

@@ -248,6 +248,33 @@ def trace_gemm_steps(model):
     print(f'  {"prologue / other":28s} median {np.median(rest):9.0f} cyc  {100 * np.median(rest / tot):5.1f} %')
 
 
+def trace_cv(model):
+  """phase totals of cv_heads_mfma_kernel per workgroup (wall clock, 100 MHz), config-2 cost-volume stage"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  B, Q, T, h, w = 1, 256, 48, 32, 32
+  qf = torch.nn.functional.normalize(torch.randn(B, Q, 256, device=dev), dim=-1)
+  grid = torch.nn.functional.normalize(torch.randn(B, T, h, w, 256, device=dev), dim=-1)
+  pts = torch.empty(B, Q, T, 2, device=dev); occ = torch.empty(B, Q, T, device=dev); ex = torch.empty(B, Q, T, device=dev)
+  tr = torch.zeros(512, 8, dtype=torch.int64, device=dev)
+  def run():
+    rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), None, B, Q, T, h, w,
+                                           pts.data_ptr(), occ.data_ptr(), ex.data_ptr(), model._stream())
+    assert rc == 0, lib.tapir_last_error(ctx)
+  for _ in range(3):
+    run()
+  torch.cuda.synchronize()
+  lib.tapir_debug_set_trace(ctx, tr.data_ptr()); run(); torch.cuda.synchronize()
+  lib.tapir_debug_set_trace(ctx, None)
+  t = tr.cpu().numpy().astype(np.float64) * 0.01   # us per workgroup (24 maps each)
+  names = ['barrier (previous map done)', 'stage cost map + prefetch + barrier', 'conv 1->16 + relu (+barrier)',
+           'conv 16->1', 'argmax + softmax sums', 'occlusion conv (MFMA) + barrier', 'tail (one wave)']
+  tot = t[:, :7].sum(axis=1)
+  print(f'cv_heads trace: {t.shape[0]} workgroups, median total {np.median(tot):.1f} us for {Q * T // 512} maps each')
+  for k in range(7):
+    print(f'  {names[k]:40s} median {np.median(t[:, k]):7.1f} us  {100 * np.median(t[:, k] / tot):5.1f} %')
+
+
 def bench_norm(model, reps, results):
   """backbone glue kernels (HBM-bound): InstanceNorm statistics (with / without the fused residual add)
   and normalise + ReLU at the ResNet's activation shapes, over slab counts"""
@@ -340,6 +367,8 @@ def main():
       trace_gemm(model)
     if 'gemmsteps' in what:
       trace_gemm_steps(model)
+    if 'cvtrace' in what:
+      trace_cv(model)
     if 'norm' in what:
       bench_norm(model, args.reps, results)
     if 'mixtrace' in what:
