@@ -158,10 +158,12 @@ typedef struct tapir_traj_args {
  * reproduced. */
 int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, void* stream);
 
-/* Measurement support (bench.py).  When enabled, every launch of the kernel classes below
- * is bracketed by two hipEvents recorded on the caller's stream; tapir_profile_read()
- * synchronises on them and returns the number of launches and their summed duration since
- * the previous read of that class. */
+/* Measurement support (bench.py).  When enabled, every launch of the kernel classes below is
+ * timed with two hipEvents on the caller's stream -- filled in by the dispatch itself with the
+ * kernel's start / stop timestamps (hipExtLaunchKernelGGL; the value rocprofv3 reports as the
+ * kernel's duration), or recorded as markers around the launches when a class takes more than
+ * one launch (split-K GEMMs of the online model); tapir_profile_read() synchronises on them and
+ * returns the number of launches and their summed duration since the previous read of that class. */
 #define TAPIR_PROF_GEMM_UP 0    /* mixer mlp2_up GEMM   [R,512]x[512,2048] + bias + GELU  */
 #define TAPIR_PROF_GEMM_DOWN 1  /* mixer mlp2_down GEMM [R,2048]x[2048,512] + bias + skip */
 #define TAPIR_PROF_MIX 2        /* LN + temporal depthwise convs + LN (mix_kernel)         */
@@ -204,16 +206,26 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * 2: C f32 = acc + bias + resid [M,ldr] f32.  tile: 0 = automatic, 1 = 192x128 (4 LDS stages), 2 = 128x128,
  * 3 = 192x64, 4 = 192x128 (3 stages), 5 = 192x128 wave-specialised (4 DMA + 8 MFMA waves),
  * 6 = 192x256, 7 = 256x128 (3 stages), 8 = 128x128 with 8 waves, 9 = 192x64 with 8 waves,
- * 10 = 128x64 with 8 waves (three workgroups per CU); bits 8..19 of `tile`, when non-zero, cap the persistent grid (tests).  K must be a multiple of 64 (bf16) / 32 (f32); N, ldc multiples of 4. */
+ * 10 = 128x64 with 8 waves (three workgroups per CU), 11 = 256x128 with 16 waves, 3 stages and
+ * fragment prefetch, 12 = 128x128 8 waves 3 stages + prefetch, 13 = 256x128 16 waves 2 stages,
+ * 14 = 256x128 16 waves 3 stages, 15 = 128x128 8 waves 3 stages; bits 8..19 of `tile`, when non-zero,
+ * cap the persistent grid (tests); bit 20 (bf16 build, epi 1 | 2, trace buffer set, tiles 1 / 3 / 6 / 8):
+ * the TRACE build of the kernel, whose waves write their per-k-step cycle totals
+ * ([workgroup*16 + wave][8] int64: copy issue, fragment reads + MFMAs, wait for own copies, barrier,
+ * epilogue, lifetime) into the trace buffer.  K must be a multiple of 64 (bf16) / 32 (f32); N, ldc
+ * multiples of 4. */
 int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, long ldw,
                      const float* bias, const float* resid, long ldr, void* C, long ldc,
                      int M, int N, int K, int epi, int tile, void* stream);
 /* One launch of the token-mixing kernel of mixer block `block` (LN, temporal depthwise
  * convs, GELU, group sum, skip, LN): x_in [N,T,512] f32 -> x_out [N,T,512] f32 and
- * xn [N*T,512] in the operand type.  Non-causal contexts only.  tc: 0 = automatic, > 0 caps the
- * number of persistent workgroups (tests: several units per workgroup). */
-/* Phase tracing for tools/kbench.py: when a device buffer of int64 [units][6] is set, the next
- * tapir_debug_mix launches write wall-clock stamps (100 MHz) per work unit; NULL turns it off. */
+ * xn [N*T,512] in the operand type.  Non-causal contexts only.  tc: 0 = production form (one
+ * (track, 12-frame chunk) unit per workgroup), > 0 = the persistent double-buffered form on at most
+ * tc workgroups (tests: several units per workgroup). */
+/* Phase tracing for tools/kbench.py: while a device buffer is set, tapir_debug_mix writes
+ * wall-clock stamps (100 MHz) per work unit (int64 [units][6]), tapir_debug_gemm per workgroup
+ * (int64 [workgroups][16], or the bit-20 layout above) and the bf16 cost-volume heads kernel its
+ * phase totals per workgroup (int64 [512][8]); NULL turns it off. */
 int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
