@@ -195,8 +195,8 @@ def main():
                 frac=round(ach / peak, 4) if ach else None, traffic=None,
                 launches=up_n, avg_us=round(up_ms / up_n * 1e3, 2) if up_n else None,
                 flops_per_launch=flops)
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc):
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # measured on the bf16 build
+    if os.path.exists(pmc) and dtype == 'bfloat16':
       try:
         roof['traffic'] = json.load(open(pmc)).get('gemm_up_hbm_bytes_per_launch')
       except Exception:

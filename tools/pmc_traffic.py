@@ -15,21 +15,33 @@ import os
 import sys
 
 KERNELS = {
-    'gemm_up': ('gemm_nt_kernel<unsigned short, unsigned short, 1', 'GemmTile<2, 2, 4, 4, 2'),
-    'gemm_down': ('gemm_nt_kernel<unsigned short, float, 2', 'GemmTile<2, 2, 6, 2, 2'),
-    'mix': ('mix_stream_kernel<unsigned short', ''),
+    'gemm_up': ('gemm_nt_kernel<unsigned short, unsigned short, 1', 'GemmTile<2, 4, 4, 2, 2'),   # 128x128, 8 waves
+    'gemm_down': ('gemm_nt_kernel<unsigned short, float, 2', 'GemmTile<2, 2, 6, 2, 2'),          # 192x64
+    'mix': ('mix_stream_kernel<unsigned short, 12, false', ''),
 }
 
 
+def rows_of(d):
+  """(kernel name, counter name, value) of every dispatch: rocprofv3's CSV or rocpd (sqlite) output"""
+  f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))
+  if f:
+    for r in csv.DictReader(open(f[0])):
+      yield r['Kernel_Name'], r['Counter_Name'], float(r['Counter_Value'])
+    return
+  import sqlite3
+  db = sqlite3.connect(glob.glob(os.path.join(d, '*', '*results.db'))[0])
+  for row in db.execute('select kernel_name, counter_name, value from counters_collection'):
+    yield row[0], row[1], float(row[2])
+
+
 def per_kernel(d, counter):
-  f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))[0]
   acc = collections.defaultdict(list)
-  for r in csv.DictReader(open(f)):
-    if r['Counter_Name'] != counter:
+  for name, cname, value in rows_of(d):
+    if cname != counter:
       continue
     for key, (a, b) in KERNELS.items():
-      if a in r['Kernel_Name'] and b in r['Kernel_Name']:
-        acc[key].append(float(r['Counter_Value']))
+      if a in name and b in name:
+        acc[key].append(value)
   return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
