@@ -353,3 +353,38 @@ def test_track_many_points_matches_per_frame_api_loop():
         margin = (vis - 0.5).abs().cpu().numpy() > 1e-3
         np.testing.assert_array_equal(out['separation_visibility'][k][lo:hi, t][margin],
                                       (vis > 0.5).cpu().numpy()[margin])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,Q,res,pyr,chunk', [(5, 7, (256, 256), 0, 3), (3, 1, (192, 256), 1, None),
+                                               (1, 4, (256, 256), 0, None), (9, 13, (128, 160), 1, 5)])
+def test_ragged_shapes_vs_oracle(T, Q, res, pyr, chunk):
+  """Ragged / minimal shapes through the whole hot path, f32 build vs the oracle at 1e-3: frame counts
+  that are not a multiple of 8 (token-order fallback of the patch kernel, partial time chunks of the mix
+  kernel), a single query, a single frame, non-square grids (24x32, 16x20), ragged GEMM tiles
+  (R = 21 ... 117 token rows) and query chunks with a remainder; the bf16 build on the same input
+  stays close to it."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(30 + T, pyramid_level=pyr, extra_convs=False)
+  video = synthetic.make_video(40 + Q, T, res[0], res[1])
+  qp = synthetic.make_queries(50 + T, Q, T, res[0], res[1])
+  m = tapir_model.TAPIR(pyramid_level=pyr, extra_convs=False, weights=w, device='cuda:0',
+                        initial_resolution=res)
+  fg = m.get_feature_grids(video)
+  out = m(video, False, qp, feature_grids=fg, query_chunk_size=chunk)
+  lows = [x.cpu().numpy() for x in fg.lowres]; his = [x.cpu().numpy() for x in fg.hires]
+  ref = O.tapir_from_grids(w, video.shape, lows, his, list(fg.resolutions), qp, pyramid_level=pyr)
+  ql, _ = O.get_query_features(lows, his, list(fg.resolutions), qp, video.shape)
+  _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], qp, return_stages=True)
+  ok = (st['top2_rel_gap'] > 1e-4).all(axis=-1)   # queries whose every frame has a clear argmax
+  assert out['tracks'].shape == (1, Q, T, 2) and np.isfinite(out['tracks']).all()
+  assert ok.any()
+  np.testing.assert_allclose(out['tracks'][ok], ref['tracks'][ok], atol=1e-3)
+  np.testing.assert_allclose(out['occlusion'][ok], ref['occlusion'][ok], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'][ok], ref['expected_dist'][ok], atol=1e-3)
+  m16 = tapir_model.TAPIR(pyramid_level=pyr, extra_convs=False, weights=w, device='cuda:0',
+                          initial_resolution=res, dtype='bfloat16')
+  b = m16(video, False, qp, feature_grids=fg, query_chunk_size=chunk)
+  assert np.isfinite(b['tracks']).all()
+  d = np.linalg.norm(b['tracks'] - out['tracks'], axis=-1)
+  assert np.median(d) < 0.5, np.median(d)
