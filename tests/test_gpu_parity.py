@@ -388,3 +388,36 @@ def test_ragged_shapes_vs_oracle(T, Q, res, pyr, chunk):
   assert np.isfinite(b['tracks']).all()
   d = np.linalg.norm(b['tracks'] - out['tracks'], axis=-1)
   assert np.median(d) < 0.5, np.median(d)
+
+
+@pytest.mark.gpu
+def test_error_conventions_match_the_reference():
+  """SURVEY 8b error conventions: ValueError for a resolution that is not a multiple of 8
+  (tapir_model.py:663-664), for get_query_feats=True (:1109-1110), for training with a causal
+  context (:941-943); assert on mismatched pyramid lengths in refine_pips (:495); and the C ABI
+  reports bad arguments as error codes with a message, never by crashing."""
+  import ctypes
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(2, pyramid_level=0, extra_convs=False)
+  m = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0', use_causal_conv=True)
+  video = synthetic.make_video(1, 2, 64, 64)
+  qp = synthetic.make_queries(2, 3, 2, 64, 64)
+  with pytest.raises(ValueError, match='multiple of 8'):
+    m.get_feature_grids(video, False, refinement_resolutions=[(60, 64)])
+  with pytest.raises(ValueError, match='query feats'):
+    m(video, False, qp, get_query_feats=True)
+  m64 = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, weights=w, device='cuda:0', use_causal_conv=True,
+                          initial_resolution=(64, 64))
+  fg = m64.get_feature_grids(video)
+  qf = m64.get_query_features(video, False, qp, fg)
+  state = m64.construct_initial_causal_state(3, len(qf.resolutions) - 1)
+  with pytest.raises(ValueError, match='causal context'):
+    m64.estimate_trajectories((64, 64), True, fg, qf, None, causal_context=state, get_causal_context=True)
+  with pytest.raises(AssertionError):
+    m64.refine_pips([qf.hires[0]], None, [fg.hires[0], fg.lowres[0]], None, None, None, (64, 64))
+  with pytest.raises(ValueError):
+    tapir_model.TAPIR(mixer_hidden_dim=256, weights=w, device='cuda:0')
+  # C ABI: invalid arguments come back as codes + message
+  lib, ctx = m64._lib, m64._ctx
+  rc = lib.tapir_build_cost_volume(ctx, None, None, 1, 3, 2, 8, 8, 256, None, None)
+  assert rc != 0 and lib.tapir_last_error(ctx)
