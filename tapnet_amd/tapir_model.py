@@ -116,8 +116,11 @@ class TAPIR:
       dtype: str = 'float32',
       device: Any = None,
       haiku_state_names: bool = False,
+      use_casual_conv: Optional[bool] = None,
   ):
     del bilinear_interp_with_depthwise_conv, parallelize_query_extraction, name
+    if use_casual_conv is not None:   # the torch twin spells the argument this way (torch/tapir_model.py:84)
+      use_causal_conv = use_casual_conv
     if mixer_hidden_dim != 512 or mixer_kernel_shape != 3 or patch_size != 7:
       raise ValueError('the HIP kernels are built for mixer_hidden_dim=512, '
                        'mixer_kernel_shape=3, patch_size=7 (the released checkpoints)')
@@ -204,6 +207,34 @@ class TAPIR:
           torch.bfloat16 if self.dtype == 'bfloat16' else torch.float32, self.blocks_per_group,
           engine=(self._lib, self._ctx))
     self._weights_loaded = True
+
+  # -- the call surface of the reference's PyTorch twin (tapnet/torch/tapir_model.py:139-147 and its
+  #    use in tapnet/pytorch_live_demo.py:110-116): same model, nn.Module-style entry points
+  def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
+    """``model.load_state_dict(torch.load(checkpoint.pt))`` (pytorch_live_demo.py:111-113)."""
+    del strict
+    self.load_weights(state_dict)
+    return self
+
+  def to(self, *args, **kwargs):
+    """The engine lives on the GPU it was created on; moving it is a no-op (returns self)."""
+    del args, kwargs
+    return self
+
+  def eval(self):
+    return self
+
+  def train(self, mode: bool = True):
+    if mode:
+      raise ValueError('tapnet_amd.TAPIR is an inference engine: training mode is not supported')
+    return self
+
+  def forward(self, video, query_points, is_training: bool = False, query_chunk_size: Optional[int] = 64,
+              get_query_feats: bool = False,
+              refinement_resolutions: Optional[List[Tuple[int, int]]] = None):
+    """torch/tapir_model.py:139-215: the torch twin's argument order (query_points second)."""
+    return self(video, is_training, query_points, query_chunk_size=query_chunk_size,
+                get_query_feats=get_query_feats, refinement_resolutions=refinement_resolutions)
 
   def reserve(self, batch: int, num_queries: int, num_frames: int, lowres_hw: Tuple[int, int]):
     """Pre-sizes all workspaces (needed before hipGraph capture)."""

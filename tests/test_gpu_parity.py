@@ -421,3 +421,23 @@ def test_error_conventions_match_the_reference():
   lib, ctx = m64._lib, m64._ctx
   rc = lib.tapir_build_cost_volume(ctx, None, None, 1, 3, 2, 8, 8, 256, None, None)
   assert rc != 0 and lib.tapir_last_error(ctx)
+
+
+@pytest.mark.gpu
+def test_torch_twin_call_surface():
+  """The reference's PyTorch twin is driven as an nn.Module (pytorch_live_demo.py:110-116):
+  TAPIR(pyramid_level=1, use_casual_conv=True); load_state_dict; .to(device).eval();
+  forward(video, query_points) with the twin's argument order."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(5, pyramid_level=1, extra_convs=False)
+  m = tapir_model.TAPIR(pyramid_level=1, use_casual_conv=True, device='cuda:0', initial_resolution=(64, 64))
+  assert m.use_causal_conv
+  m = m.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()}).to('cuda:0').eval()
+  video = torch.as_tensor(synthetic.make_video(6, 3, 64, 64)).cuda()
+  qp = torch.as_tensor(synthetic.make_queries(7, 5, 3, 64, 64)).cuda()
+  a = m.forward(video, qp)
+  b = m(video, False, qp)
+  for k in ('tracks', 'occlusion', 'expected_dist'):
+    torch.testing.assert_close(a[k], b[k], atol=1e-3, rtol=0)
+  with pytest.raises(ValueError):
+    m.train()
