@@ -531,7 +531,6 @@ class TAPIR:
     )
     return out
 
-  forward = __call__   # torch twin spelling (tapnet/torch/tapir_model.py:139)
 
   # ------------------------------------------------------------------ R6
   def construct_initial_causal_state(self, num_points: int, num_resolutions: int = 1) -> CausalState:
