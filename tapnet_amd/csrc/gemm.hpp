@@ -709,7 +709,13 @@ typedef GemmTile<2, 4, 4, 2, 3> GemmTileSquare8S3;        // 128x128, 8 waves, 3
 // operands, and re-arranging the instructions only moves the waiting from one phase to another.
 // Narrow outputs with a long K (N <= 1024) run best on 192x64, wide GELU outputs on 128x128,
 // both with EIGHT waves and two workgroups per CU.
-inline int gemm_pick_tile(int M, int N) {
+// Long-K narrow outputs (mlp2_down) and everything at >= 24576 rows (BootsTAPIR-size query sets, the
+// high-resolution config) run best on 256x128 with SIXTEEN waves in one workgroup per CU and three
+// stages (one in flight across the barrier): same-box A/B, profiles/r01_ab_bigtile.log: mlp2_down
+// 39.8 -> 37.9 us at 12288 rows and 176 -> 136 us at 49152; mlp2_up 156 -> 146 us at 49152 but
+// 33.1 -> 33.8 us at 12288 rows, where it keeps the 128x128 tile.
+inline int gemm_pick_tile(int M, int N, int K) {
+  if (N >= 512 && (M >= 24576 || (N <= 1024 && K >= 1024 && M >= 6144))) return GEMM_TILE_256x128_W16_S3;
   if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
   return GEMM_TILE_128x128_W8;
 }
@@ -789,7 +795,7 @@ inline void launch_gemm_splitk(const GemmArgs& g, int splits, float* part, hipSt
 
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, int max_grid) {
-  if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N);
+  if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N, g.K);
   switch (tile) {
     case GEMM_TILE_192x128: launch_gemm_tile_traced<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
     case GEMM_TILE_192x64: launch_gemm_tile_traced<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
@@ -801,7 +807,7 @@ inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, 
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_TILE_AUTO,
                         int max_grid = 0) {
-  if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N);
+  if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N, g.K);
   switch (tile) {
     case GEMM_TILE_192x128: launch_gemm_tile<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_S3: launch_gemm_tile<TA, TO, EPI, GemmTileBig3>(g, stream, max_grid); break;

@@ -70,7 +70,9 @@ def bench_gemm(model, reps, results, ablate=False, only_shapes=None, only_tiles=
   shapes = [('up', R, 2048, 512, 1), ('down', R, 512, 2048, 2), ('first', R, 512, 576, 0),
             ('last', R, 388, 512, 0), ('costvol', 256, 49152, 256, 0),
             # the online model's per-frame shapes (256 points x 1 frame)
-            ('up256', 256, 2048, 512, 1), ('down256', 256, 512, 2048, 2), ('costvol1', 256, 1024, 256, 0)]
+            ('up256', 256, 2048, 512, 1), ('down256', 256, 512, 2048, 2), ('costvol1', 256, 1024, 256, 0),
+            # one rank's share of config 3 (1024 queries x 48 frames)
+            ('up4', 4 * R, 2048, 512, 1), ('down4', 4 * R, 512, 2048, 2)]
   g = torch.Generator(device='cpu').manual_seed(0)
   for name, M, N, K, epi in shapes:
     nset = 3
