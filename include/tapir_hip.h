@@ -208,7 +208,7 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * 6 = 192x256, 7 = 256x128 (3 stages), 8 = 128x128 with 8 waves, 9 = 192x64 with 8 waves,
  * 10 = 128x64 with 8 waves (three workgroups per CU), 11 = 256x128 with 16 waves, 3 stages and
  * fragment prefetch, 12 = 128x128 8 waves 3 stages + prefetch, 13 = 256x128 16 waves 2 stages,
- * 14 = 256x128 16 waves 3 stages, 15 = 128x128 8 waves 3 stages; bits 8..19 of `tile`, when non-zero,
+ * 14 = 256x128 16 waves 3 stages, 15 = 128x128 8 waves 3 stages, 16 = 256x256 8 waves 2 stages; bits 8..19 of `tile`, when non-zero,
  * cap the persistent grid (tests); bit 20 (bf16 build, epi 1 | 2, trace buffer set, tiles 1 / 3 / 6 / 8):
  * the TRACE build of the kernel, whose waves write their per-k-step cycle totals
  * ([workgroup*16 + wave][8] int64: copy issue, fragment reads + MFMAs, wait for own copies, barrier,

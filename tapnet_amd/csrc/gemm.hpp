@@ -682,7 +682,8 @@ enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TI
        GEMM_TILE_192x128_S3 = 4, GEMM_TILE_192x128_WS = 5, GEMM_TILE_192x256 = 6, GEMM_TILE_256x128 = 7,
        GEMM_TILE_128x128_W8 = 8, GEMM_TILE_192x64_W8 = 9, GEMM_TILE_128x64_W8 = 10,
        GEMM_TILE_256x128_W16_PF = 11, GEMM_TILE_128x128_W8_PF = 12, GEMM_TILE_256x128_W16 = 13,
-       GEMM_TILE_256x128_W16_S3 = 14, GEMM_TILE_128x128_W8_S3 = 15, GEMM_TILE_COUNT = 16 };
+       GEMM_TILE_256x128_W16_S3 = 14, GEMM_TILE_128x128_W8_S3 = 15, GEMM_TILE_256x256 = 16,
+       GEMM_TILE_COUNT = 17 };
 typedef GemmTile<4, 2, 3, 4, 4> GemmTileBig;     // 192x128, 8 waves, 4 stages = 160 KiB: 1 per CU
 typedef GemmTile<4, 2, 3, 4, 3> GemmTileBig3;    // same, 3 stages = 120 KiB
 typedef GemmTile<2, 2, 4, 4, 2> GemmTileSquare;  // 128x128, 4 waves, 64 KiB: 2 per CU
@@ -698,6 +699,7 @@ typedef GemmTile<2, 4, 4, 2, 3, true> GemmTileSquare8P;   // 128x128, 8 waves, 9
 typedef GemmTile<4, 4, 4, 2, 2> GemmTileLong16;           // 256x128, 2 stages = 96 KiB
 typedef GemmTile<4, 4, 4, 2, 3> GemmTileLong16S3;         // 256x128, 3 stages (one in flight across the barrier)
 typedef GemmTile<2, 4, 4, 2, 3> GemmTileSquare8S3;        // 128x128, 8 waves, 3 stages = 96 KiB: 1 per CU
+typedef GemmTile<2, 4, 8, 4, 2> GemmTileHuge;             // 256x256, 8 waves (128x64 each), 2 stages = 128 KiB
 
 // Measured on MI355X at the config-2 shapes (tools/kbench.py, profiles/r01_kbench_gemm.log,
 // profiles/r01_gemm_step_trace.txt): every configuration with 16 waves per CU lands within 5 % of
@@ -715,6 +717,9 @@ typedef GemmTile<2, 4, 4, 2, 3> GemmTileSquare8S3;        // 128x128, 8 waves, 3
 // 39.8 -> 37.9 us at 12288 rows and 176 -> 136 us at 49152; mlp2_up 156 -> 146 us at 49152 but
 // 33.1 -> 33.8 us at 12288 rows, where it keeps the 128x128 tile.
 inline int gemm_pick_tile(int M, int N, int K) {
+  // wide outputs at >= 24576 rows: 256x256 (8 waves, 128x64 each: least copy volume and fewest LDS
+  // reads per MFMA; 1536 tiles at config-3 size = 6 per CU): mlp2_up 158 -> 144 us standalone
+  if (M >= 24576 && N >= 2048) return GEMM_TILE_256x256;
   if (N >= 512 && (M >= 24576 || (N <= 1024 && K >= 1024 && M >= 6144))) return GEMM_TILE_256x128_W16_S3;
   if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
   return GEMM_TILE_128x128_W8;
@@ -822,6 +827,7 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
     case GEMM_TILE_256x128_W16: launch_gemm_tile<TA, TO, EPI, GemmTileLong16>(g, stream, max_grid); break;
     case GEMM_TILE_256x128_W16_S3: launch_gemm_tile<TA, TO, EPI, GemmTileLong16S3>(g, stream, max_grid); break;
     case GEMM_TILE_128x128_W8_S3: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8S3>(g, stream, max_grid); break;
+    case GEMM_TILE_256x256: launch_gemm_tile<TA, TO, EPI, GemmTileHuge>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_WS: {   // 8 consumer + 4 producer waves, 4 stages, one workgroup per CU
       using TL = GemmTileBig;
       const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);

@@ -46,7 +46,7 @@ def run_gemm(lib, dtype, A, W, bias, resid, epi, tile, max_grid=0):
 
 
 @pytest.mark.parametrize('dtype', [_ffi.TAPIR_F32, _ffi.TAPIR_BF16])
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm_tile_shapes(dtype, tile, epi):
   lib = emu_lib()

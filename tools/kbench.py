@@ -25,7 +25,7 @@ import torch
 
 from tapnet_amd import _ffi, synthetic, tapir_model
 
-TILES = {1: '192x128s4', 2: '128x128', 3: '192x64', 4: '192x128s3', 5: '192x128ws', 6: '192x256', 7: '256x128s3', 8: '128x128w8', 9: '192x64w8', 10: '128x64w8', 11: '256x128w16pf', 12: '128x128w8pf', 13: '256x128w16', 14: '256x128w16s3', 15: '128x128w8s3'}
+TILES = {1: '192x128s4', 2: '128x128', 3: '192x64', 4: '192x128s3', 5: '192x128ws', 6: '192x256', 7: '256x128s3', 8: '128x128w8', 9: '192x64w8', 10: '128x64w8', 11: '256x128w16pf', 12: '128x128w8pf', 13: '256x128w16', 14: '256x128w16s3', 15: '128x128w8s3', 16: '256x256'}
 R = 256 * 48
 
 
