@@ -421,10 +421,14 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) arrive(fa0[i]);
       sched_fence();
-      gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
+      // tiles with 128 accumulator registers (256x256) cannot also hold both halves' fragments:
+      // their second-half reads follow the first-half MFMAs (32 MFMAs of the SIMD's other wave cover them)
+      constexpr bool SEQ = FM * FN >= 32;
+      if (!SEQ) gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1);
       sched_fence();
       gemm_mfma_frags<TA, TL>(fa0, fw0, acc);
       sched_fence();
+      if (SEQ) { gemm_load_frags<TL, PAIR>(bufs[S], a_row, w_row, fr, fg, 1, fa1, fw1); sched_fence(); }
 #pragma unroll
       for (int j = 0; j < FN; ++j) arrive(fw1[j]);
 #pragma unroll
