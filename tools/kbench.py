@@ -3,7 +3,11 @@
 config-2 shapes (256 queries x 48 frames = 12288 token rows), timed with events on the
 launch stream, checked against a torch reference, reported against the roofline.
 
-    python tools/kbench.py [--what gemm,mix,mixer,backbone] [--reps 40] [--out gpurun_out/kbench.json]
+    python tools/kbench.py [--what gemm,mix,mixer,backbone,norm,gemmtrace,gemmsteps,mixtrace,cvtrace]
+                           [--shapes up,down,up4,...] [--tiles 3,8,14,...] [--reps 40] [--out gpurun_out/kbench.json]
+
+--what gemmtrace / gemmsteps / mixtrace / cvtrace print in-kernel phase traces (wall-clock stamps or
+per-wave cycle totals written by the TRACE builds of the kernels), norm the backbone glue kernels.
 
 GEMM rows: every tile shape of gemm.hpp (tapir_debug_gemm hook) on the mixer shapes
 (up: [R,512]x[512,2048]+GELU -> bf16; down: [R,2048]x[2048,512]+skip -> f32), the first /
@@ -61,7 +65,7 @@ def gelu_tanh(x):
   return torch.nn.functional.gelu(x, approximate='tanh')
 
 
-def bench_gemm(model, reps, results, ablate=False, only_shapes=None, only_tiles=None, dbg_list=None):
+def bench_gemm(model, reps, results, only_shapes=None, only_tiles=None):
   lib, ctx = model._lib, model._ctx
   bf = model.dtype == 'bfloat16'
   tdt = torch.bfloat16 if bf else torch.float32
@@ -92,15 +96,9 @@ def bench_gemm(model, reps, results, ablate=False, only_shapes=None, only_tiles=
     bytes_alg = M * K * es + N * K * es + M * N * (es if epi == 1 else 4) + (M * N * 4 if epi == 2 else 0)
     if only_shapes and name not in only_shapes:
       continue
-    variants = [(t, n, 0) for t, n in TILES.items() if not only_tiles or t in only_tiles]
-    if dbg_list:
-      variants = [(t, f'{n}/dbg{d}', d) for t, n, _ in variants for d in dbg_list]
-    if ablate and name in ('up', 'down'):
-      for dbg, dn in ((1, 'noDMA'), (2, 'noMFMA'), (4, 'noStore'), (8, 'noGELU'), (12, 'noStore+noGELU'),
-                      (3, 'noDMA+noMFMA'), (7, 'onlyBarriers+epi')):
-        variants += [(1, f'192x128s4/{dn}', dbg), (2, f'128x128/{dn}', dbg)]
-    for tile, tname, dbg in variants:
-      def run(i, tile=tile | (dbg << 20)):
+    variants = [(t, n) for t, n in TILES.items() if not only_tiles or t in only_tiles]
+    for tile, tname in variants:
+      def run(i, tile=tile):
         k = i % nset
         rc = lib.tapir_debug_gemm(ctx, A[k].data_ptr(), K, W.data_ptr(), K, bias.data_ptr(),
                                   resid.data_ptr() if resid is not None else None, N,
@@ -108,7 +106,7 @@ def bench_gemm(model, reps, results, ablate=False, only_shapes=None, only_tiles=
         assert rc == 0, lib.tapir_last_error(ctx)
       run(0)
       torch.cuda.synchronize()
-      err = float((C[0].float() - ref).abs().max()) if dbg == 0 else -1.0
+      err = float((C[0].float() - ref).abs().max())
       t = timeit(run, reps)
       tb = timeit_batch(run, reps)
       row = dict(kernel=f'gemm_{name}', tile=tname, M=M, N=N, K=K, dtype=model.dtype, max_err=round(err, 5),
@@ -347,10 +345,8 @@ def main():
   ap.add_argument('--what', default='gemm,mix,mixer')
   ap.add_argument('--reps', type=int, default=40)
   ap.add_argument('--dtypes', default='bfloat16')
-  ap.add_argument('--ablate', action='store_true')
   ap.add_argument('--shapes', default='')
   ap.add_argument('--tiles', default='')
-  ap.add_argument('--dbg', default='')
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'kbench.json'))
   args = ap.parse_args()
   what = set(args.what.split(','))
@@ -360,9 +356,8 @@ def main():
     w = synthetic.make_weights(0, 0, False, backbone=need_bb)
     model = tapir_model.TAPIR(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0')
     if 'gemm' in what:
-      bench_gemm(model, args.reps, results, args.ablate, set(args.shapes.split(',')) if args.shapes else None,
-                 set(int(t) for t in args.tiles.split(',')) if args.tiles else None,
-                 [int(d) for d in args.dbg.split(',')] if args.dbg else None)
+      bench_gemm(model, args.reps, results, set(args.shapes.split(',')) if args.shapes else None,
+                 set(int(t) for t in args.tiles.split(',')) if args.tiles else None)
     if 'mix' in what:
       bench_mix(model, args.reps, results)
     if 'gemmtrace' in what:
