@@ -270,6 +270,9 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
 // is folded into the first convolution's weights and the second convolution's biases into one
 // constant; and every operation acts on the thread's TWO ADJACENT channels, so the compiler emits
 // packed f32 math (v_pk_fma_f32 / v_pk_mul_f32: 2 lanes-worth per issue on the SIMD-16 VALU).
+// (Writing the stream with explicit 2-wide vector types packs the GELU's polynomial too -- 1941 ->
+// 1781 VALU instructions -- but needs 134 VGPRs; capped at 128 for four waves per SIMD it spills and
+// measured 29.3 us against 27.9, tools/ab_mix.sh.)
 //   rows  r = 0 .. TC+3  <->  frames tau = t0 - 2 + r;  outputs o = t0 .. t0 + TC - 1
 //   xn_r            = LN1(x)[tau]            (0 outside the clip: SAME padding of conv 1)
 //   g_{r-1}[m]      = gelu(b1[m] + sum_k w1'[m][k] xn_{r-2+k})     (0 outside the clip)
