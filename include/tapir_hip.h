@@ -74,6 +74,13 @@ int tapir_finalize_weights(tapir_ctx* ctx);
  * h x w of the low-resolution pyramid), so later calls allocate nothing. */
 int tapir_reserve(tapir_ctx* ctx, int B, int Q, int T, int max_lowres_h, int max_lowres_w);
 
+/* Counted pin: on != 0 adds a pin, on == 0 removes one.  While pinned, a call that would have to
+ * GROW a workspace fails with TAPIR_ERR_INVALID instead of reallocating it.  Set after tapir_reserve() and before capturing calls into a
+ * hipGraph: the graph holds the workspace pointers, so a later, larger call on the same context
+ * must not free them (it gets an error; reserve the largest shape first or use a second context).
+ * Calls on one context also share these workspaces: one stream at a time per context. */
+int tapir_pin_workspaces(tapir_ctx* ctx, int on);
+
 /* einsum('bnc,bthwc->tbnhw') of TAPIR.tracks_from_cost_volume
  * (tapir_model.py:433) -- the north_star's "build_cost_volume".
  * qfeat [B,Q,C], grid [B,T,h,w,C] -> volume [B,Q,T,h,w] (the reference's

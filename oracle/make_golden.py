@@ -43,6 +43,12 @@ CASES = {
     # two refinement resolutions -> 8 iterations, level averaging (:1142-1152)
     'multires': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
                      causal=False, res=64, video=128, T=3, Q=6, wseed=14),
+    # online with a MID-STREAM POINT REPLACEMENT (update_query_features + fresh causal state for
+    # the replaced points, torch/tapir_model.py:774-806; tapir_model.py:1172-1203) on a frame
+    # larger than initial_resolution (two refinement levels -> 8 iterations of causal state)
+    'causal_update': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
+                          causal=True, res=64, video=128, T=5, Q=6, wseed=15,
+                          update_frame=2, update_idx=(1, 4)),
 }
 
 
@@ -130,6 +136,23 @@ def make_case(tm, name, cfg):
       state = [{k: v.clone() for k, v in d.items()} for d in state]
       tr, oc, ex = [], [], []
       for t in range(cfg['T']):
+        if t == cfg.get('update_frame', -1):
+          # replace points: query features from THIS frame alone (live_demo.py:128-141)
+          idx = list(cfg['update_idx'])
+          new_q = synthetic.make_queries(cfg['wseed'] + 300, len(idx), 1, cfg['video'], cfg['video'])
+          out['update_query_points'] = new_q
+          out['update_idx'] = np.array(idx, np.int32)
+          fg_u = model.get_feature_grids(tv[:, t:t + 1], False)
+          new_qf = model.get_query_features(tv[:, t:t + 1], False, torch.from_numpy(new_q), fg_u)
+          # the twin updates in place; levels that share a tensor are written twice (same values)
+          qf = tm.QueryFeatures(tuple(x.clone() for x in qf.lowres), tuple(x.clone() for x in qf.hires),
+                                qf.resolutions)
+          state = [{k: v.clone() for k, v in d.items()} for d in state]
+          qf, state = model.update_query_features(qf, new_qf, idx, state)
+          for i in sorted(set(level_src)):
+            out[f'updated_qlowres_{i}'] = np_(qf.lowres[i])
+            out[f'updated_qhires_{i}'] = np_(qf.hires[i])
+          out['state_after_update_block_3_causal_1'] = np_(state[1]['block_3_causal_1'])
         fg_t = model.get_feature_grids(tv[:, t:t + 1], False)
         traj = model.estimate_trajectories(
             (cfg['video'], cfg['video']), False, fg_t, qf, None,

@@ -568,5 +568,33 @@ def construct_initial_causal_state(num_points, num_resolutions=1, num_blocks=12,
           for _ in range(num_resolutions * 4)]
 
 
+def update_query_features(q_lowres, q_hires, new_q_lowres, new_q_hires, idx_to_update,
+                          causal_state=None, num_blocks=12):
+  """TAPIR.update_query_features (tapir_model.py:1172-1203; torch twin :774-806), functional
+  like the JAX model: entries ``idx_to_update`` of every level's query features are replaced by
+  the new ones and, if a causal state is given, the same entries of every state tensor are
+  replaced by a fresh (zero) state (construct_initial_causal_state for len(idx) points).
+
+  q_lowres / q_hires: per-level lists of [B,N,C]; new_*: per-level lists of [B,len(idx),C].
+  Returns (q_lowres, q_hires) or (q_lowres, q_hires, causal_state)."""
+  if isinstance(idx_to_update, int):
+    idx_to_update = (idx_to_update,)
+  idx = np.array(idx_to_update)
+
+  def upd(s1, s2):
+    out = np.array(s1, copy=True)
+    out[:, idx] = s2
+    return out
+
+  ql = [upd(a, b) for a, b in zip(q_lowres, new_q_lowres)]
+  qh = [upd(a, b) for a, b in zip(q_hires, new_q_hires)]
+  if causal_state is None:
+    return ql, qh
+  init = construct_initial_causal_state(len(idx), len(q_lowres) - 1, num_blocks)
+  assert len(init) == len(causal_state)
+  new_state = [{k: upd(d[k], z[k]) for k in d} for d, z in zip(causal_state, init)]
+  return ql, qh, new_state
+
+
 def cast_weights(weights, dtype):
   return {k: np.asarray(v).astype(dtype) for k, v in weights.items()}

@@ -59,6 +59,7 @@ PROTOTYPES = {
     'tapir_set_weight': (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     'tapir_finalize_weights': (c_int, [c_void_p]),
     'tapir_reserve': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    'tapir_pin_workspaces': (c_int, [c_void_p, c_int]),
     'tapir_build_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_void_p, c_void_p]),
     'tapir_tracks_from_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -60,6 +60,7 @@ struct tapir_ctx {
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
   DevBuf norm_ss;   // [N, C, 2] scale / shift of the InstanceNorm being applied
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
+  int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
   // which caller grid each cast slot currently holds (valid within one call)
   const float* cast_src[kMaxLevels] = {nullptr, nullptr, nullptr};
@@ -114,6 +115,12 @@ struct ProfScope {
 
 int ensure(tapir_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return TAPIR_OK;
+  // A captured hipGraph (tapnet_amd.online.OnlineTracker) has the workspace pointers baked in:
+  // freeing one under it would make every later replay read and write freed memory.
+  if (c->pinned)
+    return fail(c, TAPIR_ERR_INVALID,
+                "workspace growth while pinned (a captured hipGraph uses the current buffers): "
+                "tapir_reserve() the largest shape before capturing, or use a separate context");
   if (b.p) HIP_TRY(c, hipFree(b.p));
   b.p = nullptr; b.cap = 0;
   const size_t want = (bytes + 255) / 256 * 256;
@@ -749,6 +756,13 @@ int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
     TRY(ensure(c, c->grid_cast[1], frames * mh * mw * kLowresDim * es));
   }
   if (c->cfg.pyramid_level >= 1) TRY(ensure(c, c->pooled, frames * (mh / 2) * (mw / 2) * kLowresDim * es));
+  return TAPIR_OK;
+}
+
+int tapir_pin_workspaces(tapir_ctx* c, int on) {
+  if (!c) return TAPIR_ERR_INVALID;
+  if (on) ++c->pinned;
+  else if (c->pinned > 0) --c->pinned;
   return TAPIR_OK;
 }
 

@@ -25,7 +25,7 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from tapnet_amd import _ffi
+from tapnet_amd import _ffi, model_utils
 from tapnet_amd.tapir_model import TAPIR, FeatureGrids, QueryFeatures, _res_hw
 
 
@@ -40,7 +40,14 @@ class OnlineTracker:
     self.hw = (int(frame_hw[0]), int(frame_hw[1]))
     self.use_graph = use_graph
     dev = model.device
-    self.ni = model.num_pips_iter   # one refinement level, as in the live demos
+    # refinement levels of this frame size, fixed for the session (the reference sizes the state the
+    # same way: len(query_features.resolutions) - 1 levels x num_pips_iter iterations,
+    # tapir_clustering.py:819-820, live_demo.py:120): one level when the frame has
+    # initial_resolution, more for larger frames (model_utils.generate_default_resolutions)
+    self.refinement_resolutions = [tuple(int(v) for v in r) for r in
+                                   model_utils.generate_default_resolutions(self.hw, model.initial_resolution)]
+    self.nl = 1 + len(self.refinement_resolutions)
+    self.ni = model.num_pips_iter * (self.nl - 1)
     nb = model.num_mixer_blocks
     self._frame = torch.zeros((1, 1, self.hw[0], self.hw[1], 3), device=dev)
     self._state = [(torch.zeros((self.ni, nb, self.n, 2, 512), device=dev),
@@ -52,13 +59,28 @@ class OnlineTracker:
     self._qf: Optional[QueryFeatures] = None
     self._graphs = [None, None]
     self._warm = False
+    self._pinned = False
+
+  def close(self) -> None:
+    """Drops the captured graphs and releases this session's pin on the model's workspaces."""
+    self._graphs = [None, None]
+    self._warm = False
+    if self._pinned:
+      self._pinned = False
+      try:
+        self.model._lib.tapir_pin_workspaces(self.model._ctx, 0)
+      except Exception:   # interpreter shutdown / model already destroyed
+        pass
+
+  def __del__(self):
+    self.close()
 
   # ------------------------------------------------------------------ points
   def init(self, frames, query_points) -> QueryFeatures:
     """live_demo.online_model_init: query features of `query_points` [1,N,3] (t,y,x) in `frames`
     [1,T,H,W,3] (typically the first frame).  Resets the causal state."""
     m = self.model
-    fg = m.get_feature_grids(m._dev(frames))
+    fg = m.get_feature_grids(m._dev(frames), False, self.refinement_resolutions)
     qf = m.get_query_features(m._dev(frames), False, m._dev(query_points), fg)
     return self.set_query_features(qf)
 
@@ -70,6 +92,9 @@ class OnlineTracker:
                        qf.resolutions)
     if qf.lowres[0].shape[1] != self.n:
       raise ValueError(f'expected {self.n} query points')
+    if len(qf.lowres) != self.nl:
+      raise ValueError(f'query features hold {len(qf.lowres)} levels, the session {self.nl} '
+                       f'(frame {self.hw}, initial resolution {self.model.initial_resolution})')
     if self._qf is None:
       self._qf = QueryFeatures(tuple(t.clone() for t in qf.lowres), tuple(t.clone() for t in qf.hires),
                                qf.resolutions)
@@ -84,7 +109,7 @@ class OnlineTracker:
     """TAPIR.update_query_features (tapir_model.py:1172-1203), in place: new query features and a
     zero causal state for the points `idx`."""
     m = self.model
-    fg = m.get_feature_grids(m._dev(frames))
+    fg = m.get_feature_grids(m._dev(frames), False, self.refinement_resolutions)
     new = m.get_query_features(m._dev(frames), False, m._dev(query_points), fg)
     ix = torch.as_tensor(np.asarray(idx), device=m.device, dtype=torch.long)
     for d, s in zip(self._qf.lowres + self._qf.hires, new.lowres + new.hires):
@@ -97,8 +122,9 @@ class OnlineTracker:
   def _run(self, src: int) -> None:
     """backbone(frame) + estimate_trajectories with state src -> 1 - src, outputs into self._out"""
     m = self.model
-    fg = m.get_feature_grids(self._frame)
+    fg = m.get_feature_grids(self._frame, False, self.refinement_resolutions)
     nl = len(fg.lowres)
+    assert nl == self.nl   # the state / output buffers are sized for exactly these levels
     a = _ffi.TapirTrajArgs()
     a.B, a.Q, a.T, a.n_levels = 1, self.n, 1, nl
     keep = []
@@ -123,7 +149,8 @@ class OnlineTracker:
   def _prepare(self) -> None:
     """workspaces, MIOpen solver search and scratch buffers: everything that allocates"""
     m = self.model
-    m.reserve(1, self.n, 1, (m.initial_resolution[0] // 8, m.initial_resolution[1] // 8))
+    big = max([tuple(m.initial_resolution)] + self.refinement_resolutions, key=lambda r: r[0] * r[1])
+    m.reserve(1, self.n, 1, (big[0] // 8, big[1] // 8))
     saved = [(a.clone(), b.clone()) for a, b in self._state]
     for _ in range(2):
       self._run(0)
@@ -131,6 +158,10 @@ class OnlineTracker:
     for (a, b), (sa, sb) in zip(self._state, saved):
       a.copy_(sa); b.copy_(sb)
     if self.use_graph:
+      # the graphs bake in the engine's workspace pointers: from here on a larger call on this
+      # model gets an error instead of reallocating them under the graphs (include/tapir_hip.h)
+      m._check(m._lib.tapir_pin_workspaces(m._ctx, 1), 'tapir_pin_workspaces')
+      self._pinned = True
       for src in (0, 1):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

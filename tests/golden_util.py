@@ -17,6 +17,9 @@ CASES = {
                    causal=True, res=64, video=64, T=4, Q=6, wseed=13),
     'multires': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
                      causal=False, res=64, video=128, T=3, Q=6, wseed=14),
+    'causal_update': dict(pyramid_level=1, extra_convs=False, softmax_temperature=20.0,
+                          causal=True, res=64, video=128, T=5, Q=6, wseed=15,
+                          update_frame=2, update_idx=(1, 4)),
 }
 
 

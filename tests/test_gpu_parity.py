@@ -441,3 +441,80 @@ def test_torch_twin_call_surface():
     torch.testing.assert_close(a[k], b[k], atol=1e-3, rtol=0)
   with pytest.raises(ValueError):
     m.train()
+
+
+@pytest.mark.gpu
+def test_update_query_features_golden():
+  """R6: TAPIR.update_query_features + construct_initial_causal_state through the public API, with
+  the reference's feature grids, vs the reference torch twin's streaming run with a mid-stream
+  point replacement (fixture causal_update: 128x128 frames, two refinement levels = 8 iterations
+  of causal state), 1e-3."""
+  from tapnet_amd import tapir_model
+  cfg, g, w = load_case('causal_update')
+  m = _model(cfg, w)
+  fg_all = _grids(g)
+  qf = m.get_query_features(g['video'], False, g['query_points'], fg_all)
+  nres = len(g['res_list']) - 1
+  state = m.construct_initial_causal_state(cfg['Q'], nres)
+  assert len(state) == 8
+  tr, oc, ex = [], [], []
+  for t in range(cfg['T']):
+    fg = tapir_model.FeatureGrids(tuple(torch.as_tensor(x[:, t:t + 1]) for x in g['lowres']),
+                                  tuple(torch.as_tensor(x[:, t:t + 1]) for x in g['hires']),
+                                  tuple(g['res_list']))
+    if t == cfg['update_frame']:
+      new_qf = m.get_query_features(g['video'][:, t:t + 1], False, g['update_query_points'], fg)
+      qf, state = m.update_query_features(qf, new_qf, [int(i) for i in g['update_idx']], state)
+      for i in sorted(set(int(s) for s in g['level_src'])):
+        np.testing.assert_allclose(qf.lowres[i].cpu().numpy(), g[f'updated_qlowres_{i}'], atol=2e-6)
+        np.testing.assert_allclose(qf.hires[i].cpu().numpy(), g[f'updated_qhires_{i}'], atol=2e-6)
+      np.testing.assert_allclose(state[1]['block_3_causal_1'].cpu().numpy(),
+                                 g['state_after_update_block_3_causal_1'], atol=1e-3)
+    traj = m.estimate_trajectories((cfg['video'], cfg['video']), False, fg, qf, None,
+                                   causal_context=state, get_causal_context=True)
+    state = traj['causal_context']
+    tr.append(traj['tracks'][-1].cpu().numpy()); oc.append(traj['occlusion'][-1].cpu().numpy())
+    ex.append(traj['expected_dist'][-1].cpu().numpy())
+  np.testing.assert_allclose(np.concatenate(tr, 2), g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(oc, 2), g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(ex, 2), g['expected_dist'], atol=1e-3)
+  np.testing.assert_allclose(state[-1]['block_11_causal_2'].cpu().numpy(),
+                             g['state_last_block_11_causal_2'], atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_online_tracker_multilevel_update_points_golden(use_graph):
+  """f3: tapnet_amd.online.OnlineTracker on frames LARGER than initial_resolution (128x128 vs 64x64:
+  two refinement levels, 8 iterations of packed state -- the session sizes its state / output
+  buffers from generate_default_resolutions) with OnlineTracker.update_points mid-stream, video ->
+  tracks entirely on the GPU (HIP backbone + hipGraph-replayed step), against the REFERENCE torch
+  twin's outputs (fixture causal_update).  The backbone's own deviation from the reference
+  (2e-4 on the grids, test_backbone_golden_gpu) is inside the 2e-3 px / logit bound."""
+  from tapnet_amd import online
+  cfg, g, w = load_case('causal_update')
+  m = _model(cfg, w)
+  video = torch.as_tensor(g['video']).cuda()
+  trk = online.OnlineTracker(m, cfg['Q'], (cfg['video'], cfg['video']), use_graph=use_graph)
+  assert trk.nl == 3 and trk.ni == 8
+  trk.init(video, torch.as_tensor(g['query_points']).cuda())   # query features from the whole clip
+  for t in range(cfg['T']):
+    if t == cfg['update_frame']:
+      trk.update_points([int(i) for i in g['update_idx']], video[:, t:t + 1],
+                        torch.as_tensor(g['update_query_points']).cuda())
+    out = trk.step(video[:, t:t + 1])
+    np.testing.assert_allclose(out['tracks'].cpu().numpy(), g['tracks'][:, :, t:t + 1], atol=2e-3,
+                               err_msg=f'frame {t}')
+    np.testing.assert_allclose(out['occlusion'].cpu().numpy(), g['occlusion'][:, :, t:t + 1], atol=2e-3)
+    np.testing.assert_allclose(out['expected_dist'].cpu().numpy(), g['expected_dist'][:, :, t:t + 1],
+                               atol=2e-3)
+  st = trk.causal_state
+  np.testing.assert_allclose(st[-1]['block_11_causal_2'].cpu().numpy(),
+                             g['state_last_block_11_causal_2'], atol=2e-3)
+  # a larger call on the same model must not reallocate the workspaces the graphs captured
+  if use_graph:
+    big = synthetic.make_queries(1, 64, cfg['T'], cfg['video'], cfg['video'])
+    with pytest.raises(ValueError, match='pinned'):
+      m(g['video'], False, big)
+    out2 = trk.step(video[:, 0:1])   # the session still works
+    assert torch.isfinite(out2['tracks']).all()

@@ -1,0 +1,166 @@
+"""`-m gpu`: parity AT THE BENCHMARKED CONFIGURATION (BASELINE.json configs[1]: 256x256x48 clip,
+256 queries) -- the production kernel paths (persistent multi-tile GEMM walk, interior epilogues,
+residual-as-accumulator across tiles, the fused mixer) against the numpy oracle.
+
+The oracle is per-query independent (tapnet/tapvid/README.md:32-38; chunk loop
+tapir_model.py:952), so comparing a SUBSET of the queries of the full-size call with the oracle
+run on that subset alone is exact, and costs ~10 s of numpy per case instead of minutes.
+
+Tolerances:
+  * f32 build: 1e-3 abs (north_star) on tracks / occlusion / expected_dist, final and per
+    iteration, gated on a clear argmax of the cost-volume heat map (soft-argmax is discontinuous
+    at ties, model_utils.py:232).
+  * bf16 build END TO END (bf16 backbone + bf16 hot path) vs the f32 oracle: the drift
+    distribution is recorded (gpurun_out/accuracy_bf16.json -> profiles/) and gated; see
+    test_bf16_end_to_end_vs_oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import tapir_oracle as O  # noqa: E402
+from tapnet_amd import synthetic  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = {
+    'tapir': dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0),
+    'bootstapir': dict(pyramid_level=1, extra_convs=True, softmax_temperature=10.0),
+}
+T, S = 48, 256
+
+
+def _clip():
+  return synthetic.make_video(7, T, S, S)
+
+
+def _np_grids(fg):
+  return ([x.cpu().numpy() for x in fg.lowres], [x.cpu().numpy() for x in fg.hires],
+          [tuple(r) for r in fg.resolutions])
+
+
+def _oracle_subset(w, kw, video_shape, grids, qp, idx):
+  lows, his, res = grids
+  sub = qp[:, idx]
+  ref = O.tapir_from_grids(w, video_shape, lows, his, res, sub, pyramid_level=kw['pyramid_level'],
+                           softmax_temperature=kw['softmax_temperature'])
+  ql, _ = O.get_query_features(lows, his, res, sub, video_shape)
+  _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], sub,
+                                          softmax_temperature=kw['softmax_temperature'],
+                                          return_stages=True)
+  clear = (st['top2_rel_gap'] > 1e-4).all(axis=-1)   # [1, n]: every frame has a clear argmax
+  return ref, clear
+
+
+def _check_against(out, ref, idx, clear, atol):
+  assert clear.mean() > 0.8, clear.mean()
+  for k in ('tracks', 'occlusion', 'expected_dist'):
+    np.testing.assert_allclose(out[k][:, idx][clear], ref[k][clear], atol=atol, err_msg=k)
+  n_it = len(ref['unrefined_tracks'])
+  assert len(out['unrefined_tracks']) == n_it
+  for i in range(n_it):
+    for k in ('unrefined_tracks', 'unrefined_occlusion', 'unrefined_expected_dist'):
+      np.testing.assert_allclose(out[k][i][:, idx][clear], ref[k][i][clear], atol=atol,
+                                 err_msg=f'{k}[{i}]')
+
+
+@pytest.mark.parametrize('name,Q', [('tapir', 256), ('bootstapir', 256), ('tapir', 512)])
+def test_f32_full_size_vs_oracle(name, Q):
+  """f32 TAPIR.__call__ at 256x256x48 with Q = 256 (R = 12288 token rows: the config-2 tiles)
+  and Q = 512 (R = 24576: the large-row tiles), TAPIR and BootsTAPIR kwargs, against
+  O.tapir_from_grids on a 16-query subset: final outputs and every unrefined iteration."""
+  from tapnet_amd import tapir_model
+  kw = KW[name]
+  w = synthetic.make_weights(3 if name == 'tapir' else 5, kw['pyramid_level'], kw['extra_convs'])
+  video = _clip()
+  qp = synthetic.make_queries(8 + Q, Q, T, S, S)
+  m = tapir_model.TAPIR(**kw, weights=w, device='cuda:0')
+  fg = m.get_feature_grids(torch.as_tensor(video).cuda())
+  out = m(video, False, qp, feature_grids=fg)
+  idx = np.random.default_rng(Q).choice(Q, 16, replace=False)
+  ref, clear = _oracle_subset(w, kw, video.shape, _np_grids(fg), qp, idx)
+  _check_against(out, ref, idx, clear, 1e-3)
+
+
+def _stats(d):
+  d = np.asarray(d, np.float64).ravel()
+  return dict(median=float(np.median(d)), p90=float(np.percentile(d, 90)),
+              p99=float(np.percentile(d, 99)), max=float(d.max()))
+
+
+def test_bf16_end_to_end_vs_oracle():
+  """The configuration bench.py times -- bf16 backbone (bf16 activations through the ResNet, bf16
+  MIOpen convolutions, bf16 glue kernels) + bf16 hot path -- against the f32 oracle fed with the
+  f32 build's feature grids (themselves pinned to the reference by test_backbone_golden_gpu).
+
+  Records the drift distribution of tracks (px) and occlusion / expected_dist logits, and the
+  argmax-flip rate of the cost-volume initialisation (a different heat-map cell wins: an 8-px
+  jump of unrefined_tracks[0] that refinement may or may not pull back).  Gates (SURVEY.md 7
+  probe: median 8e-3 px, p99 1.5e-2 px for bf16 operands; this test also carries the bf16
+  BACKBONE, whose feature error moves the soft-argmax): median <= 2e-2 px, p99 <= 1e-1 px and
+  <= 0.25 logits outside flips, flip rate <= 1 %."""
+  from tapnet_amd import tapir_model
+  kw = KW['tapir']
+  w = synthetic.make_weights(3, kw['pyramid_level'], kw['extra_convs'])
+  video = _clip()
+  Q = 256
+  qp = synthetic.make_queries(8 + Q, Q, T, S, S)
+  m32 = tapir_model.TAPIR(**kw, weights=w, device='cuda:0')
+  fg32 = m32.get_feature_grids(torch.as_tensor(video).cuda())
+  idx = np.random.default_rng(1).choice(Q, 32, replace=False)
+  ref, clear = _oracle_subset(w, kw, video.shape, _np_grids(fg32), qp, idx)
+  del m32
+  m16 = tapir_model.TAPIR(**kw, weights=w, device='cuda:0', dtype='bfloat16')
+  out = m16(video, False, qp)     # bf16 backbone inside
+  # feature grids of the bf16 backbone vs the f32 one (both L2-normalised)
+  fg16 = m16.get_feature_grids(torch.as_tensor(video).cuda())
+  cos_low = float((fg16.lowres[0] * fg32.lowres[0]).sum(-1).min())
+  cos_hi = float((fg16.hires[0] * fg32.hires[0]).sum(-1).min())
+  d0 = np.linalg.norm(out['unrefined_tracks'][0][:, idx] - ref['unrefined_tracks'][0], axis=-1)
+  flip = d0 > 4.0                                   # another cell of the 8-px grid won
+  keep = clear[..., None] & ~flip
+  d = np.linalg.norm(out['tracks'][:, idx] - ref['tracks'], axis=-1)
+  do = np.abs(out['occlusion'][:, idx] - ref['occlusion'])
+  de = np.abs(out['expected_dist'][:, idx] - ref['expected_dist'])
+  rec = dict(config='TAPIR kwargs, 256x256x48, Q=256 (32-query subset vs the f32 numpy oracle)',
+             build='bf16 backbone + bf16 hot path',
+             tracks_px=_stats(d[keep]), occlusion_logit=_stats(do[keep]),
+             expected_dist_logit=_stats(de[keep]),
+             argmax_flip_rate=float(flip[clear].mean()),
+             tracks_px_incl_flips=_stats(d[clear]),
+             min_cos_lowres=cos_low, min_cos_hires=cos_hi, points=int(keep.sum()))
+  os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+  with open(os.path.join(ROOT, 'gpurun_out', 'accuracy_bf16.json'), 'w') as f:
+    json.dump(rec, f, indent=1)
+  print(json.dumps(rec))
+  assert rec['argmax_flip_rate'] <= 0.01, rec
+  assert rec['tracks_px']['median'] <= 2e-2 and rec['tracks_px']['p99'] <= 1e-1, rec
+  assert rec['occlusion_logit']['p99'] <= 0.25 and rec['expected_dist_logit']['p99'] <= 0.25, rec
+  assert cos_low > 0.995 and cos_hi > 0.995, rec
+
+
+@pytest.mark.parametrize('tag,extra', [('tapir', False), ('boots', True)])
+def test_bf16_backbone_golden(tag, extra):
+  """bf16 Backbone.features (what bench.py runs) vs the reference's feature grids
+  (tests/golden/backbone.npz).  The grids are unit vectors per pixel (components ~ 1/16);
+  tolerance: every pixel's cosine to the reference > 0.998 and max abs component error 1.5e-2
+  (bf16 has 8 mantissa bits and the activations pass 17 convolutions + norms in bf16)."""
+  from tests.golden_util import GOLDEN_DIR
+  from tapnet_amd import tapir_model
+  g = np.load(os.path.join(GOLDEN_DIR, 'backbone.npz'))
+  w = synthetic.make_weights(21, 1, extra)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=extra, weights=w, device='cuda:0',
+                        dtype='bfloat16')
+  v = torch.as_tensor(g['video']).cuda()
+  low, hi = m._backbone.features(v.reshape(-1, 64, 64, 3))
+  for got, ref in ((low, g[f'{tag}_lowres'][0]), (hi, g[f'{tag}_hires'][0])):
+    got = got.float().cpu().numpy()
+    cos = (got * ref).sum(-1)
+    err = np.abs(got - ref).max()
+    print(tag, 'min cos', cos.min(), 'max abs err', err)
+    assert cos.min() > 0.998, cos.min()
+    assert err < 1.5e-2, err

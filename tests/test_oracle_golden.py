@@ -111,3 +111,42 @@ def test_causal_streaming():
   whole = O.estimate_trajectories(w, (cfg['video'], cfg['video']), g['lowres'], g['hires'],
                                   g['res_list'], ql, qh, None, **kw)
   np.testing.assert_allclose(whole['tracks'][-1], g['tracks'], atol=1e-3)
+
+
+def test_causal_streaming_with_point_update():
+  """Online path with a mid-stream point replacement (update_query_features + zero causal state
+  for the replaced points, tapir_model.py:1172-1203) on a 128x128 frame (two refinement levels,
+  8 iterations of state), vs the reference torch twin's outputs (fixture causal_update)."""
+  cfg, g, w = load_case('causal_update')
+  kw = oracle_kwargs(cfg)
+  kw.pop('num_pips_iter')
+  ql, qh = list(g['qlowres']), list(g['qhires'])
+  nres = len(g['res_list']) - 1
+  assert nres == 2
+  state = O.construct_initial_causal_state(cfg['Q'], nres)
+  assert len(state) == 8
+  tr, oc, ex = [], [], []
+  vshape1 = (1, 1) + g['video'].shape[2:]
+  for t in range(cfg['T']):
+    lo = [x[:, t:t + 1] for x in g['lowres']]
+    hi = [x[:, t:t + 1] for x in g['hires']]
+    if t == cfg['update_frame']:
+      nl, nh = O.get_query_features(lo, hi, g['res_list'], g['update_query_points'], vshape1)
+      ql, qh, state = O.update_query_features(ql, qh, nl, nh, g['update_idx'], state)
+      src = g['level_src']
+      for i in sorted(set(int(s) for s in src)):
+        np.testing.assert_allclose(ql[i], g[f'updated_qlowres_{i}'], atol=2e-6)
+        np.testing.assert_allclose(qh[i], g[f'updated_qhires_{i}'], atol=2e-6)
+      np.testing.assert_allclose(state[1]['block_3_causal_1'], g['state_after_update_block_3_causal_1'],
+                                 atol=1e-3)
+      assert not state[1]['block_3_causal_1'][:, g['update_idx']].any()
+    traj = O.estimate_trajectories(w, (cfg['video'], cfg['video']), lo, hi, g['res_list'],
+                                   ql, qh, None, causal_context=state,
+                                   get_causal_context=True, **kw)
+    state = traj['causal_context']
+    tr.append(traj['tracks'][-1]); oc.append(traj['occlusion'][-1]); ex.append(traj['expected_dist'][-1])
+  np.testing.assert_allclose(np.concatenate(tr, 2), g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(oc, 2), g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(np.concatenate(ex, 2), g['expected_dist'], atol=1e-3)
+  np.testing.assert_allclose(state[-1]['block_0_causal_1'], g['state_last_block_0_causal_1'], atol=1e-3)
+  np.testing.assert_allclose(state[-1]['block_11_causal_2'], g['state_last_block_11_causal_2'], atol=1e-3)
