@@ -177,7 +177,9 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 #define TAPIR_PROF_PATCH 3      /* pyramid patch correlation (patch_corr_kernel)           */
 #define TAPIR_PROF_CV_HEADS 4   /* cost-volume heads (cv_heads_kernel)                     */
 #define TAPIR_PROF_CV_GEMM 5    /* cost-volume einsum GEMM                                 */
-#define TAPIR_PROF_KINDS 6
+#define TAPIR_PROF_MIXER 6      /* track-resident fused PIPs mixer (mixer_fused_kernel): one launch
+                                   per refinement iteration = input Linear + all blocks + output Linear */
+#define TAPIR_PROF_KINDS 7
 /* on: bit mask of kernel classes (1 << TAPIR_PROF_*) to bracket with events; -1 = all, 0 = off. */
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
@@ -234,6 +236,12 @@ int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, lon
  * (int64 [workgroups][16], or the bit-20 layout above) and the bf16 cost-volume heads kernel its
  * phase totals per workgroup (int64 [512][8]); NULL turns it off. */
 int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
+/* Which implementation tapir_pips_mixer / tapir_refine_pips / tapir_estimate_trajectories use for the
+ * PIPs mixer: 0 = automatic (the track-resident fused kernel for non-causal clips of <= 64 frames
+ * (48 in the f32 build) with >= 128 tracks, separate launches otherwise), 1 = always separate
+ * launches (token-mixing kernel + tiled GEMMs), 2 = always the fused kernel (TAPIR_ERR_UNSUPPORTED
+ * where it does not apply).  Both are HIP paths; tests and tools/kbench.py A/B them. */
+int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

@@ -20,7 +20,10 @@ TAPIR_F32 = 0
 TAPIR_BF16 = 1
 TAPIR_MAX_LEVELS = 8
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libtapir_hip.so')
+# (TAPIR_HIP_LIB: tools/kbench.py points this at a -DTAPIR_EXPERIMENTS build of the same sources --
+# still a gfx950 library built from tapnet_amd/csrc, never a fallback)
+LIB_PATH = os.environ.get('TAPIR_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                           'csrc', 'libtapir_hip.so')
 
 c_float_p = POINTER(c_float)
 
@@ -83,13 +86,15 @@ PROTOTYPES = {
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     'tapir_debug_set_trace': (c_int, [c_void_p, c_void_p]),
+    'tapir_debug_set_mixer_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_mix': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p]),
     'tapir_profile_enable': (c_int, [c_void_p, c_int]),
     'tapir_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 
-PROF_KINDS = {'gemm_up': 0, 'gemm_down': 1, 'mix': 2, 'patch_corr': 3, 'cv_heads': 4, 'cv_gemm': 5}
+PROF_KINDS = {'gemm_up': 0, 'gemm_down': 1, 'mix': 2, 'patch_corr': 3, 'cv_heads': 4, 'cv_gemm': 5,
+              'mixer_fused': 6}
 
 
 def declare_prototypes(lib: ctypes.CDLL) -> ctypes.CDLL:

@@ -15,6 +15,7 @@
 #include "costvol.hpp"
 #include "gemm.hpp"
 #include "mixer.hpp"
+#include "mixer_fused.hpp"
 #include "pips.hpp"
 
 using namespace tapir;
@@ -54,6 +55,10 @@ struct tapir_ctx {
   std::vector<BlockW> blocks;
   float* lnF = nullptr;
   void* Wout = nullptr; float* bout = nullptr;    // [388, 512]
+  // track-resident fused mixer (mixer_fused.hpp): per-wave A-fragment streams + per-block vectors
+  uint4* fused_stream = nullptr; long fused_fpw = 0;
+  std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
+  int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
 
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
@@ -173,6 +178,100 @@ int get_w(tapir_ctx* c, const std::string& name, std::vector<int64_t> shape, con
 }
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != TAPIR_OK) return rc_; } while (0)
+
+// ---- weights of the fused mixer kernel (mixer_fused.hpp): every wave reads ONE linear stream of
+// 1-KiB MFMA A fragments, in the order it multiplies them.  Fragment (row0, k0) of matrix W [rows,
+// cols]: lane l holds W[row0 + (l & 15)][k0 + (l >> 4) * EPC + j], j < EPC (zero outside W).
+template <typename TA>
+void pack_fragment(uint8_t* dst, const float* W, int rows, int cols, int row0, int k0) {
+  constexpr int EPC = 16 / (int)sizeof(TA);
+  for (int l = 0; l < 64; ++l)
+    for (int j = 0; j < EPC; ++j) {
+      const int r = row0 + (l & 15), k = k0 + (l >> 4) * EPC + j;
+      const float v = (r < rows && k < cols) ? W[(size_t)r * cols + k] : 0.f;
+      if (sizeof(TA) == 2) ((uint16_t*)dst)[l * EPC + j] = host_f2bf(v);
+      else ((float*)dst)[l * EPC + j] = v;
+    }
+}
+
+template <typename TA>
+int build_fused_weights(tapir_ctx* c) {
+  using CF = FusedCfg<TA>;
+  const int nb = c->cfg.num_mixer_blocks;
+  const long fpw = fused_frags_per_wave<TA>(c->k0_pad, nb);
+  std::vector<uint8_t> host((size_t)FM_WAVES * fpw * 1024, 0);
+  const std::string mx = "torch_pips_mixer.";
+  const HostTensor *w0, *wout;
+  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
+  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
+  std::vector<const HostTensor*> wup(nb), wdn(nb);
+  for (int b = 0; b < nb; ++b) {
+    const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
+    TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup[b]));
+    TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn[b]));
+  }
+  constexpr int RAU = CF::HC / 8 / 16, NC = kHidden4 / CF::HC;
+  for (int w = 0; w < FM_WAVES; ++w) {
+    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
+    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
+      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
+      q += 1024;
+    };
+    for (int ks = 0; ks < c->k0_pad / CF::KS; ++ks)
+      for (int a = 0; a < 4; ++a) put(w0, kHidden, c->in_dim, 64 * w + 16 * a, ks * CF::KS);
+    for (int b = 0; b < nb; ++b)
+      for (int hc = 0; hc < NC; ++hc) {
+        for (int ks = 0; ks < kHidden / CF::KS; ++ks)
+          for (int a = 0; a < RAU; ++a)
+            put(wup[b], kHidden4, kHidden, hc * CF::HC + w * (CF::HC / 8) + 16 * a, ks * CF::KS);
+        for (int ks = 0; ks < CF::HC / CF::KS; ++ks)
+          for (int a = 0; a < 4; ++a)
+            put(wdn[b], kHidden, kHidden4, 64 * w + 16 * a, hc * CF::HC + ks * CF::KS);
+      }
+    for (int ks = 0; ks < kHidden / CF::KS; ++ks)
+      for (int a = 0; a < 4; ++a) put(wout, kMixOut, kHidden, 64 * w + 16 * a, ks * CF::KS);
+    if (q + (size_t)FM_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
+      return fail(c, TAPIR_ERR_WEIGHTS, "fused stream layout mismatch");
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  c->fused_stream = (uint4*)d;
+  c->fused_fpw = fpw;
+  // per-channel temporal-convolution parameters (LN1 scale folded into the first convolution)
+  std::vector<FusedBlockParams> bps(nb);
+  for (int b = 0; b < nb; ++b) {
+    const std::string p = mx + "blocks." + std::to_string(b) + ".";
+    const HostTensor *ln1, *w1, *b1, *w2, *b2;
+    TRY(get_w(c, p + "layer_norm.weight", {kHidden}, &ln1));
+    TRY(get_w(c, p + "mlp1_up.weight", {kHidden4, 1, 3}, &w1));
+    TRY(get_w(c, p + "mlp1_up.bias", {kHidden4}, &b1));
+    TRY(get_w(c, p + "mlp1_up_1.weight", {kHidden4, 1, 3}, &w2));
+    TRY(get_w(c, p + "mlp1_up_1.bias", {kHidden4}, &b2));
+    std::vector<float> mw((size_t)kHidden * FM_MIXW, 0.f);
+    for (int ch = 0; ch < kHidden; ++ch) {
+      float* o = mw.data() + (size_t)ch * FM_MIXW;
+      float bsum = 0.f;
+      for (int m = 0; m < 4; ++m) {
+        const int oc = 4 * ch + m;
+        for (int k = 0; k < 3; ++k) {
+          o[m * 3 + k] = w1->data[oc * 3 + k] * ln1->data[ch];
+          o[16 + m * 3 + k] = w2->data[oc * 3 + k];
+        }
+        o[12 + m] = b1->data[oc];
+        bsum += b2->data[oc];
+      }
+      o[28] = bsum;
+    }
+    float* dm = nullptr;
+    TRY(upload_f32(c, mw.data(), mw.size(), &dm));
+    bps[b].mixw = dm;
+    bps[b].ln2 = c->blocks[b].ln2; bps[b].bup = c->blocks[b].bup; bps[b].bdn = c->blocks[b].bdn;
+  }
+  c->fused_blocks = bps;
+  return TAPIR_OK;
+}
 
 // ----------------------------------------------------------------------------
 // small helper kernels
@@ -324,6 +423,32 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
               float* ctx1_out, float* ctx2_out, hipStream_t s) {
   const long R = (long)N * T;
   const int nb = c->cfg.num_mixer_blocks;
+  // track-resident fused kernel (mixer_fused.hpp) for whole non-causal clips; separate launches for
+  // the online model, long clips, and few tracks (one workgroup per track: below ~128 tracks the
+  // chip is mostly idle and the split-K / tiled GEMMs on all rows are faster)
+  {
+    const bool has_ctx = ctx1_in || ctx2_in || ctx1_out || ctx2_out;
+    bool fused = c->fused_stream != nullptr &&
+                 fused_mixer_supported<TA>(T, c->k0_pad, c->cfg.use_causal_conv != 0, has_ctx);
+    if (c->mixer_mode == 2 && !fused)
+      return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
+    if (c->mixer_mode == 1) fused = false;
+    if (c->mixer_mode == 0 && fused) fused = N >= 128 && R >= 4096;
+    if (fused) {
+      TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
+      FusedArgs fa{};
+      fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
+      fa.stream = c->fused_stream; fa.frags_per_wave = c->fused_fpw;
+      fa.b0 = c->b0; fa.nblocks = nb;
+      for (int i = 0; i < nb; ++i) fa.blocks[i] = c->fused_blocks[i];
+      fa.dbg_times = (long long*)c->dbg_times;
+      fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
+      fa.N = N; fa.T = T;
+      ProfScope ps(c, TAPIR_PROF_MIXER, s);
+      launch_mixer_fused<TA>(fa, s);
+      return TAPIR_OK;
+    }
+  }
   TRY(ensure(c, c->xa, (size_t)R * kHidden * 4));
   TRY(ensure(c, c->xb, (size_t)R * kHidden * 4));
   TRY(ensure(c, c->xn, (size_t)R * kHidden * sizeof(TA)));
@@ -626,7 +751,10 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   c->cfg = *cfg;
   c->device = device;
   c->in_dim = kMixOut + kPatch * (2 + cfg->pyramid_level);
-  c->k0_pad = (c->in_dim + 63) / 64 * 64;
+  // K of the input Linear, zero padded: whole GEMM k-steps, and rows of a multiple of 256 bytes for
+  // the LDS image of the fused mixer kernel (128 bf16 / 64 f32 elements)
+  const int kq = cfg->dtype == TAPIR_BF16 ? 128 : 64;
+  c->k0_pad = (c->in_dim + kq - 1) / kq * kq;
   *out = c;
   return TAPIR_OK;
 }
@@ -728,6 +856,11 @@ int tapir_finalize_weights(tapir_ctx* c) {
     TRY(upload_matrix(c, t->data.data(), kHidden, kHidden4, kHidden4, &b.Wdn));
     TRY(get_w(c, p + "conv_channels_mixer.mlp2_down.bias", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.bdn));
     c->blocks.push_back(b);
+  }
+  c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
+  if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
+    if (c->cfg.dtype == TAPIR_BF16) TRY(build_fused_weights<bf16_t>(c));
+    else TRY(build_fused_weights<float>(c));
   }
   c->host_w.clear();
   c->finalized = true;
@@ -932,15 +1065,27 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
   const int mg = (tile >> 8) & 0xfff;   // test hook: cap the persistent grid (several tiles per workgroup)
   const bool traced = (tile >> 20) & 1;  // bf16 build: per-k-step cycle trace into the trace buffer
   tile &= 0xff;
+  if (!gemm_tile_available(tile))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "GEMM tile not in this build (experiment tiles need -DTAPIR_EXPERIMENTS)");
   if (traced) {
+#ifdef TAPIR_EXPERIMENTS
     if (!bf || epi == 0 || !c->dbg_times) return fail(c, TAPIR_ERR_INVALID, "traced GEMM: bf16, epi 1|2, trace buffer set");
     if (epi == 1) launch_gemm_traced<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg);
     else launch_gemm_traced<bf16_t, float, EPI_BIAS_RESID>(g, s, tile, mg);
     return TAPIR_OK;
+#else
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "traced GEMM needs a -DTAPIR_EXPERIMENTS build");
+#endif
   }
   if (epi == 0) { if (bf) launch_gemm<bf16_t, float, EPI_BIAS>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS>(g, s, tile, mg); }
   else if (epi == 1) { if (bf) launch_gemm<bf16_t, bf16_t, EPI_BIAS_GELU>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_GELU>(g, s, tile, mg); }
   else { if (bf) launch_gemm<bf16_t, float, EPI_BIAS_RESID>(g, s, tile, mg); else launch_gemm<float, float, EPI_BIAS_RESID>(g, s, tile, mg); }
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
+  c->mixer_mode = mode;
   return TAPIR_OK;
 }
 

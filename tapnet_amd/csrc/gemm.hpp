@@ -533,6 +533,7 @@ __global__ __launch_bounds__(TL::THREADS) void gemm_nt_kernel(GemmArgs g) {
 //   producer, step t: copies of stage t+NS-1 (into the buffer read in step t-1), then wait until its
 //                     copies of stage t+1 have landed (vmcnt), barrier
 //   consumer, step t: fragments + MFMAs of stage t, LDS reads returned (lgkmcnt), barrier
+#ifdef TAPIR_EXPERIMENTS
 template <typename TA, typename TO, int EPI, typename TL, int PW>
 __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs g) {
   constexpr int EPC = 16 / (int)sizeof(TA);
@@ -681,6 +682,8 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
   }
 }
 
+#endif  // TAPIR_EXPERIMENTS
+
 // Tile shapes.  Slots = workgroups per CU (LDS-limited) x 256 CUs.
 enum { GEMM_TILE_AUTO = 0, GEMM_TILE_192x128 = 1, GEMM_TILE_128x128 = 2, GEMM_TILE_192x64 = 3,
        GEMM_TILE_192x128_S3 = 4, GEMM_TILE_192x128_WS = 5, GEMM_TILE_192x256 = 6, GEMM_TILE_256x128 = 7,
@@ -739,6 +742,7 @@ inline void launch_gemm_tile(const GemmArgs& g, hipStream_t stream, int max_grid
 }
 
 // the same launch with the per-k-step cycle trace compiled in (debug entry only)
+#ifdef TAPIR_EXPERIMENTS
 template <typename TA, typename TO, int EPI, typename TL>
 inline void launch_gemm_tile_traced(const GemmArgs& g, hipStream_t stream, int max_grid) {
   const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
@@ -747,6 +751,7 @@ inline void launch_gemm_tile_traced(const GemmArgs& g, hipStream_t stream, int m
   if (max_grid > 0) grid = std::min(grid, (max_grid + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<TA, TO, EPI, TL, true>), dim3(grid), dim3(TL::THREADS), 0, stream, g);
 }
+#endif
 
 // ---- split-K for few rows (the online model: M = points x 1 frame).  With M = 256 a mixer GEMM is
 // 8-32 tiles of up to 32 DEPENDENT k-steps on a 256-CU chip; slicing K puts 64 workgroups of 4 k-steps
@@ -802,6 +807,7 @@ inline void launch_gemm_splitk(const GemmArgs& g, int splits, float* part, hipSt
                      dim3(256), 0, stream, r);
 }
 
+#ifdef TAPIR_EXPERIMENTS
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, int max_grid) {
   if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N, g.K);
@@ -812,26 +818,41 @@ inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, 
     default: launch_gemm_tile_traced<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
   }
 }
+#endif
+
+// true when `tile` is compiled into this build: the product library carries the four tile shapes
+// gemm_pick_tile selects; the other twelve (the tile-shape study of round 1: profiles/r01_kbench_gemm.log)
+// and the wave-specialised kernel are built only with -DTAPIR_EXPERIMENTS (tools/kbench.py, the host
+// emulator's tile tests).
+inline bool gemm_tile_available(int tile) {
+#ifdef TAPIR_EXPERIMENTS
+  return tile >= 0 && tile < GEMM_TILE_COUNT;
+#else
+  return tile == GEMM_TILE_AUTO || tile == GEMM_TILE_192x64 || tile == GEMM_TILE_128x128_W8 ||
+         tile == GEMM_TILE_256x128_W16_S3 || tile == GEMM_TILE_256x256;
+#endif
+}
 
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_TILE_AUTO,
                         int max_grid = 0) {
   if (tile == GEMM_TILE_AUTO) tile = gemm_pick_tile(g.M, g.N, g.K);
   switch (tile) {
+    case GEMM_TILE_192x64: launch_gemm_tile<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
+    case GEMM_TILE_256x128_W16_S3: launch_gemm_tile<TA, TO, EPI, GemmTileLong16S3>(g, stream, max_grid); break;
+    case GEMM_TILE_256x256: launch_gemm_tile<TA, TO, EPI, GemmTileHuge>(g, stream, max_grid); break;
+#ifdef TAPIR_EXPERIMENTS
     case GEMM_TILE_192x128: launch_gemm_tile<TA, TO, EPI, GemmTileBig>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_S3: launch_gemm_tile<TA, TO, EPI, GemmTileBig3>(g, stream, max_grid); break;
-    case GEMM_TILE_192x64: launch_gemm_tile<TA, TO, EPI, GemmTileTall>(g, stream, max_grid); break;
+    case GEMM_TILE_128x128: launch_gemm_tile<TA, TO, EPI, GemmTileSquare>(g, stream, max_grid); break;
     case GEMM_TILE_192x256: launch_gemm_tile<TA, TO, EPI, GemmTileWide>(g, stream, max_grid); break;
     case GEMM_TILE_256x128: launch_gemm_tile<TA, TO, EPI, GemmTileLong>(g, stream, max_grid); break;
-    case GEMM_TILE_128x128_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
     case GEMM_TILE_192x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileTall8>(g, stream, max_grid); break;
     case GEMM_TILE_128x64_W8: launch_gemm_tile<TA, TO, EPI, GemmTileSmall8>(g, stream, max_grid); break;
     case GEMM_TILE_256x128_W16_PF: launch_gemm_tile<TA, TO, EPI, GemmTileLong16P>(g, stream, max_grid); break;
     case GEMM_TILE_128x128_W8_PF: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8P>(g, stream, max_grid); break;
     case GEMM_TILE_256x128_W16: launch_gemm_tile<TA, TO, EPI, GemmTileLong16>(g, stream, max_grid); break;
-    case GEMM_TILE_256x128_W16_S3: launch_gemm_tile<TA, TO, EPI, GemmTileLong16S3>(g, stream, max_grid); break;
     case GEMM_TILE_128x128_W8_S3: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8S3>(g, stream, max_grid); break;
-    case GEMM_TILE_256x256: launch_gemm_tile<TA, TO, EPI, GemmTileHuge>(g, stream, max_grid); break;
     case GEMM_TILE_192x128_WS: {   // 8 consumer + 4 producer waves, 4 stages, one workgroup per CU
       using TL = GemmTileBig;
       const int ntiles = ((g.N + TL::BN - 1) / TL::BN) * ((g.M + TL::BM - 1) / TL::BM);
@@ -840,7 +861,8 @@ inline void launch_gemm(const GemmArgs& g, hipStream_t stream, int tile = GEMM_T
       TAPIR_LAUNCH((gemm_ws_kernel<TA, TO, EPI, TL, 4>), dim3(grid), dim3(TL::THREADS + 256), stream, g);
       break;
     }
-    default: launch_gemm_tile<TA, TO, EPI, GemmTileSquare>(g, stream, max_grid); break;
+#endif
+    default: launch_gemm_tile<TA, TO, EPI, GemmTileSquare8>(g, stream, max_grid); break;
   }
 }
 

@@ -1,0 +1,516 @@
+// Track-resident PIPs MLP-mixer: the WHOLE PIPSMLPMixer (tapnet/models/tapir_model.py:127-156) of
+// one track -- input Linear, num_mixer_blocks x PIPsConvBlock (:101-124: LayerNorm, temporal
+// depthwise convs :39-89, GELU, LayerNorm, channel MLP 512 -> 2048 -> 512 :92-98, both skips), final
+// LayerNorm and output Linear -- in ONE workgroup, with the residual stream of the track held in
+// registers from the first instruction to the last.
+//
+// Why this shape.  With separate launches (mixer.hpp + gemm.hpp) every block writes and re-reads
+// x [R,512] f32 twice, LN(x) and the 2048-wide hidden tensor (100 MB per block at 12288 token rows,
+// 4.8 GB per call) and pays 37 launches per refinement iteration; the two GEMMs of a block sat at
+// 27-30 % of the MFMA peak.  Tokens of different tracks never interact inside the mixer, and the
+// only operator that couples the frames of a track is a depthwise convolution over time, so a
+// track (T <= 64 frames x 512 channels) is a closed unit: nothing but the mixer input row and the
+// 388 outputs of a token ever has to touch HBM.
+//
+// Layout.  512 threads = 8 waves.  Wave w owns output channels [64 w, 64 w + 64) of every
+// 512-wide tensor.  The residual x[t][ch] lives in MFMA accumulator layout (v_mfma 16x16, weights
+// on the A port, tokens on the B port): register xr[a][i][r] of lane l (c = l & 15, g = l >> 4)
+// is channel 64 w + 16 a + 4 g + r of token t = 16 i + c.  In this layout
+//   * the channel MLP's second GEMM accumulates straight into the residual (+ skip for free),
+//   * a lane holds 4 consecutive channels of one token: LayerNorm / GELU outputs go to LDS as
+//     8-byte (bf16) stores in the [token][channel] image the next GEMM reads as its B operand,
+//   * the time axis runs along the 16 lanes of a DPP row: the temporal convolutions shift by
+//     row_shr / row_shl and patch the row edge from the neighbouring token tile (row_ror).
+// Weights are never shared between waves (a wave multiplies ITS 64 output rows, or its slice of the
+// hidden rows, by all tokens), so they do not go through LDS at all: the host packs them per wave
+// into one linear stream of 1-KiB MFMA A-fragments in exactly the order the wave consumes them
+// (tapir_finalize_weights), and the wave keeps FM_RING = 16 fragment loads (global_load_dwordx4
+// straight to VGPRs, 64 VGPRs) in flight across phase boundaries and barriers.  LDS holds only what
+// waves exchange: LN2(x) [T,512] and one 512-wide (bf16; 256 f32) chunk of the hidden tensor.
+//
+// Roofline.  A CU streams both weight matrices of a block (4.2 MB bf16) from L2 for ONE track:
+// 64 B/clk/CU on the L2 -> CU path = ~32 us per block, against 21 us of MFMA time at the dense peak
+// (2 x 2 x 48 x 512 x 2048 flop per block and track) -- the kernel is bound by the L2 -> CU fill at
+// T = 48, i.e. at 64 % of the MFMA peak, plus the VALU time of the temporal convolutions (two GELUs
+// per channel and frame, quarter-rate transcendentals) which nothing overlaps within one track.
+#pragma once
+#include "common.hpp"
+#include "gemm.hpp"    // MfmaStep
+#include "mixer.hpp"   // kLnEps
+
+namespace tapir {
+
+constexpr int FM_WAVES = 8;
+constexpr int FM_THREADS = FM_WAVES * 64;
+constexpr int FM_RING = 16;          // weight fragments (1 KiB each) in flight per wave
+constexpr int FM_MIXW = 32;          // floats per channel of packed temporal-conv parameters
+constexpr int FM_OUT_PAD = 512;      // output Linear rows padded to 8 waves x 64
+constexpr int FM_MAX_BLOCKS = 16;    // per-block parameter pointers travel in the kernel arguments
+
+template <typename TA> struct FusedCfg;
+template <> struct FusedCfg<bf16_t> {   // one 16-byte chunk = 8 bf16: a 16x16x32 MFMA k-slice
+  static constexpr int EPC = 8, KS = 32, HC = 512, MAX_NT = 4;
+};
+template <> struct FusedCfg<float> {    // one 16-byte chunk = 4 f32: four 16x16x4 MFMAs, k = 16
+  static constexpr int EPC = 4, KS = 16, HC = 256, MAX_NT = 3;
+};
+
+struct FusedBlockParams {
+  const float* mixw;   // [512][FM_MIXW]: w1[4][3] * ln1, b1[4], w2[4][3], sum_m b2[m], 0, 0, 0
+  const float* ln2;    // [512]
+  const float* bup;    // [2048]
+  const float* bdn;    // [512]
+};
+
+struct FusedArgs {
+  const void* mlp_in;            // [N*T, ld_in] operand type (patch_corr_kernel output)
+  int ld_in;                     // = k0_pad: ld_in * sizeof(TA) is a multiple of 256 bytes
+  const uint4* stream;           // [8 waves][frags_per_wave][64 lanes] packed A fragments
+  long frags_per_wave;
+  const float* b0;               // [512] bias of the input Linear
+  FusedBlockParams blocks[FM_MAX_BLOCKS];   // by value: kernel-argument (scalar) loads
+  int nblocks;
+  const float* lnF;              // [512] final LayerNorm scale
+  const float* bout;             // [388]
+  float* res;                    // [N*T, 388]
+  int N, T;
+  long long* dbg_times;          // TRACE build: [N][8 waves][8] shader-cycle totals per phase
+};
+
+// Number of A fragments in one wave's stream (host packing and kernel must agree).
+template <typename TA>
+inline long fused_frags_per_wave(int k0_pad, int nblocks) {
+  using CF = FusedCfg<TA>;
+  const long in = (long)(k0_pad / CF::KS) * 4;
+  const long up = (long)(CF::HC / 8 / 16) * (kHidden / CF::KS);   // per chunk
+  const long dn = 4L * (CF::HC / CF::KS);
+  const long blk = (kHidden4 / CF::HC) * (up + dn);
+  const long out = 4L * (kHidden / CF::KS);
+  return in + nblocks * blk + out + FM_RING;   // + one ring of padding (prefetched, never used)
+}
+
+// ---- time shifts along the token axis of the MFMA column layout (token = 16 i + (lane & 15)) ----
+// value of token t-1: lane c <- lane c-1 of v, lane 0 <- lane 15 of vprev (the previous token tile;
+// pass 0 for the first tile: SAME padding).  Two DPP moves: row_ror:1 of vprev as the fill value,
+// row_shr:1 of v over it (bound_ctrl off: lanes whose source falls off the row keep the fill).
+__device__ __forceinline__ float tok_prev(float v, float vprev, int lane) {
+#ifdef TAPIR_HIPEMU
+  const float a = __shfl(v, (lane & 48) | ((lane - 1) & 15));
+  const float b = __shfl(vprev, (lane & 48) | 15);
+  return (lane & 15) ? a : b;
+#else
+  (void)lane;
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(vprev), 0x121, 0xf, 0xf, false);
+  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x111, 0xf, 0xf, false));
+#endif
+}
+// value of token t+1: lane c <- lane c+1 of v, lane 15 <- lane 0 of vnext
+__device__ __forceinline__ float tok_next(float v, float vnext, int lane) {
+#ifdef TAPIR_HIPEMU
+  const float a = __shfl(v, (lane & 48) | ((lane + 1) & 15));
+  const float b = __shfl(vnext, (lane & 48));
+  return ((lane & 15) != 15) ? a : b;
+#else
+  (void)lane;
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(vnext), 0x12F, 0xf, 0xf, false);
+  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x101, 0xf, 0xf, false));
+#endif
+}
+
+// 16-byte load through an explicit global-address-space pointer: pointers taken from a struct are
+// generic to the compiler, and a flat_load counts on vmcnt AND lgkmcnt (it would tie the LDS waits of
+// the GEMM loops to the weight stream).
+__device__ __forceinline__ f32x4 gload4(const float* p) {
+#ifdef TAPIR_HIPEMU
+  return *reinterpret_cast<const f32x4*>(p);
+#else
+  typedef const __attribute__((address_space(1))) f32x4* gptr;
+  return *(gptr)(uintptr_t)p;
+#endif
+}
+
+// 4 consecutive channels of one token -> the [token][channel] LDS image (operand type), 16-byte
+// chunks XOR-swizzled by the token's low 4 bits so that the B-fragment ds_read_b128 of a 16-lane
+// group (16 tokens, one chunk column) covers all 64 banks.
+template <typename TA>
+__device__ __forceinline__ void store_act4(char* base, int stride, int row, int ch0, int c,
+                                           float v0, float v1, float v2, float v3) {
+  constexpr int EPC = 16 / (int)sizeof(TA);
+  char* p = base + row * stride + (((ch0 / EPC) ^ c) << 4) + (ch0 % EPC) * (int)sizeof(TA);
+  if (sizeof(TA) == 2) {
+    uint2 o;
+    o.x = pack_bf16x2(v0, v1);
+    o.y = pack_bf16x2(v2, v3);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v0, v1, v2, v3);
+  }
+}
+
+// One GEMM phase of a wave: acc[r][i] += W_frag(r, k) . act(token tile i, k) over `groups` x G
+// k-steps, G = FM_RING / RA.  A fragments come from the wave's register ring (slot order = stream
+// order; every consumed slot is refilled with the fragment FM_RING positions further down the
+// stream), B fragments from the swizzled LDS image at bbase.
+template <typename TA, int RA, int NT>
+__device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RING],
+                                           const char* bbase, int bstride, int groups, int c, int g,
+                                           f32x4 (&acc)[RA][NT]) {
+  constexpr int G = FM_RING / RA;
+  static_assert(FM_RING % RA == 0, "ring must hold whole k-steps");
+  // Schedule (pinned with scheduling fences: left alone, hipcc sinks the FM_RING refill loads of a
+  // group to the bottom of the loop body, i.e. issues each fragment load right before its use):
+  //   B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (one step ahead);
+  //   each A fragment is refilled right after its last MFMA, so FM_RING - 1 loads stay in flight.
+  const char* brow = bbase + c * bstride;
+  auto read_b = [&](int ks, uint4 (&fb)[NT]) {
+    const int chunk = (ks * 4 + g) ^ c;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      fb[i] = *reinterpret_cast<const uint4*>(brow + 16 * i * bstride + (chunk << 4));
+  };
+  const int ksteps = groups * G;
+  uint4 fb0[NT], fb1[NT];
+  read_b(0, fb0);
+  for (int kg = 0; kg < groups; ++kg) {
+#pragma unroll
+    for (int kk = 0; kk < G; ++kk) {
+      uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
+      uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
+      int ks1 = kg * G + kk + 1;
+      ks1 = ks1 < ksteps ? ks1 : 0;   // past the end: any valid address (the values are not used)
+      read_b(ks1, nxt);
+      sched_fence();
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const uint4 fa = ring[kk * RA + r];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) MfmaStep<TA>::run(fa, cur[i], acc[r][i]);
+        ring[kk * RA + r] = *wp;
+        wp += 64;
+        sched_fence();
+      }
+    }
+  }
+}
+
+template <typename TA, int NT, bool TRACE = false>
+__global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
+  using CF = FusedCfg<TA>;
+  constexpr int EPC = CF::EPC, KS = CF::KS, HC = CF::HC;
+  constexpr int ROWS = NT * 16;
+  constexpr int RAU = HC / 8 / 16;          // hidden-row tiles of a wave per chunk
+  constexpr int NC = kHidden4 / HC;         // hidden chunks per block
+  constexpr int XN_STRIDE = kHidden * (int)sizeof(TA);
+  constexpr int H_STRIDE = HC * (int)sizeof(TA);
+  constexpr int XN_BYTES = ROWS * XN_STRIDE, H_BYTES = ROWS * H_STRIDE;
+  static_assert(NT >= 1 && NT <= CF::MAX_NT, "token tiles");
+  // LN2(x) image [ROWS][512] then the hidden chunk [ROWS][HC]; the mixer-input rows use both, and so
+  // do the temporal-convolution parameters of a block (64 KiB) while its token mixing runs
+  constexpr int PAR_BYTES = kHidden * FM_MIXW * 4;
+  constexpr int ACT_BYTES = XN_BYTES + H_BYTES > PAR_BYTES ? XN_BYTES + H_BYTES : PAR_BYTES;
+  static_assert(ACT_BYTES + 2 * ROWS * 8 * 4 + kHidden4 * 4 <= 160 * 1024, "LDS budget");
+  __shared__ uint4 s_act[ACT_BYTES / 16];
+  __shared__ float s_stat[2][ROWS][8];      // per-wave partial sums of the LayerNorm statistics
+  __shared__ float s_bup[kHidden4];         // up-projection bias of the current block (see below)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int n = blockIdx.x;
+  const int T = a.T;
+  char* const s_xn = reinterpret_cast<char*>(s_act);
+  char* const s_h = s_xn + XN_BYTES;
+  const int ch_lane = 64 * wave + 4 * g;    // channel of (a = 0, r = 0) of this lane
+
+  // TRACE (tools/kbench.py --what fusedtrace): shader cycles (s_memtime) per phase, summed per wave
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto tick = [&](int k) {
+#ifndef TAPIR_HIPEMU
+    if (TRACE) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+      if (k >= 0) tph[k] += t - tlast;
+      tlast = t;
+    }
+#endif
+  };
+  tick(-1);
+
+  // ---- weight stream: fill the ring (the loads fly while the input rows are staged)
+  const uint4* wp = a.stream + ((long)wave * a.frags_per_wave) * 64 + lane;
+  uint4 ring[FM_RING];
+#pragma unroll
+  for (int s = 0; s < FM_RING; ++s) { ring[s] = *wp; wp += 64; }
+
+  // ---- stage the mixer-input rows of this track: [ROWS][ld_in], rows >= T zero
+  const int in_stride = a.ld_in * (int)sizeof(TA);
+  {
+    const int cpr = in_stride >> 4;   // 16-byte chunks per row (a multiple of 16)
+    const uint4* src = reinterpret_cast<const uint4*>(
+        reinterpret_cast<const char*>(a.mlp_in) + (long)n * T * in_stride);
+    for (int id = tid; id < ROWS * cpr; id += FM_THREADS) {
+      const int row = id / cpr, q = id - row * cpr;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row < T) v = src[id];
+      s_act[row * cpr + (q ^ (row & 15))] = v;
+    }
+  }
+  lds_barrier();
+
+  // ---- residual stream <- input Linear (tapir_model.py:139): x = mlp_in . W0^T + b0
+  f32x4 xr[4][NT];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = gload4(a.b0 + ch_lane + 16 * q);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) xr[q][i] = b;
+  }
+  fused_gemm<TA, 4, NT>(wp, ring, s_xn, in_stride, a.ld_in / KS / (FM_RING / 4), c, g, xr);
+  lds_barrier();   // every wave is done with the input rows: the region is reused from here on
+  tick(0);
+
+  // tokens past the end of the clip (T not a multiple of 16): zero inputs of both convolutions
+  float valid[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) valid[i] = (16 * i + c < T) ? 1.0f : 0.0f;
+
+  // per-token LayerNorm statistics over the 512 channels spread over lane groups and waves
+  auto ln_stats = [&](float (&mean)[NT], float (&rstd)[NT]) {
+    float s[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t += (xr[q][i][0] + xr[q][i][1]) + (xr[q][i][2] + xr[q][i][3]);
+      s[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 16);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 32);
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) s_stat[0][16 * i + c][wave] = s[i];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&s_stat[0][16 * i + c][0]);
+      const float4 p1 = *reinterpret_cast<const float4*>(&s_stat[0][16 * i + c][4]);
+      mean[i] = (((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w))) * (1.0f / kHidden);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = xr[q][i][r] - mean[i]; t = fmaf(d, d, t); }
+      s[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 16);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 32);
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) s_stat[1][16 * i + c][wave] = s[i];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&s_stat[1][16 * i + c][0]);
+      const float4 p1 = *reinterpret_cast<const float4*>(&s_stat[1][16 * i + c][4]);
+      const float var = (((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w))) * (1.0f / kHidden);
+      rstd[i] = 1.0f / sqrtf(var + kLnEps);
+    }
+  };
+
+  // LN(x) * scale -> operand type -> LDS image at s_xn
+  auto write_xn = [&](const float* scale, const float (&mean)[NT], const float (&rstd)[NT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 sc = gload4(scale + ch_lane + 16 * q);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        store_act4<TA>(s_xn, XN_STRIDE, 16 * i + c, ch_lane + 16 * q, c,
+                       (xr[q][i][0] - mean[i]) * rstd[i] * sc[0], (xr[q][i][1] - mean[i]) * rstd[i] * sc[1],
+                       (xr[q][i][2] - mean[i]) * rstd[i] * sc[2], (xr[q][i][3] - mean[i]) * rstd[i] * sc[3]);
+    }
+  };
+
+  for (int b = 0; b < a.nblocks; ++b) {
+    const FusedBlockParams& bp = a.blocks[b];
+    float mean[NT], rstd[NT];
+
+    // temporal-convolution parameters of this block -> LDS (the activation images are dead until
+    // LN2: every wave has passed the barrier that ends the previous block's last down-projection).
+    // Read straight from global memory, channel by channel, each load is a dependent L2 round trip
+    // with nothing to hide it behind (16 per lane and block).  Visible after ln_stats' first barrier.
+    {
+      const f32x4* src = reinterpret_cast<const f32x4*>(bp.mixw);
+      f32x4* dst = reinterpret_cast<f32x4*>(s_act);
+      f32x4 v[PAR_BYTES / 16 / FM_THREADS];
+#pragma unroll
+      for (int k = 0; k < PAR_BYTES / 16 / FM_THREADS; ++k) v[k] = gload4(reinterpret_cast<const float*>(src + tid + k * FM_THREADS));
+#pragma unroll
+      for (int k = 0; k < PAR_BYTES / 16 / FM_THREADS; ++k) dst[tid + k * FM_THREADS] = v[k];
+    }
+
+    // ---- token mixing (tapir_model.py:39-89,111-119): LN1 -> depthwise conv k=3 (x4 channels) ->
+    // GELU -> depthwise conv k=3 -> sum of each group of 4 -> + skip, per channel, along time
+    ln_stats(mean, rstd);
+    tick(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // (opaque: the 16 parameter addresses of a lane are otherwise computed up front and spilled)
+        const f32x4* pw = reinterpret_cast<const f32x4*>(s_act) + opaque(ch_lane + 16 * q + r) * (FM_MIXW / 4);
+        const f32x4 wa = pw[0], wb = pw[1], wc = pw[2], b1 = pw[3], va = pw[4], vb = pw[5], vc = pw[6], tail = pw[7];
+        const float w1[4][3] = {{wa.x, wa.y, wa.z}, {wa.w, wb.x, wb.y}, {wb.z, wb.w, wc.x}, {wc.y, wc.z, wc.w}};
+        const float w2[4][3] = {{va.x, va.y, va.z}, {va.w, vb.x, vb.y}, {vb.z, vb.w, vc.x}, {vc.y, vc.z, vc.w}};
+        const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+        float xc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) xc[i] = (xr[q][i][r] - mean[i]) * rstd[i] * valid[i];
+        float p0[NT], p1[NT], p2[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float xp = tok_prev(xc[i], i > 0 ? xc[i - 1] : 0.f, lane);
+          const float xq = tok_next(xc[i], i + 1 < NT ? xc[i + 1] : 0.f, lane);
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float u = bb1[m];
+            u = fmaf(w1[m][0], xp, u);
+            u = fmaf(w1[m][1], xc[i], u);
+            u = fmaf(w1[m][2], xq, u);
+            const float gl = gelu_tanh(u) * valid[i];
+            s0 = fmaf(w2[m][0], gl, s0);
+            s1 = fmaf(w2[m][1], gl, s1);
+            s2 = fmaf(w2[m][2], gl, s2);
+          }
+          p0[i] = s0; p1[i] = s1; p2[i] = s2;
+        }
+        // y[t] = sum_m b2[m] + P0[t-1] + P1[t] + P2[t+1]   (shifting the three partial sums instead
+        // of the four GELU outputs: 2 shifted values per token tile instead of 8)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float y = tail.x + tok_prev(p0[i], i > 0 ? p0[i - 1] : 0.f, lane) + p1[i] +
+                          tok_next(p2[i], i + 1 < NT ? p2[i + 1] : 0.f, lane);
+          xr[q][i][r] += y;
+        }
+        // one channel at a time: without the fence the scheduler hoists the parameter loads of all
+        // 16 channels of the lane to the top (512 registers' worth) and spills the residual
+        sched_fence();
+      }
+    }
+
+    tick(2);
+    // ---- channel MLP (tapir_model.py:92-98,121-123): x += W_dn . gelu(W_up . LN2(x) + b_up) + b_dn
+    ln_stats(mean, rstd);
+    write_xn(bp.ln2, mean, rstd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bd = gload4(bp.bdn + ch_lane + 16 * q);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) xr[q][i] += bd;
+    }
+    // The up-projection bias goes through LDS: a vector load inside the chunk loop would be YOUNGER
+    // than the FM_RING weight loads in flight, and waiting for it (vmcnt) would drain the ring at
+    // every chunk.  Here the ring's loads are a whole token-mixing phase old.
+    *reinterpret_cast<f32x4*>(&s_bup[tid * 4]) = gload4(bp.bup + tid * 4);
+    lds_barrier();   // LN2(x) (and the bias) visible to every wave
+    tick(3);
+    for (int hc = 0; hc < NC; ++hc) {
+      // up: this wave's HC/8 hidden rows of the chunk x all tokens, K = 512
+      f32x4 ua[RAU][NT];
+      const int hid_lane = wave * (HC / 8) + 4 * g;   // hidden unit (within the chunk) of (r = 0, reg 0)
+#pragma unroll
+      for (int r = 0; r < RAU; ++r) {
+        const f32x4 bu = *reinterpret_cast<const f32x4*>(&s_bup[hc * HC + hid_lane + 16 * r]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ua[r][i] = bu;
+      }
+      fused_gemm<TA, RAU, NT>(wp, ring, s_xn, XN_STRIDE, (kHidden / KS) / (FM_RING / RAU), c, g, ua);
+#pragma unroll
+      for (int r = 0; r < RAU; ++r)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          store_act4<TA>(s_h, H_STRIDE, 16 * i + c, hid_lane + 16 * r, c, gelu_tanh(ua[r][i][0]),
+                         gelu_tanh(ua[r][i][1]), gelu_tanh(ua[r][i][2]), gelu_tanh(ua[r][i][3]));
+      tick(4);
+      lds_barrier();   // hidden chunk visible
+      tick(5);
+      // down: this wave's 64 output channels += W_dn[:, chunk] . hidden chunk, K = HC
+      fused_gemm<TA, 4, NT>(wp, ring, s_h, H_STRIDE, (HC / KS) / (FM_RING / 4), c, g, xr);
+      tick(6);
+      lds_barrier();   // every wave is done reading the chunk before the next one overwrites it
+      tick(7);
+    }
+  }
+
+  // ---- final LayerNorm + output Linear (tapir_model.py:154-155): 388 outputs, rows padded to 512
+  {
+    float mean[NT], rstd[NT];
+    ln_stats(mean, rstd);
+    write_xn(a.lnF, mean, rstd);
+    lds_barrier();
+    f32x4 oa[4][NT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o0 = ch_lane + 16 * q;
+      f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (o0 < kMixOut) bo = gload4(a.bout + o0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) oa[q][i] = bo;
+    }
+    fused_gemm<TA, 4, NT>(wp, ring, s_xn, XN_STRIDE, (kHidden / KS) / (FM_RING / 4), c, g, oa);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o0 = ch_lane + 16 * q;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int t = 16 * i + c;
+        if (o0 < kMixOut && t < T)
+          *reinterpret_cast<f32x4*>(a.res + ((long)n * T + t) * kMixOut + o0) = oa[q][i];
+      }
+    }
+  }
+  if (TRACE && a.dbg_times != nullptr && lane == 0) {
+    tick(0);   // final LayerNorm + output Linear are booked with the input Linear
+    long long* o = a.dbg_times + ((long)n * FM_WAVES + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (long long)tph[k];
+  }
+}
+
+// true when the fused kernel covers this shape (non-causal whole clips of up to MAX_NT x 16 frames)
+template <typename TA>
+inline bool fused_mixer_supported(int T, int k0_pad, bool causal, bool has_ctx) {
+  using CF = FusedCfg<TA>;
+  if (causal || has_ctx || T < 1 || T > 16 * CF::MAX_NT) return false;
+  if ((k0_pad * (int)sizeof(TA)) % 256 != 0) return false;
+  if ((k0_pad / CF::KS) % (FM_RING / 4) != 0) return false;
+  return true;
+}
+
+template <typename TA>
+inline void launch_mixer_fused(const FusedArgs& a, hipStream_t s) {
+  const int nt = (a.T + 15) / 16;
+  const dim3 grid((unsigned)a.N), block(FM_THREADS);
+#ifdef TAPIR_EXPERIMENTS
+  if (a.dbg_times != nullptr && nt == 3) {   // phase trace (tools/kbench.py --what fusedtrace)
+    hipLaunchKernelGGL((mixer_fused_kernel<TA, 3, true>), grid, block, 0, s, a);
+    return;
+  }
+#endif
+  if (nt == 1) TAPIR_LAUNCH((mixer_fused_kernel<TA, 1>), grid, block, s, a);
+  else if (nt == 2) TAPIR_LAUNCH((mixer_fused_kernel<TA, 2>), grid, block, s, a);
+  else if (nt == 3) TAPIR_LAUNCH((mixer_fused_kernel<TA, 3>), grid, block, s, a);
+  else if constexpr (FusedCfg<TA>::MAX_NT >= 4) TAPIR_LAUNCH((mixer_fused_kernel<TA, 4>), grid, block, s, a);
+}
+
+}  // namespace tapir

@@ -3,5 +3,5 @@
 # against tests/hipemu/hip/hip_runtime.h -> tests/hipemu/libtapir_emu.so
 set -e
 cd "$(dirname "$0")"
-/opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fopenmp -fPIC -shared -I. \
+/opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fopenmp -fPIC -shared -I. -DTAPIR_EXPERIMENTS \
   -Wno-unused-value ../../tapnet_amd/csrc/engine.hip emu_switch.cpp -o libtapir_emu.so "$@"

@@ -1,0 +1,64 @@
+"""CPU tests of the track-resident fused mixer kernel (tapnet_amd/csrc/mixer_fused.hpp) on the host
+emulator (lane-accurate MFMA fragment layouts, shuffles, barriers): the packed weight streams, the
+register-resident residual in MFMA accumulator layout, the DPP time shifts across token tiles, the
+swizzled LDS activation images and ragged clip lengths -- against the numpy oracle (f32 build) and
+against the separate-launch path on the same bf16-rounded operands (bf16 build)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import tapir_oracle as O
+from tapnet_amd import _ffi, synthetic
+from tests.emu_engine import EmuEngine
+
+
+def _mixer(e, x, mode):
+  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, mode) == 0
+  return e.pips_mixer(x)
+
+
+@pytest.mark.parametrize('pyr,T,N', [(1, 19, 2), (0, 16, 1), (1, 33, 1), (0, 48, 1), (1, 5, 3)])
+def test_fused_mixer_f32_vs_oracle(pyr, T, N):
+  """f32 build (exact-f32 MFMA): 1, 2 and 3 token tiles, ragged T (masking of the padded
+  tokens in both temporal convolutions), both input widths (486 -> 512, 535 -> 576)."""
+  w = synthetic.make_weights(6 + T, pyr, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=pyr, num_mixer_blocks=2, initial_resolution=(64, 64))
+  rng = np.random.default_rng(T)
+  x = rng.standard_normal((N, T, 388 + 49 * (2 + pyr))).astype(np.float32)
+  out = _mixer(e, x, 2)
+  ref, _ = O.pips_mlp_mixer(w, x, num_blocks=2)
+  np.testing.assert_allclose(out, ref, atol=2e-4)
+  sep = _mixer(e, x, 1)
+  np.testing.assert_allclose(out, sep, atol=2e-4)
+  e.close()
+
+
+@pytest.mark.parametrize('T', [20, 64])
+def test_fused_mixer_bf16_matches_separate_launches(T):
+  """bf16 build: same roundings as the separate-launch path (LN output, GELU output and mixer input
+  rounded to bf16, f32 residual / accumulation), so the two agree to accumulation-order noise;
+  T = 64 is the four-token-tile instantiation."""
+  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
+  rng = np.random.default_rng(T)
+  x = rng.standard_normal((2, T, 535)).astype(np.float32)
+  fused = _mixer(e, x, 2)
+  sep = _mixer(e, x, 1)
+  ref, _ = O.pips_mlp_mixer(w, x, num_blocks=2)
+  assert np.abs(fused - sep).max() < 2e-2, np.abs(fused - sep).max()
+  assert np.abs(fused - ref).max() < 0.15     # bf16 operand rounding vs the f32 oracle
+  assert np.median(np.abs(fused - sep)) < 2e-3
+  e.close()
+
+
+def test_fused_mixer_rejects_unsupported_shapes():
+  w = synthetic.make_weights(3, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64))
+  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, 2) == 0
+  x = np.zeros((1, 49, 535), np.float32)    # f32 build covers up to 48 frames
+  out = np.zeros((1, 49, 388), np.float32)
+  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  rc = e.lib.tapir_pips_mixer(e.ctx, p(x), 1, 49, p(out), None, None, None, None, None)
+  assert rc == _ffi.TAPIR_ERR_UNSUPPORTED
+  e.close()

@@ -306,25 +306,71 @@ def bench_norm(model, reps, results):
         print(json.dumps(row), flush=True)
 
 
-def bench_mixer(model, reps, results):
-  """whole PIPSMLPMixer (12 blocks) on 256 x 48 tokens through the public C ABI"""
+def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (128, 48), (256, 24), (256, 64))):
+  """whole PIPSMLPMixer (12 blocks) through the public C ABI (tapir_pips_mixer: staging of the input
+  rows + mixer + copy of the result), A/B: separate launches (mode 1) vs the track-resident fused
+  kernel (mode 2), same inputs; max |fused - separate| is the cross-check."""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  cin = 388 + 49 * (2 + model.pyramid_level)
+  stream = model._stream()
+  for N, T in shapes:
+    if model.dtype == 'float32' and T > 48:
+      continue
+    x = torch.randn(N, T, cin, device=dev)
+    outs = {}
+    for mode, name in ((1, 'separate'), (2, 'fused')):
+      assert lib.tapir_debug_set_mixer_mode(ctx, mode) == 0
+      out = torch.empty(N, T, 388, device=dev)
+
+      def run(i):
+        rc = lib.tapir_pips_mixer(ctx, x.data_ptr(), N, T, out.data_ptr(), None, None, None, None, stream)
+        assert rc == 0, lib.tapir_last_error(ctx)
+      t = timeit(run, max(5, reps // 4), warm=2)
+      outs[name] = out.clone()
+      flops = 2.0 * N * T * (cin * 512 + 12 * 2 * 512 * 2048 + 512 * 388)
+      row = dict(kernel=f'pips_mixer_12blocks_{name}', N=N, T=T, dtype=model.dtype, **t,
+                 tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
+                 us_per_block=round(t['med_us'] / 12, 2))
+      if name == 'fused':
+        d = (outs['fused'] - outs['separate']).abs()
+        row['max_abs_diff_vs_separate'] = float(d.max())
+        row['median_abs_diff_vs_separate'] = float(d.median())
+        row['finite'] = bool(torch.isfinite(outs['fused']).all())
+      results.append(row)
+      print(json.dumps(row), flush=True)
+    assert lib.tapir_debug_set_mixer_mode(ctx, 0) == 0
+
+
+def trace_fused(model):
+  """per-phase shader-cycle totals of the fused mixer kernel (TRACE build: needs a library built with
+  -DTAPIR_EXPERIMENTS, TAPIR_HIP_LIB=...): mean over waves of [in/out linear, LN1, token mixing,
+  LN2 + xn, up + GELU + store, barrier, down, barrier] for N = 256 tracks x 48 frames."""
   lib, ctx = model._lib, model._ctx
   dev = model.device
   N, T = 256, 48
   cin = 388 + 49 * (2 + model.pyramid_level)
   x = torch.randn(N, T, cin, device=dev)
   out = torch.empty(N, T, 388, device=dev)
-  stream = model._stream()
-
-  def run(i):
-    rc = lib.tapir_pips_mixer(ctx, x.data_ptr(), N, T, out.data_ptr(), None, None, None, None, stream)
+  buf = torch.zeros(N * 8 * 8, dtype=torch.int64, device=dev)
+  assert lib.tapir_debug_set_mixer_mode(ctx, 2) == 0
+  for it in range(3):
+    buf.zero_()
+    assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
+    rc = lib.tapir_pips_mixer(ctx, x.data_ptr(), N, T, out.data_ptr(), None, None, None, None, model._stream())
     assert rc == 0, lib.tapir_last_error(ctx)
-  t = timeit(run, max(5, reps // 4), warm=2)
-  flops = 2.0 * N * T * (cin * 512 + 12 * 2 * 512 * 2048 + 512 * 388)
-  row = dict(kernel='pips_mixer_12blocks', dtype=model.dtype, **t,
-             tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1))
-  results.append(row)
-  print(json.dumps(row), flush=True)
+    torch.cuda.synchronize()
+  lib.tapir_debug_set_trace(ctx, None)
+  lib.tapir_debug_set_mixer_mode(ctx, 0)
+  t = buf.view(N, 8, 8).double().cpu().numpy()
+  names = ['in+out linear', 'LN1', 'token mixing', 'LN2 + xn write', 'up + GELU + h store', 'barrier (h visible)',
+           'down', 'barrier (h free)']
+  tot = t.sum(-1).mean()
+  print(f'fused mixer phase trace ({model.dtype}): mean shader cycles per wave, whole kernel {tot:.0f} cycles')
+  for k, nm in enumerate(names):
+    per_wave = t[:, :, k].mean(0)
+    print(f'  {nm:24s} {t[:, :, k].mean():10.0f} cycles  {100 * t[:, :, k].mean() / tot:5.1f} %   per block {t[:, :, k].mean() / 12:8.0f}'
+          f'   waves min/max {per_wave.min():.0f}/{per_wave.max():.0f}')
 
 
 def bench_backbone(model, reps, results):
@@ -368,6 +414,8 @@ def main():
       trace_cv(model)
     if 'norm' in what:
       bench_norm(model, args.reps, results)
+    if 'fusedtrace' in what:
+      trace_fused(model)
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
