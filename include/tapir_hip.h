@@ -237,8 +237,8 @@ int tapir_debug_gemm(tapir_ctx* ctx, const void* A, long lda, const void* W, lon
  * phase totals per workgroup (int64 [512][8]); NULL turns it off. */
 int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
 /* Which implementation tapir_pips_mixer / tapir_refine_pips / tapir_estimate_trajectories use for the
- * PIPs mixer: 0 = automatic (the track-resident fused kernel for non-causal clips of <= 64 frames
- * (48 in the f32 build) with >= 128 tracks, separate launches otherwise), 1 = always separate
+ * PIPs mixer: 0 = automatic (the track-resident fused kernel for non-causal clips of <= 48 frames
+ * with >= 128 tracks, separate launches otherwise), 1 = always separate
  * launches (token-mixing kernel + tiled GEMMs), 2 = always the fused kernel (TAPIR_ERR_UNSUPPORTED
  * where it does not apply).  Both are HIP paths; tests and tools/kbench.py A/B them. */
 int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);

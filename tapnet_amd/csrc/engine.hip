@@ -219,15 +219,22 @@ int build_fused_weights(tapir_ctx* c) {
     };
     for (int ks = 0; ks < c->k0_pad / CF::KS; ++ks)
       for (int a = 0; a < 4; ++a) put(w0, kHidden, c->in_dim, 64 * w + 16 * a, ks * CF::KS);
-    for (int b = 0; b < nb; ++b)
-      for (int hc = 0; hc < NC; ++hc) {
-        for (int ks = 0; ks < kHidden / CF::KS; ++ks)
-          for (int a = 0; a < RAU; ++a)
-            put(wup[b], kHidden4, kHidden, hc * CF::HC + w * (CF::HC / 8) + 16 * a, ks * CF::KS);
-        for (int ks = 0; ks < CF::HC / CF::KS; ++ks)
-          for (int a = 0; a < 4; ++a)
-            put(wdn[b], kHidden, kHidden4, 64 * w + 16 * a, hc * CF::HC + ks * CF::KS);
-      }
+    // per block, the order the pipelined chunk loop consumes them in: U0 U1 D0 U2 D1 ... D(NC-1)
+    auto put_up = [&](int b, int hc) {
+      for (int ks = 0; ks < kHidden / CF::KS; ++ks)
+        for (int a = 0; a < RAU; ++a)
+          put(wup[b], kHidden4, kHidden, hc * CF::HC + w * (CF::HC / 8) + 16 * a, ks * CF::KS);
+    };
+    auto put_dn = [&](int b, int hc) {
+      for (int ks = 0; ks < CF::HC / CF::KS; ++ks)
+        for (int a = 0; a < 4; ++a)
+          put(wdn[b], kHidden, kHidden4, 64 * w + 16 * a, hc * CF::HC + ks * CF::KS);
+    };
+    for (int b = 0; b < nb; ++b) {
+      put_up(b, 0);
+      for (int hc = 1; hc < NC; ++hc) { put_up(b, hc); put_dn(b, hc - 1); }
+      put_dn(b, NC - 1);
+    }
     for (int ks = 0; ks < kHidden / CF::KS; ++ks)
       for (int a = 0; a < 4; ++a) put(wout, kMixOut, kHidden, 64 * w + 16 * a, ks * CF::KS);
     if (q + (size_t)FM_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
@@ -251,18 +258,20 @@ int build_fused_weights(tapir_ctx* c) {
     TRY(get_w(c, p + "mlp1_up_1.bias", {kHidden4}, &b2));
     std::vector<float> mw((size_t)kHidden * FM_MIXW, 0.f);
     for (int ch = 0; ch < kHidden; ++ch) {
-      float* o = mw.data() + (size_t)ch * FM_MIXW;
+      // slot j (0-2: w1[m][k] * ln1, 3: b1[m], 4-6: w2[m][k], 7: sum of b2 for m == 0) of multiplier m
+      // of channel ch sits at [(ch / 2) * FM_MIXW + m * 8 + j][ch & 1] (channel pairs interleaved)
+      float* o = mw.data() + (size_t)(ch >> 1) * FM_MIXW * 2 + (ch & 1);
       float bsum = 0.f;
       for (int m = 0; m < 4; ++m) {
         const int oc = 4 * ch + m;
         for (int k = 0; k < 3; ++k) {
-          o[m * 3 + k] = w1->data[oc * 3 + k] * ln1->data[ch];
-          o[16 + m * 3 + k] = w2->data[oc * 3 + k];
+          o[2 * (m * 8 + k)] = w1->data[oc * 3 + k] * ln1->data[ch];
+          o[2 * (m * 8 + 4 + k)] = w2->data[oc * 3 + k];
         }
-        o[12 + m] = b1->data[oc];
+        o[2 * (m * 8 + 3)] = b1->data[oc];
         bsum += b2->data[oc];
       }
-      o[28] = bsum;
+      o[2 * 7] = bsum;
     }
     float* dm = nullptr;
     TRY(upload_f32(c, mw.data(), mw.size(), &dm));

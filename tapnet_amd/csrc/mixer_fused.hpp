@@ -9,7 +9,7 @@
 // 4.8 GB per call) and pays 37 launches per refinement iteration; the two GEMMs of a block sat at
 // 27-30 % of the MFMA peak.  Tokens of different tracks never interact inside the mixer, and the
 // only operator that couples the frames of a track is a depthwise convolution over time, so a
-// track (T <= 64 frames x 512 channels) is a closed unit: nothing but the mixer input row and the
+// track (T <= 48 frames x 512 channels) is a closed unit: nothing but the mixer input row and the
 // 388 outputs of a token ever has to touch HBM.
 //
 // Layout.  512 threads = 8 waves.  Wave w owns output channels [64 w, 64 w + 64) of every
@@ -49,14 +49,15 @@ constexpr int FM_MAX_BLOCKS = 16;    // per-block parameter pointers travel in t
 
 template <typename TA> struct FusedCfg;
 template <> struct FusedCfg<bf16_t> {   // one 16-byte chunk = 8 bf16: a 16x16x32 MFMA k-slice
-  static constexpr int EPC = 8, KS = 32, HC = 512, MAX_NT = 4;
+  static constexpr int EPC = 8, KS = 32, HC = 512, MAX_NT = 3;
 };
 template <> struct FusedCfg<float> {    // one 16-byte chunk = 4 f32: four 16x16x4 MFMAs, k = 16
-  static constexpr int EPC = 4, KS = 16, HC = 256, MAX_NT = 3;
+  static constexpr int EPC = 4, KS = 16, HC = 128, MAX_NT = 3;
 };
 
 struct FusedBlockParams {
-  const float* mixw;   // [512][FM_MIXW]: w1[4][3] * ln1, b1[4], w2[4][3], sum_m b2[m], 0, 0, 0
+  const float* mixw;   // [256 channel pairs][4 multipliers m][8][2]: per channel and m: w1[m][0..2] * ln1,
+                       // b1[m], w2[m][0..2], (m == 0: sum_m b2[m]) -- the two channels of a pair interleaved
   const float* ln2;    // [512]
   const float* bup;    // [2048]
   const float* bdn;    // [512]
@@ -147,20 +148,40 @@ __device__ __forceinline__ void store_act4(char* base, int stride, int row, int 
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// gelu_tanh (common.hpp) on two values at once: the same operations in the same order, the
+// polynomial part as packed f32 math (v_pk_mul_f32 / v_pk_fma_f32), the two transcendentals per value
+// scalar (there is no packed v_exp / v_rcp).
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+  const float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  const float c3 = c1 * 0.044715f;
+  const f32x2 z = x * __builtin_elementwise_fma(f32x2{c3, c3}, x * x, f32x2{c1, c1});
+  const f32x2 d = f32x2{fast_exp2(z.x), fast_exp2(z.y)} + 1.0f;
+  return x * f32x2{fast_rcp(d.x), fast_rcp(d.y)};
+}
+
+struct NoEpilogue {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
 // One GEMM phase of a wave: acc[r][i] += W_frag(r, k) . act(token tile i, k) over `groups` x G
 // k-steps, G = FM_RING / RA.  A fragments come from the wave's register ring (slot order = stream
 // order; every consumed slot is refilled with the fragment FM_RING positions further down the
-// stream), B fragments from the swizzled LDS image at bbase.
-template <typename TA, int RA, int NT>
+// stream), B fragments from the swizzled LDS image at bbase.  epi(step) runs after the MFMAs of
+// every fragment (step = running fragment index of the phase): VALU work of ANOTHER stage slotted
+// between the MFMAs (the matrix pipe and the VALU are separate); GROUPS > 0 unrolls the group loop
+// so that `step` is a compile-time constant inside epi.
+// Schedule (pinned with scheduling fences: left alone, hipcc sinks the FM_RING refill loads of a
+// group to the bottom of the loop body, i.e. issues each fragment load right before its use):
+//   B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (one step ahead);
+//   each A fragment is refilled right after its last MFMA, so FM_RING - 1 loads stay in flight.
+template <typename TA, int RA, int NT, int GROUPS = 0, typename Epi = NoEpilogue>
 __device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RING],
                                            const char* bbase, int bstride, int groups, int c, int g,
-                                           f32x4 (&acc)[RA][NT]) {
+                                           f32x4 (&acc)[RA][NT], Epi epi = Epi()) {
   constexpr int G = FM_RING / RA;
   static_assert(FM_RING % RA == 0, "ring must hold whole k-steps");
-  // Schedule (pinned with scheduling fences: left alone, hipcc sinks the FM_RING refill loads of a
-  // group to the bottom of the loop body, i.e. issues each fragment load right before its use):
-  //   B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (one step ahead);
-  //   each A fragment is refilled right after its last MFMA, so FM_RING - 1 loads stay in flight.
   const char* brow = bbase + c * bstride;
   auto read_b = [&](int ks, uint4 (&fb)[NT]) {
     const int chunk = (ks * 4 + g) ^ c;
@@ -168,10 +189,11 @@ __device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RI
     for (int i = 0; i < NT; ++i)
       fb[i] = *reinterpret_cast<const uint4*>(brow + 16 * i * bstride + (chunk << 4));
   };
+  if (GROUPS > 0) groups = GROUPS;
   const int ksteps = groups * G;
   uint4 fb0[NT], fb1[NT];
   read_b(0, fb0);
-  for (int kg = 0; kg < groups; ++kg) {
+  auto group = [&](int kg) {
 #pragma unroll
     for (int kk = 0; kk < G; ++kk) {
       uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
@@ -187,13 +209,22 @@ __device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RI
         for (int i = 0; i < NT; ++i) MfmaStep<TA>::run(fa, cur[i], acc[r][i]);
         ring[kk * RA + r] = *wp;
         wp += 64;
+        epi((kg * G + kk) * RA + r);
         sched_fence();
       }
     }
+  };
+  if constexpr (GROUPS > 0) {
+#pragma unroll
+    for (int kg = 0; kg < GROUPS; ++kg) group(kg);
+  } else {
+    for (int kg = 0; kg < groups; ++kg) group(kg);
   }
 }
 
-template <typename TA, int NT, bool TRACE = false>
+// RAGGED: T is not a multiple of 16 -- the tokens past the end of the clip are masked out of both
+// temporal convolutions (zero padding at the clip end).
+template <typename TA, int NT, bool RAGGED, bool TRACE = false>
 __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   using CF = FusedCfg<TA>;
   constexpr int EPC = CF::EPC, KS = CF::KS, HC = CF::HC;
@@ -203,11 +234,14 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   constexpr int XN_STRIDE = kHidden * (int)sizeof(TA);
   constexpr int H_STRIDE = HC * (int)sizeof(TA);
   constexpr int XN_BYTES = ROWS * XN_STRIDE, H_BYTES = ROWS * H_STRIDE;
+  constexpr int DN_GROUPS = (HC / KS) / (FM_RING / 4);
   static_assert(NT >= 1 && NT <= CF::MAX_NT, "token tiles");
-  // LN2(x) image [ROWS][512] then the hidden chunk [ROWS][HC]; the mixer-input rows use both, and so
-  // do the temporal-convolution parameters of a block (64 KiB) while its token mixing runs
+  static_assert(RAU * NT * 4 <= DN_GROUPS * FM_RING, "one GELU per down-projection fragment step");
+  // LN2(x) image [ROWS][512], then TWO hidden chunks [ROWS][HC] (chunk c+1 is written while chunk c
+  // is multiplied); the mixer-input rows use the same region at the start, and so do the
+  // temporal-convolution parameters of a block (64 KiB) while its token mixing runs
   constexpr int PAR_BYTES = kHidden * FM_MIXW * 4;
-  constexpr int ACT_BYTES = XN_BYTES + H_BYTES > PAR_BYTES ? XN_BYTES + H_BYTES : PAR_BYTES;
+  constexpr int ACT_BYTES = XN_BYTES + 2 * H_BYTES > PAR_BYTES ? XN_BYTES + 2 * H_BYTES : PAR_BYTES;
   static_assert(ACT_BYTES + 2 * ROWS * 8 * 4 + kHidden4 * 4 <= 160 * 1024, "LDS budget");
   __shared__ uint4 s_act[ACT_BYTES / 16];
   __shared__ float s_stat[2][ROWS][8];      // per-wave partial sums of the LayerNorm statistics
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   const int n = blockIdx.x;
   const int T = a.T;
   char* const s_xn = reinterpret_cast<char*>(s_act);
-  char* const s_h = s_xn + XN_BYTES;
+  char* const s_h0 = s_xn + XN_BYTES;
   const int ch_lane = 64 * wave + 4 * g;    // channel of (a = 0, r = 0) of this lane
 
   // TRACE (tools/kbench.py --what fusedtrace): shader cycles (s_memtime) per phase, summed per wave
@@ -267,10 +301,8 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     for (int i = 0; i < NT; ++i) xr[q][i] = b;
   }
   fused_gemm<TA, 4, NT>(wp, ring, s_xn, in_stride, a.ld_in / KS / (FM_RING / 4), c, g, xr);
-  lds_barrier();   // every wave is done with the input rows: the region is reused from here on
   tick(0);
 
-  // tokens past the end of the clip (T not a multiple of 16): zero inputs of both convolutions
   float valid[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) valid[i] = (16 * i + c < T) ? 1.0f : 0.0f;
@@ -340,70 +372,95 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     }
   };
 
+  const int hid_lane = wave * (HC / 8) + 4 * g;   // hidden unit (within a chunk) of (row tile 0, reg 0)
+
+  // Temporal-convolution parameters of a block (64 KiB) go through LDS: read straight from global
+  // memory, channel by channel, each read is a dependent L2 round trip with nothing to hide it
+  // behind (16 per lane and block).  The loads are ISSUED before the barrier that ends the previous
+  // block (their latency passes while the waves gather there) and the values stored into the
+  // activation region -- dead until LN2 -- after it; visible after ln_stats' first barrier.
+  constexpr int PARV = PAR_BYTES / 16 / FM_THREADS;
+  f32x4 parv[PARV];
+  auto params_load = [&](int blk) {
+    const float* src = a.blocks[blk].mixw;
+#pragma unroll
+    for (int k = 0; k < PARV; ++k) parv[k] = gload4(src + (tid + k * FM_THREADS) * 4);
+  };
+  auto params_commit = [&]() {
+    f32x4* dst = reinterpret_cast<f32x4*>(s_act);
+#pragma unroll
+    for (int k = 0; k < PARV; ++k) dst[tid + k * FM_THREADS] = parv[k];
+  };
+  if (a.nblocks > 0) params_load(0);
+  lds_barrier();   // every wave is done with the input rows: the region is reused from here on
+
   for (int b = 0; b < a.nblocks; ++b) {
     const FusedBlockParams& bp = a.blocks[b];
     float mean[NT], rstd[NT];
-
-    // temporal-convolution parameters of this block -> LDS (the activation images are dead until
-    // LN2: every wave has passed the barrier that ends the previous block's last down-projection).
-    // Read straight from global memory, channel by channel, each load is a dependent L2 round trip
-    // with nothing to hide it behind (16 per lane and block).  Visible after ln_stats' first barrier.
-    {
-      const f32x4* src = reinterpret_cast<const f32x4*>(bp.mixw);
-      f32x4* dst = reinterpret_cast<f32x4*>(s_act);
-      f32x4 v[PAR_BYTES / 16 / FM_THREADS];
-#pragma unroll
-      for (int k = 0; k < PAR_BYTES / 16 / FM_THREADS; ++k) v[k] = gload4(reinterpret_cast<const float*>(src + tid + k * FM_THREADS));
-#pragma unroll
-      for (int k = 0; k < PAR_BYTES / 16 / FM_THREADS; ++k) dst[tid + k * FM_THREADS] = v[k];
-    }
+    params_commit();
 
     // ---- token mixing (tapir_model.py:39-89,111-119): LN1 -> depthwise conv k=3 (x4 channels) ->
-    // GELU -> depthwise conv k=3 -> sum of each group of 4 -> + skip, per channel, along time
+    // GELU -> depthwise conv k=3 -> sum of each group of 4 -> + skip, per channel, along time.
+    // Two adjacent channels of the lane at a time (registers 2 rp, 2 rp + 1 of a fragment), all
+    // arithmetic on f32x2 -> packed f32 instructions; the parameters of a channel pair are
+    // interleaved in LDS ([32][2] floats).
     ln_stats(mean, rstd);
     tick(1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (opaque: the 16 parameter addresses of a lane are otherwise computed up front and spilled)
-        const f32x4* pw = reinterpret_cast<const f32x4*>(s_act) + opaque(ch_lane + 16 * q + r) * (FM_MIXW / 4);
-        const f32x4 wa = pw[0], wb = pw[1], wc = pw[2], b1 = pw[3], va = pw[4], vb = pw[5], vc = pw[6], tail = pw[7];
-        const float w1[4][3] = {{wa.x, wa.y, wa.z}, {wa.w, wb.x, wb.y}, {wb.z, wb.w, wc.x}, {wc.y, wc.z, wc.w}};
-        const float w2[4][3] = {{va.x, va.y, va.z}, {va.w, vb.x, vb.y}, {vb.z, vb.w, vc.x}, {vc.y, vc.z, vc.w}};
-        const float bb1[4] = {b1.x, b1.y, b1.z, b1.w};
-        float xc[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) xc[i] = (xr[q][i][r] - mean[i]) * rstd[i] * valid[i];
-        float p0[NT], p1[NT], p2[NT];
+      for (int rp = 0; rp < 2; ++rp) {
+        // (opaque: the parameter addresses of a lane are otherwise all computed up front and spilled)
+        const f32x4* pw = reinterpret_cast<const f32x4*>(s_act) +
+                          opaque((ch_lane + 16 * q + 2 * rp) >> 1) * (2 * FM_MIXW / 4);
+        f32x2 xc[NT], xp[NT], xq[NT], s0[NT], s1[NT], s2[NT];
+        const f32x2 zero = f32x2{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-          const float xp = tok_prev(xc[i], i > 0 ? xc[i - 1] : 0.f, lane);
-          const float xq = tok_next(xc[i], i + 1 < NT ? xc[i + 1] : 0.f, lane);
-          float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float u = bb1[m];
-            u = fmaf(w1[m][0], xp, u);
-            u = fmaf(w1[m][1], xc[i], u);
-            u = fmaf(w1[m][2], xq, u);
-            const float gl = gelu_tanh(u) * valid[i];
-            s0 = fmaf(w2[m][0], gl, s0);
-            s1 = fmaf(w2[m][1], gl, s1);
-            s2 = fmaf(w2[m][2], gl, s2);
-          }
-          p0[i] = s0; p1[i] = s1; p2[i] = s2;
+          xc[i] = (f32x2{xr[q][i][2 * rp], xr[q][i][2 * rp + 1]} - mean[i]) * rstd[i];
+          if (RAGGED) xc[i] = xc[i] * valid[i];
         }
-        // y[t] = sum_m b2[m] + P0[t-1] + P1[t] + P2[t+1]   (shifting the three partial sums instead
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const f32x2 xa = i > 0 ? xc[i - 1] : zero, xb = i + 1 < NT ? xc[i + 1] : zero;
+          xp[i] = f32x2{tok_prev(xc[i].x, xa.x, lane), tok_prev(xc[i].y, xa.y, lane)};
+          xq[i] = f32x2{tok_next(xc[i].x, xb.x, lane), tok_next(xc[i].y, xb.y, lane)};
+          s0[i] = zero; s1[i] = zero; s2[i] = zero;
+        }
+        f32x2 bsum = zero;
+        // one multiplier m (of the x4 depthwise expansion) at a time: 8 parameter pairs live
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const f32x4 v0 = pw[4 * m], v1 = pw[4 * m + 1], v2 = pw[4 * m + 2], v3 = pw[4 * m + 3];
+          const f32x2 w10 = f32x2{v0[0], v0[1]}, w11 = f32x2{v0[2], v0[3]}, w12 = f32x2{v1[0], v1[1]},
+                      b1m = f32x2{v1[2], v1[3]}, w20 = f32x2{v2[0], v2[1]}, w21 = f32x2{v2[2], v2[3]},
+                      w22 = f32x2{v3[0], v3[1]};
+          if (m == 0) bsum = f32x2{v3[2], v3[3]};
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            f32x2 u = b1m;
+            u = __builtin_elementwise_fma(w10, xp[i], u);
+            u = __builtin_elementwise_fma(w11, xc[i], u);
+            u = __builtin_elementwise_fma(w12, xq[i], u);
+            f32x2 gl = gelu_tanh2(u);
+            if (RAGGED) gl = gl * valid[i];
+            s0[i] = __builtin_elementwise_fma(w20, gl, s0[i]);
+            s1[i] = __builtin_elementwise_fma(w21, gl, s1[i]);
+            s2[i] = __builtin_elementwise_fma(w22, gl, s2[i]);
+          }
+        }
+        // y[t] = sum_m b2[m] + S0[t-1] + S1[t] + S2[t+1]   (shifting the three partial sums instead
         // of the four GELU outputs: 2 shifted values per token tile instead of 8)
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-          const float y = tail.x + tok_prev(p0[i], i > 0 ? p0[i - 1] : 0.f, lane) + p1[i] +
-                          tok_next(p2[i], i + 1 < NT ? p2[i + 1] : 0.f, lane);
-          xr[q][i][r] += y;
+          const f32x2 pa = i > 0 ? s0[i - 1] : zero, pb = i + 1 < NT ? s2[i + 1] : zero;
+          const f32x2 y = bsum + f32x2{tok_prev(s0[i].x, pa.x, lane), tok_prev(s0[i].y, pa.y, lane)} + s1[i] +
+                          f32x2{tok_next(s2[i].x, pb.x, lane), tok_next(s2[i].y, pb.y, lane)};
+          xr[q][i][2 * rp] += y.x;
+          xr[q][i][2 * rp + 1] += y.y;
         }
-        // one channel at a time: without the fence the scheduler hoists the parameter loads of all
-        // 16 channels of the lane to the top (512 registers' worth) and spills the residual
+        // one channel pair at a time: without the fence the scheduler hoists the parameter reads of
+        // all 16 channels of the lane to the top and spills the residual
         sched_fence();
       }
     }
@@ -424,10 +481,17 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     *reinterpret_cast<f32x4*>(&s_bup[tid * 4]) = gload4(bp.bup + tid * 4);
     lds_barrier();   // LN2(x) (and the bias) visible to every wave
     tick(3);
-    for (int hc = 0; hc < NC; ++hc) {
-      // up: this wave's HC/8 hidden rows of the chunk x all tokens, K = 512
-      f32x4 ua[RAU][NT];
-      const int hid_lane = wave * (HC / 8) + 4 * g;   // hidden unit (within the chunk) of (r = 0, reg 0)
+
+    // Chunks of HC hidden units, software-pipelined over two LDS buffers:
+    //   up(0); for c: { down(c-1) with the GELU of chunk c slotted between its MFMAs -> h[c & 1];
+    //                   barrier; up(c+1) }; down(NC-1); barrier
+    // (= the order of the weight stream: U0 U1 D0 U2 D1 ... D(NC-1)).  The GELU + pack + LDS store of
+    // a chunk (4 GELUs per hidden unit and token tile, as many as the token mixing has) is VALU
+    // work with no MFMA of its own to hide behind; the down-projection of the PREVIOUS chunk is
+    // independent of it.  One barrier per chunk: it publishes h[c & 1] and retires the reads of
+    // h[(c-1) & 1], which the GELU of chunk c+1 overwrites only after the next barrier.
+    f32x4 ua[RAU][NT];
+    auto up = [&](int hc) {
 #pragma unroll
       for (int r = 0; r < RAU; ++r) {
         const f32x4 bu = *reinterpret_cast<const f32x4*>(&s_bup[hc * HC + hid_lane + 16 * r]);
@@ -435,21 +499,40 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
         for (int i = 0; i < NT; ++i) ua[r][i] = bu;
       }
       fused_gemm<TA, RAU, NT>(wp, ring, s_xn, XN_STRIDE, (kHidden / KS) / (FM_RING / RAU), c, g, ua);
+    };
+    // GELU of value v (0 .. RAU*NT*4-1) of the up accumulators; every fourth one stores its fragment
+    auto gelu_step = [&](int v, char* hbuf) {
+      if (v < RAU * NT * 4) {
+        const int item = v >> 2, r = item / NT, i = item % NT, k = v & 3;
+        ua[r][i][k] = gelu_tanh(ua[r][i][k]);
+        if (k == 3)
+          store_act4<TA>(hbuf, H_STRIDE, 16 * i + c, hid_lane + 16 * r, c, ua[r][i][0], ua[r][i][1],
+                         ua[r][i][2], ua[r][i][3]);
+      }
+    };
+    up(0);
+    tick(4);
 #pragma unroll
-      for (int r = 0; r < RAU; ++r)
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-          store_act4<TA>(s_h, H_STRIDE, 16 * i + c, hid_lane + 16 * r, c, gelu_tanh(ua[r][i][0]),
-                         gelu_tanh(ua[r][i][1]), gelu_tanh(ua[r][i][2]), gelu_tanh(ua[r][i][3]));
+    for (int v = 0; v < RAU * NT * 4; ++v) gelu_step(v, s_h0);   // chunk 0: nothing to overlap with
+    tick(5);
+    lds_barrier();
+    tick(7);
+    for (int hc = 1; hc < NC; ++hc) {
+      up(hc);
       tick(4);
-      lds_barrier();   // hidden chunk visible
-      tick(5);
-      // down: this wave's 64 output channels += W_dn[:, chunk] . hidden chunk, K = HC
-      fused_gemm<TA, 4, NT>(wp, ring, s_h, H_STRIDE, (HC / KS) / (FM_RING / 4), c, g, xr);
+      char* const hprev = s_h0 + ((hc - 1) & 1) * H_BYTES;
+      char* const hcur = s_h0 + (hc & 1) * H_BYTES;
+      fused_gemm<TA, 4, NT, DN_GROUPS>(wp, ring, hprev, H_STRIDE, DN_GROUPS, c, g, xr,
+                                       [&](int step) { gelu_step(step, hcur); });
       tick(6);
-      lds_barrier();   // every wave is done reading the chunk before the next one overwrites it
+      lds_barrier();
       tick(7);
     }
+    fused_gemm<TA, 4, NT>(wp, ring, s_h0 + ((NC - 1) & 1) * H_BYTES, H_STRIDE, DN_GROUPS, c, g, xr);
+    tick(6);
+    if (b + 1 < a.nblocks) params_load(b + 1);
+    lds_barrier();   // every wave is done with the activation images before the next block reuses them
+    tick(7);
   }
 
   // ---- final LayerNorm + output Linear (tapir_model.py:154-155): 388 outputs, rows padded to 512
@@ -487,7 +570,8 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   }
 }
 
-// true when the fused kernel covers this shape (non-causal whole clips of up to MAX_NT x 16 frames)
+// true when the fused kernel covers this shape (non-causal whole clips of up to MAX_NT x 16 = 48 frames;
+// longer clips, the online model and small track counts run the separate launches of mixer.hpp / gemm.hpp)
 template <typename TA>
 inline bool fused_mixer_supported(int T, int k0_pad, bool causal, bool has_ctx) {
   using CF = FusedCfg<TA>;
@@ -500,17 +584,24 @@ inline bool fused_mixer_supported(int T, int k0_pad, bool causal, bool has_ctx) 
 template <typename TA>
 inline void launch_mixer_fused(const FusedArgs& a, hipStream_t s) {
   const int nt = (a.T + 15) / 16;
+  const bool ragged = a.T % 16 != 0;
   const dim3 grid((unsigned)a.N), block(FM_THREADS);
 #ifdef TAPIR_EXPERIMENTS
-  if (a.dbg_times != nullptr && nt == 3) {   // phase trace (tools/kbench.py --what fusedtrace)
-    hipLaunchKernelGGL((mixer_fused_kernel<TA, 3, true>), grid, block, 0, s, a);
+  if (a.dbg_times != nullptr && nt == 3 && !ragged) {   // phase trace (tools/kbench.py --what fusedtrace)
+    hipLaunchKernelGGL((mixer_fused_kernel<TA, 3, false, true>), grid, block, 0, s, a);
     return;
   }
 #endif
-  if (nt == 1) TAPIR_LAUNCH((mixer_fused_kernel<TA, 1>), grid, block, s, a);
-  else if (nt == 2) TAPIR_LAUNCH((mixer_fused_kernel<TA, 2>), grid, block, s, a);
-  else if (nt == 3) TAPIR_LAUNCH((mixer_fused_kernel<TA, 3>), grid, block, s, a);
-  else if constexpr (FusedCfg<TA>::MAX_NT >= 4) TAPIR_LAUNCH((mixer_fused_kernel<TA, 4>), grid, block, s, a);
+  if (nt == 1) {
+    if (ragged) TAPIR_LAUNCH((mixer_fused_kernel<TA, 1, true>), grid, block, s, a);
+    else TAPIR_LAUNCH((mixer_fused_kernel<TA, 1, false>), grid, block, s, a);
+  } else if (nt == 2) {
+    if (ragged) TAPIR_LAUNCH((mixer_fused_kernel<TA, 2, true>), grid, block, s, a);
+    else TAPIR_LAUNCH((mixer_fused_kernel<TA, 2, false>), grid, block, s, a);
+  } else {
+    if (ragged) TAPIR_LAUNCH((mixer_fused_kernel<TA, 3, true>), grid, block, s, a);
+    else TAPIR_LAUNCH((mixer_fused_kernel<TA, 3, false>), grid, block, s, a);
+  }
 }
 
 }  // namespace tapir

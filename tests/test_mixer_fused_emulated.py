@@ -34,11 +34,11 @@ def test_fused_mixer_f32_vs_oracle(pyr, T, N):
   e.close()
 
 
-@pytest.mark.parametrize('T', [20, 64])
+@pytest.mark.parametrize('T', [20, 48])
 def test_fused_mixer_bf16_matches_separate_launches(T):
   """bf16 build: same roundings as the separate-launch path (LN output, GELU output and mixer input
   rounded to bf16, f32 residual / accumulation), so the two agree to accumulation-order noise;
-  T = 64 is the four-token-tile instantiation."""
+  T = 48 is the benchmark's three-token-tile instantiation (unmasked), T = 20 a ragged two-tile one."""
   w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
   e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
   rng = np.random.default_rng(T)
@@ -56,7 +56,7 @@ def test_fused_mixer_rejects_unsupported_shapes():
   w = synthetic.make_weights(3, 1, False, num_mixer_blocks=1, backbone=False)
   e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64))
   assert e.lib.tapir_debug_set_mixer_mode(e.ctx, 2) == 0
-  x = np.zeros((1, 49, 535), np.float32)    # f32 build covers up to 48 frames
+  x = np.zeros((1, 49, 535), np.float32)    # the fused kernel covers up to 48 frames (3 token tiles)
   out = np.zeros((1, 49, 388), np.float32)
   p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
   rc = e.lib.tapir_pips_mixer(e.ctx, p(x), 1, 49, p(out), None, None, None, None, None)
