@@ -242,6 +242,11 @@ int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
  * launches (token-mixing kernel + tiled GEMMs), 2 = always the fused kernel (TAPIR_ERR_UNSUPPORTED
  * where it does not apply).  Both are HIP paths; tests and tools/kbench.py A/B them. */
 int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
+/* Cost-volume stage (tapir_tracks_from_cost_volume and the first stage of
+ * tapir_estimate_trajectories): 0 = automatic (ONE kernel -- einsum on the matrix cores into LDS +
+ * heads, no volume in HBM -- for grids of up to 32 x 32 cells; larger grids take the path below),
+ * 1 = einsum GEMM into a workspace followed by the heads kernel (round-1 path; tools A/B it). */
+int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

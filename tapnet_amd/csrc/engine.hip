@@ -13,6 +13,7 @@
 #include "backbone.hpp"
 #include "common.hpp"
 #include "costvol.hpp"
+#include "costvol_fused.hpp"
 #include "gemm.hpp"
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
@@ -59,6 +60,7 @@ struct tapir_ctx {
   uint4* fused_stream = nullptr; long fused_fpw = 0;
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
+  int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
 
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
@@ -385,7 +387,21 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     c->cast_src[1] = nullptr;   // slot no longer mirrors a pyramid level
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
   }
-  // bound the cost-volume workspace to ~256 MiB per launch
+  if (cv_fused_supported(h, w) && c->cv_mode != 1) {
+    // one kernel: contraction on the matrix cores into LDS + heads; no volume in HBM
+    CvFusedArgs fa{};
+    fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = c->cvw; fa.qpts = qpts_init;
+    fa.points = points; fa.occ = occ; fa.expd = expd;
+    fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w;
+    fa.temperature = c->cfg.softmax_temperature;
+    fa.img_h = (float)c->cfg.initial_h; fa.img_w = (float)c->cfg.initial_w;
+    fa.dbg_times = (long long*)c->dbg_times;
+    ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
+    launch_cv_fused<TA>(fa, s);
+    return TAPIR_OK;
+  }
+  // grids beyond 32 x 32 cells (or cv_mode 1, tools): einsum into a workspace of <= 256 MiB per
+  // launch, then the heads kernel
   long qc = (256L << 20) / ((long)T * hw * 4);
   qc = std::max<long>(1, std::min<long>(qc, Q));
   TRY(ensure(c, c->cv, (size_t)qc * T * hw * sizeof(float)));
@@ -1095,6 +1111,12 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_cv_mode(tapir_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  c->cv_mode = mode;
   return TAPIR_OK;
 }
 

@@ -243,3 +243,38 @@ def test_cost_volume_stage_bf16_mfma():
     ok = st['top2_rel_gap'] > 1e-3
     np.testing.assert_allclose(pts[ok], rp[ok], atol=2e-3)   # the soft-argmax path stays f32
     e.close()
+
+
+@pytest.mark.parametrize('dtype', [_ffi.TAPIR_F32, _ffi.TAPIR_BF16])
+def test_cost_volume_fused_matches_workspace_path(dtype):
+  """The fused cost-volume kernel (costvol_fused.hpp: einsum on the matrix cores into LDS + heads, the
+  two small convolutions as chained exact-f32 MFMA products) against the round-1 path (einsum GEMM into
+  a workspace + heads kernel) on the full 32x32 grid: two clips, a query count that is not a multiple
+  of the query tile, and against the oracle in the f32 build."""
+  w = synthetic.make_weights(19, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(256, 256), dtype=dtype)
+  rng = np.random.default_rng(5)
+  B, Q, T = 2, 19, 2
+  grid = O.l2_normalize(rng.standard_normal((B, T, 32, 32, 256)).astype(np.float32))
+  qf = O.l2_normalize(rng.standard_normal((B, Q, 256)).astype(np.float32))
+  qp = np.stack([rng.integers(0, T, (B, Q)), rng.uniform(0, 256, (B, Q)),
+                 rng.uniform(0, 256, (B, Q))], -1).astype(np.float32)
+  assert e.lib.tapir_debug_set_cv_mode(e.ctx, 0) == 0
+  pts, occ, expd = e.tracks_from_cost_volume(qf, grid, qp)
+  assert e.lib.tapir_debug_set_cv_mode(e.ctx, 1) == 0
+  pts1, occ1, expd1 = e.tracks_from_cost_volume(qf, grid, qp)
+  if dtype == _ffi.TAPIR_F32:
+    rp, ro, re, st = O.tracks_from_cost_volume(w, qf, grid, qp, (256, 256), 20.0, return_stages=True)
+    ok = st['top2_rel_gap'] > 1e-4
+    np.testing.assert_allclose(occ, ro, atol=1e-4)
+    np.testing.assert_allclose(expd, re, atol=1e-4)
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3)
+    np.testing.assert_allclose(occ, occ1, atol=1e-4)
+  else:
+    # both paths round the operands of the einsum to bf16; the occlusion head sees hid1 rounded to
+    # bf16 in both; the soft-argmax path is f32 in both
+    np.testing.assert_allclose(occ, occ1, atol=2e-2)
+    np.testing.assert_allclose(expd, expd1, atol=2e-2)
+    d = np.linalg.norm(pts - pts1, axis=-1)
+    assert np.median(d) < 1e-3 and np.mean(d < 0.05) > 0.97, (np.median(d), d.max())
+  e.close()

@@ -340,6 +340,67 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (128, 48), 
     assert lib.tapir_debug_set_mixer_mode(ctx, 0) == 0
 
 
+def bench_cv(model, reps, results):
+  """cost-volume stage (tapir_tracks_from_cost_volume: casts + einsum + heads) at config 2 and at one
+  rank's share of config 3, A/B: mode 1 = einsum GEMM into a workspace + heads kernel, mode 0 = the
+  fused kernel (no volume in HBM)."""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  g = torch.Generator(device='cpu').manual_seed(0)
+  for Q, T in ((256, 48), (1024, 48)):
+    grid = torch.nn.functional.normalize(torch.randn(1, T, 32, 32, 256, generator=g), dim=-1).to(dev)
+    qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
+    qp = torch.cat([torch.randint(0, T, (1, Q, 1), generator=g).float(), torch.rand(1, Q, 2, generator=g) * 256], -1).to(dev)
+    outs = {}
+    for mode, name in ((1, 'workspace'), (0, 'fused')):
+      assert lib.tapir_debug_set_cv_mode(ctx, mode) == 0
+      pts = torch.empty(1, Q, T, 2, device=dev); occ = torch.empty(1, Q, T, device=dev); expd = torch.empty(1, Q, T, device=dev)
+
+      def run(i):
+        rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), qp.data_ptr(), 1, Q, T, 32, 32,
+                                               pts.data_ptr(), occ.data_ptr(), expd.data_ptr(), stream)
+        assert rc == 0, lib.tapir_last_error(ctx)
+      t = timeit(run, max(5, reps // 2), warm=2)
+      outs[name] = (pts.clone(), occ.clone())
+      row = dict(kernel=f'cost_volume_stage_{name}', Q=Q, T=T, dtype=model.dtype, **t,
+                 ns_per_map=round(t['med_us'] * 1e3 / (Q * T), 1))
+      if name == 'fused':
+        d = torch.linalg.norm(outs['fused'][0] - outs['workspace'][0], dim=-1)
+        row['tracks_median_diff_px'] = float(d.median()); row['tracks_frac_within_0.05px'] = float((d < 0.05).float().mean())
+        row['occ_max_diff'] = float((outs['fused'][1] - outs['workspace'][1]).abs().max())
+      results.append(row)
+      print(json.dumps(row), flush=True)
+    assert lib.tapir_debug_set_cv_mode(ctx, 0) == 0
+
+
+def trace_cv_fused(model):
+  """per-phase shader-cycle totals (wave 0) of the fused cost-volume kernel, TRACE build (-DTAPIR_EXPERIMENTS)"""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  Q, T = 256, 48
+  g = torch.Generator(device='cpu').manual_seed(0)
+  grid = torch.nn.functional.normalize(torch.randn(1, T, 32, 32, 256, generator=g), dim=-1).to(dev)
+  qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
+  pts = torch.empty(1, Q, T, 2, device=dev); occ = torch.empty(1, Q, T, device=dev); expd = torch.empty(1, Q, T, device=dev)
+  nwg = T * (Q // 16)
+  buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+  for it in range(2):
+    assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
+    rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), None, 1, Q, T, 32, 32,
+                                           pts.data_ptr(), occ.data_ptr(), expd.data_ptr(), model._stream())
+    assert rc == 0, lib.tapir_last_error(ctx)
+    torch.cuda.synchronize()
+  lib.tapir_debug_set_trace(ctx, None)
+  t = buf.view(nwg, 8).double().cpu().numpy()
+  names = ['zero fill + einsum + constants', 'barrier (map start)', 'conv1 + conv2P (MFMA f32)', 'barrier', 'logits + argmax + softmax sums',
+           'occlusion conv (MFMA)', 'barrier', 'tail']
+  tot = t.sum(-1).mean()
+  print(f'fused cost-volume phase trace ({model.dtype}): wave 0, mean over {nwg} workgroups of 16 maps; total {tot:.0f} cycles')
+  for k, nm in enumerate(names):
+    print(f'  {nm:34s} {t[:, k].mean():10.0f} cycles  {100 * t[:, k].mean() / tot:5.1f} %   per map {t[:, k].mean() / 16:8.0f}')
+
+
 def trace_fused(model):
   """per-phase shader-cycle totals of the fused mixer kernel (TRACE build: needs a library built with
   -DTAPIR_EXPERIMENTS, TAPIR_HIP_LIB=...): mean over waves of [in/out linear, LN1, token mixing,
@@ -412,6 +473,10 @@ def main():
       trace_cv(model)
     if 'norm' in what:
       bench_norm(model, args.reps, results)
+    if 'cv' in what:
+      bench_cv(model, args.reps, results)
+    if 'cvfusedtrace' in what:
+      trace_cv_fused(model)
     if 'fusedtrace' in what:
       trace_fused(model)
     if 'mixtrace' in what:
