@@ -100,6 +100,17 @@ int tapir_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, const floa
                                   float* points, float* occlusion, float* expected_dist,
                                   void* stream);
 
+/* TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171), num_heads = 1: the TAPIR
+ * head kernel with the TAP-Net differences (no ReLU after the stride-2 convolution, ONE occlusion
+ * logit, softmax temperature 10).  Needs the head's weights under the names
+ * "tapnet_cost_volume_track_mods.{hid1,hid2,hid3,hid4,occ_out}.{weight,bias}" (torch layout of the
+ * TAPIR head; occ_out [1,16]) before tapir_finalize_weights.  qfeat [B,Q,256], grid [B,T,h,w,256]
+ * (h, w <= 32: one fused kernel), query_points NULL or [B,Q,3] (t,y,x) in initial_resolution
+ * coordinates -> points [B,Q,T,2] (x,y), occlusion [B,Q,T] logits. */
+int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, const float* grid,
+                                         const float* query_points, int B, int Q, int T, int h, int w,
+                                         float* points, float* occlusion, void* stream);
+
 /* One grid of TAPIR.get_query_features (tapir_model.py:781-849;
  * model_utils.interp mode='nearest' :177-206): trilinear sample of
  * grid [B,T,h,w,C] at query_points [B,Q,3] (t,y,x) given in video pixels

@@ -263,6 +263,48 @@ def tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
   return points, occlusion, expected_dist
 
 
+def tapnet_tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
+                                  feature_grid, query_points, im_hw=(256, 256),
+                                  softmax_temperature=10.0, return_stages=False):
+  """TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171), num_heads = 1.
+
+  The TAP-Net head is the TAPIR head with three differences, all visible in the reference text:
+  there is NO ReLU between the stride-2 convolution `hid3` and the spatial mean (:160-161 vs
+  tapir_model.py:460-462), `occ_out` has ONE output (occlusion only, no expected distance; :90),
+  and the softmax temperature is 10 (:61).  Conv3D kernels of shape [1,3,3] over (t, h, w) are 2-D
+  3x3 convolutions per frame.  Weights: `tapnet_cost_volume_track_mods.{hid1,hid2,hid3,hid4,
+  occ_out}.{weight,bias}` in the torch layout of the TAPIR head (hid1 [16,1,3,3], ..., occ_out [1,16]).
+
+  Parity status: UNPINNED.  The reference has no torch twin of TAP-Net and JAX cannot run offline;
+  this restatement shares every line of arithmetic with `tracks_from_cost_volume` above (pinned to the
+  reference's torch TAPIR) except the three differences listed.
+
+  interp_feature [B,N,C]; feature_grid [B,T,h,w,C]; returns points [B,N,T,2], occlusion [B,N,T]."""
+  p = 'tapnet_cost_volume_track_mods.'
+  dt = feature_grid.dtype
+  cv = build_cost_volume(interp_feature, feature_grid)  # [T,B,N,h,w]  ('bncd,bthwcd->tbnhwd', d = 1)
+  t, b, n, h, w = cv.shape
+  x = cv.reshape(t * b * n, h, w, 1)
+  hid1 = np.maximum(conv2d_same(x, weights[p + 'hid1.weight'], weights[p + 'hid1.bias']), 0)
+  logits = conv2d_same(hid1, weights[p + 'hid2.weight'], weights[p + 'hid2.bias'])
+  logits = logits.reshape(t, b, n, h, w).transpose(1, 2, 0, 3, 4)  # b n t h w
+  z = logits * dt.type(softmax_temperature)
+  z = z - z.max(axis=(-2, -1), keepdims=True)
+  e = np.exp(z)
+  sm = (e / e.sum(axis=(-2, -1), keepdims=True)).astype(dt)
+  points = heatmaps_to_points(sm, im_hw, query_points)
+  occ = conv2d_same(hid1, weights[p + 'hid3.weight'], weights[p + 'hid3.bias'], stride=2)   # no ReLU
+  occ = occ.mean(axis=(1, 2), dtype=dt)
+  occ = np.maximum(occ @ weights[p + 'hid4.weight'].T.astype(dt) + weights[p + 'hid4.bias'].astype(dt), 0)
+  occ = occ @ weights[p + 'occ_out.weight'].T.astype(dt) + weights[p + 'occ_out.bias'].astype(dt)
+  occlusion = occ.reshape(t, b, n).transpose(1, 2, 0)
+  if return_stages:
+    flat = sm.reshape(b, n, t, h * w)
+    srt = np.sort(flat, axis=-1)
+    return points, occlusion, dict(top2_rel_gap=(srt[..., -1] - srt[..., -2]) / srt[..., -1])
+  return points, occlusion
+
+
 # ---------------------------------------------------------------------------
 # R3: PIPs patch correlation (front half of refine_pips)
 # ---------------------------------------------------------------------------

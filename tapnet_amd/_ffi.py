@@ -68,6 +68,8 @@ PROTOTYPES = {
     'tapir_tracks_from_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                               c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p]),
+    'tapir_tapnet_tracks_from_cost_volume': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'tapir_get_query_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tapir_pips_mixer': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -51,6 +51,8 @@ struct CvFusedArgs {
   int B, Q, T, h, w;
   float temperature;
   float img_h, img_w;
+  int tapnet;             // 1: TAP-Net head (tapnet_model.py:157-166): no ReLU after the stride-2
+                          // convolution, ONE output logit (occlusion; expd is not written)
   long long* dbg_times;   // TRACE build: [workgroups][8] shader-cycle totals per phase (wave 0)
 };
 
@@ -330,11 +332,12 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
         }
       }
       // D: lane holds channel c (and 16 + c), pixels mt*16 + 4 g + r
+      const float floor3 = a.tapnet ? -3.0e38f : 0.f;   // TAPIR: ReLU (tapir_model.py:461); TAP-Net: none
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (mt * 16 + 4 * g + r < opix) {
-          osum[0] += fmaxf(acc0[r] + b3a, 0.f);
-          osum[1] += fmaxf(acc1[r] + b3b, 0.f);
+          osum[0] += fmaxf(acc0[r] + b3a, floor3);
+          osum[1] += fmaxf(acc1[r] + b3b, floor3);
         }
       }
     }
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
       }
       wave_sync();
       const long map = (b * a.Q + q0 + m) * a.T + t;
-      if (lane < 2) {
+      if (lane < (a.tapnet ? 1 : 2)) {
         float acc = a.wt.b5[lane];
         for (int k = 0; k < 16; ++k) acc = fmaf(a.wt.w5[lane * 16 + k], s_vec[32 + k], acc);
         if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;

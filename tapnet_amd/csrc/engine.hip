@@ -50,6 +50,9 @@ struct tapir_ctx {
 
   // cost-volume head weights (f32)
   CvHeadWeights cvw;
+  CvHeadWeights tapnet_cvw;          // TAP-Net head (tapnet_model.py:64-107), uploaded when its weights are set
+  bool tapnet_ready = false;
+  bool tapir_ready = false;          // the TAPIR weights (heads + mixer) are uploaded
   // mixer weights
   int in_dim = 0, k0_pad = 0;       // 388 + 49*(2+pyr), padded to the GEMM k-step
   void* W0 = nullptr; float* b0 = nullptr;        // [512, k0_pad]
@@ -180,6 +183,46 @@ int get_w(tapir_ctx* c, const std::string& name, std::vector<int64_t> shape, con
 }
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != TAPIR_OK) return rc_; } while (0)
+
+// uploads one cost-volume head (TAPIR: tapir_model.py:342-361, n_out = 2; TAP-Net:
+// tapnet_model.py:64-107, n_out = 1) from the host tensors named prefix + {hid1..occ_out}
+int upload_cv_head(tapir_ctx* c, const std::string& cv, int n_out, CvHeadWeights* out) {
+  const HostTensor* t;
+  float* tmp;
+  TRY(get_w(c, cv + "hid1.weight", {16, 1, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); out->w1 = tmp;
+  TRY(get_w(c, cv + "hid1.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); out->b1 = tmp;
+  TRY(get_w(c, cv + "hid2.weight", {1, 16, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); out->w2 = tmp;
+  TRY(get_w(c, cv + "hid2.bias", {1}, &t)); TRY(upload_f32(c, t->data.data(), 1, &tmp)); out->b2 = tmp;
+  TRY(get_w(c, cv + "hid3.weight", {32, 16, 3, 3}, &t));
+  {
+    std::vector<float> r(144 * 32);
+    for (int co = 0; co < 32; ++co)
+      for (int ci = 0; ci < 16; ++ci)
+        for (int k = 0; k < 9; ++k) r[(ci * 9 + k) * 32 + co] = t->data[(co * 16 + ci) * 9 + k];
+    TRY(upload_f32(c, r.data(), r.size(), &tmp)); out->w3 = tmp;
+    // bf16 build: the same weights as MFMA 16x16x32 B fragments, k = tap*16 + ci padded to 160:
+    // fragment (k-step s, n-tile nt), lane l: column n = l & 15, k = 32 s + 8 (l >> 4) + j
+    std::vector<uint16_t> fb((size_t)5 * 2 * 64 * 8, 0);
+    for (int s5 = 0; s5 < 5; ++s5)
+      for (int nt = 0; nt < 2; ++nt)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s5 + 8 * (l >> 4) + j, tap = k / 16, ci = k % 16, co = nt * 16 + (l & 15);
+            if (tap < 9) fb[(((size_t)s5 * 2 + nt) * 64 + l) * 8 + j] = host_f2bf(t->data[(co * 16 + ci) * 9 + tap]);
+          }
+    void* dfb = nullptr;
+    HIP_TRY(c, hipMalloc(&dfb, fb.size() * 2));
+    c->owned.push_back(dfb);
+    HIP_TRY(c, hipMemcpy(dfb, fb.data(), fb.size() * 2, hipMemcpyHostToDevice));
+    out->w3b = (const uint4*)dfb;
+  }
+  TRY(get_w(c, cv + "hid3.bias", {32}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); out->b3 = tmp;
+  TRY(get_w(c, cv + "hid4.weight", {16, 32}, &t)); TRY(upload_f32(c, t->data.data(), 512, &tmp)); out->w4 = tmp;
+  TRY(get_w(c, cv + "hid4.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); out->b4 = tmp;
+  TRY(get_w(c, cv + "occ_out.weight", {n_out, 16}, &t)); TRY(upload_f32(c, t->data.data(), (size_t)n_out * 16, &tmp)); out->w5 = tmp;
+  TRY(get_w(c, cv + "occ_out.bias", {n_out}, &t)); TRY(upload_f32(c, t->data.data(), (size_t)n_out, &tmp)); out->b5 = tmp;
+  return TAPIR_OK;
+}
 
 // ---- weights of the fused mixer kernel (mixer_fused.hpp): every wave reads ONE linear stream of
 // 1-KiB MFMA A fragments, in the order it multiplies them.  Fragment (row0, k0) of matrix W [rows,
@@ -377,7 +420,7 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
 template <typename TA>
 int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const float* qpts_init,
                       int B, int Q, int T, int h, int w, float* points, float* occ, float* expd,
-                      hipStream_t s) {
+                      hipStream_t s, bool tapnet = false) {
   const int C = kLowresDim, hw = h * w;
   const void* qf_op = qfeat;
   const void* grid_op = grid;
@@ -390,16 +433,18 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   if (cv_fused_supported(h, w) && c->cv_mode != 1) {
     // one kernel: contraction on the matrix cores into LDS + heads; no volume in HBM
     CvFusedArgs fa{};
-    fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = c->cvw; fa.qpts = qpts_init;
+    fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = tapnet ? c->tapnet_cvw : c->cvw; fa.qpts = qpts_init;
+    fa.tapnet = tapnet ? 1 : 0;
     fa.points = points; fa.occ = occ; fa.expd = expd;
     fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w;
-    fa.temperature = c->cfg.softmax_temperature;
+    fa.temperature = tapnet ? 10.0f : c->cfg.softmax_temperature;   // tapnet_model.py:61
     fa.img_h = (float)c->cfg.initial_h; fa.img_w = (float)c->cfg.initial_w;
     fa.dbg_times = (long long*)c->dbg_times;
     ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
     launch_cv_fused<TA>(fa, s);
     return TAPIR_OK;
   }
+  if (tapnet) return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells");
   // grids beyond 32 x 32 cells (or cv_mode 1, tools): einsum into a workspace of <= 256 MiB per
   // launch, then the heads kernel
   long qc = (256L << 20) / ((long)T * hw * 4);
@@ -753,11 +798,16 @@ int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
 #define DISPATCH(ctx, fn, ...) \
   ((ctx)->cfg.dtype == TAPIR_BF16 ? fn<bf16_t>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 
-#define REQUIRE_READY(ctx)                                                         \
+#define REQUIRE_FINALIZED(ctx)                                                     \
   do {                                                                             \
     if (!(ctx)) return TAPIR_ERR_INVALID;                                          \
     if (!(ctx)->finalized) return fail((ctx), TAPIR_ERR_WEIGHTS, "weights not finalized"); \
     HIP_TRY((ctx), hipSetDevice((ctx)->device));                                   \
+  } while (0)
+#define REQUIRE_READY(ctx)                                                         \
+  do {                                                                             \
+    REQUIRE_FINALIZED(ctx);                                                        \
+    if (!(ctx)->tapir_ready) return fail((ctx), TAPIR_ERR_WEIGHTS, "TAPIR weights not set (TAP-Net head only)"); \
   } while (0)
 
 extern "C" {
@@ -815,48 +865,36 @@ int tapir_set_weight(tapir_ctx* c, const char* name, const float* data, const in
   return TAPIR_OK;
 }
 
+static int finalize_tapir(tapir_ctx* c);
+
 int tapir_finalize_weights(tapir_ctx* c) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   for (void* p : c->owned) (void)hipFree(p);
   c->owned.clear();
   c->blocks.clear();
-  const HostTensor* t;
-  const std::string cv = "torch_cost_volume_track_mods.";
-  float* tmp;
-  TRY(get_w(c, cv + "hid1.weight", {16, 1, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); c->cvw.w1 = tmp;
-  TRY(get_w(c, cv + "hid1.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); c->cvw.b1 = tmp;
-  TRY(get_w(c, cv + "hid2.weight", {1, 16, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); c->cvw.w2 = tmp;
-  TRY(get_w(c, cv + "hid2.bias", {1}, &t)); TRY(upload_f32(c, t->data.data(), 1, &tmp)); c->cvw.b2 = tmp;
-  TRY(get_w(c, cv + "hid3.weight", {32, 16, 3, 3}, &t));
-  {
-    std::vector<float> r(144 * 32);
-    for (int co = 0; co < 32; ++co)
-      for (int ci = 0; ci < 16; ++ci)
-        for (int k = 0; k < 9; ++k) r[(ci * 9 + k) * 32 + co] = t->data[(co * 16 + ci) * 9 + k];
-    TRY(upload_f32(c, r.data(), r.size(), &tmp)); c->cvw.w3 = tmp;
-    // bf16 build: the same weights as MFMA 16x16x32 B fragments, k = tap*16 + ci padded to 160:
-    // fragment (k-step s, n-tile nt), lane l: column n = l & 15, k = 32 s + 8 (l >> 4) + j
-    std::vector<uint16_t> fb((size_t)5 * 2 * 64 * 8, 0);
-    for (int s5 = 0; s5 < 5; ++s5)
-      for (int nt = 0; nt < 2; ++nt)
-        for (int l = 0; l < 64; ++l)
-          for (int j = 0; j < 8; ++j) {
-            const int k = 32 * s5 + 8 * (l >> 4) + j, tap = k / 16, ci = k % 16, co = nt * 16 + (l & 15);
-            if (tap < 9) fb[(((size_t)s5 * 2 + nt) * 64 + l) * 8 + j] = host_f2bf(t->data[(co * 16 + ci) * 9 + tap]);
-          }
-    void* dfb = nullptr;
-    HIP_TRY(c, hipMalloc(&dfb, fb.size() * 2));
-    c->owned.push_back(dfb);
-    HIP_TRY(c, hipMemcpy(dfb, fb.data(), fb.size() * 2, hipMemcpyHostToDevice));
-    c->cvw.w3b = (const uint4*)dfb;
+  c->tapnet_ready = false; c->tapir_ready = false;
+  c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
+  const bool has_tapnet = c->host_w.count("tapnet_cost_volume_track_mods.hid1.weight") != 0;
+  bool has_tapir = !has_tapnet;   // a context without TAP-Net head weights must be a complete TAPIR
+  for (const auto& kv : c->host_w)
+    if (kv.first.rfind("torch_", 0) == 0) has_tapir = true;
+  if (has_tapnet) {
+    TRY(upload_cv_head(c, "tapnet_cost_volume_track_mods.", 1, &c->tapnet_cvw));
+    c->tapnet_ready = true;
   }
-  TRY(get_w(c, cv + "hid3.bias", {32}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); c->cvw.b3 = tmp;
-  TRY(get_w(c, cv + "hid4.weight", {16, 32}, &t)); TRY(upload_f32(c, t->data.data(), 512, &tmp)); c->cvw.w4 = tmp;
-  TRY(get_w(c, cv + "hid4.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); c->cvw.b4 = tmp;
-  TRY(get_w(c, cv + "occ_out.weight", {2, 16}, &t)); TRY(upload_f32(c, t->data.data(), 32, &tmp)); c->cvw.w5 = tmp;
-  TRY(get_w(c, cv + "occ_out.bias", {2}, &t)); TRY(upload_f32(c, t->data.data(), 2, &tmp)); c->cvw.b5 = tmp;
+  if (has_tapir) {
+    TRY(finalize_tapir(c));
+    c->tapir_ready = true;
+  }
+  c->host_w.clear();
+  c->finalized = true;
+  return TAPIR_OK;
+}
 
+static int finalize_tapir(tapir_ctx* c) {
+  const HostTensor* t;
+  TRY(upload_cv_head(c, "torch_cost_volume_track_mods.", 2, &c->cvw));
   const std::string mx = "torch_pips_mixer.";
   TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &t));
   TRY(upload_matrix(c, t->data.data(), kHidden, c->in_dim, c->k0_pad, &c->W0));
@@ -882,13 +920,10 @@ int tapir_finalize_weights(tapir_ctx* c) {
     TRY(get_w(c, p + "conv_channels_mixer.mlp2_down.bias", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.bdn));
     c->blocks.push_back(b);
   }
-  c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
   if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
     if (c->cfg.dtype == TAPIR_BF16) TRY(build_fused_weights<bf16_t>(c));
     else TRY(build_fused_weights<float>(c));
   }
-  c->host_w.clear();
-  c->finalized = true;
   return TAPIR_OK;
 }
 
@@ -944,6 +979,19 @@ int tapir_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float*
   if (((long)T * h * w) % 4 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points,
                   occlusion, expected_dist, (hipStream_t)stream);
+}
+
+int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float* grid,
+                                         const float* query_points, int B, int Q, int T, int h, int w,
+                                         float* points, float* occlusion, void* stream) {
+  REQUIRE_FINALIZED(c);
+  if (!c->tapnet_ready) return fail(c, TAPIR_ERR_WEIGHTS, "TAP-Net head weights (tapnet_cost_volume_track_mods.*) not set");
+  if (!qfeat || !grid || !points || !occlusion || B < 1 || Q < 1 || T < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (c->cv_mode == 1 || !cv_fused_supported(h, w))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells (fused kernel only)");
+  return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points, occlusion,
+                  nullptr, (hipStream_t)stream, true);
 }
 
 int tapir_get_query_features(tapir_ctx* c, const float* grid, const float* query_points, int B,

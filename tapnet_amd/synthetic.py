@@ -102,6 +102,28 @@ def make_weights(seed: int = 0, pyramid_level: int = 1, extra_convs: bool = True
   return w
 
 
+def make_tapnet_head_weights(seed: int = 0, peaky: bool = True) -> Dict[str, np.ndarray]:
+  """Seeded weights of the TAP-Net cost-volume head (tapnet/models/tapnet_model.py:64-107) under the
+  names tapnet_amd.tapnet_model loads, torch layout of the TAPIR head (occ_out has ONE output)."""
+  rng = np.random.default_rng(seed)
+  w: Dict[str, np.ndarray] = {}
+  c = 'tapnet_cost_volume_track_mods.'
+  for name, co, ci in (('hid1', 16, 1), ('hid2', 1, 16), ('hid3', 32, 16)):
+    w[c + name + '.weight'] = _normal(rng, (co, ci, 3, 3), 1.0 / np.sqrt(ci * 9))
+    w[c + name + '.bias'] = _normal(rng, (co,), 0.02)
+  for name, co, ci in (('hid4', 16, 32), ('occ_out', 1, 16)):
+    w[c + name + '.weight'] = _normal(rng, (co, ci), 1.0 / np.sqrt(ci))
+    w[c + name + '.bias'] = _normal(rng, (co,), 0.02)
+  if peaky:
+    w[c + 'hid1.weight'][0] = 0.0
+    w[c + 'hid1.weight'][0, 0, 1, 1] = 1.0
+    w[c + 'hid1.bias'][0] = 0.0
+    w[c + 'hid2.weight'] *= np.float32(0.1)
+    w[c + 'hid2.weight'][0, 0] = 0.0
+    w[c + 'hid2.weight'][0, 0, 1, 1] = 3.0
+  return w
+
+
 def make_video(seed: int, num_frames: int, height: int, width: int,
                batch: int = 1, texture: bool = True) -> np.ndarray:
   """Synthetic clip [B,T,H,W,3] float32 in [-1,1].

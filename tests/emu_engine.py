@@ -92,6 +92,15 @@ class EmuEngine:
         'tracks_from_cost_volume')
     return pts, occ, expd
 
+  def tapnet_tracks_from_cost_volume(self, qfeat, grid, qpts):
+    qfeat, grid, qpts = f32(qfeat), f32(grid), f32(qpts)
+    B, Q, _ = qfeat.shape
+    _, T, h, w, _ = grid.shape
+    pts = np.zeros((B, Q, T, 2), np.float32); occ = np.zeros((B, Q, T), np.float32)
+    self._chk(self.lib.tapir_tapnet_tracks_from_cost_volume(self.ctx, _p(qfeat), _p(grid), _p(qpts), B, Q, T, h, w,
+                                                            _p(pts), _p(occ), None), 'tapnet head')
+    return pts, occ
+
   def get_query_features(self, grid, qpts, video_hw):
     grid, qpts = f32(grid), f32(qpts)
     B, T, h, w, C = grid.shape

@@ -525,3 +525,32 @@ def test_online_tracker_multilevel_update_points_golden(use_graph):
       m(g['video'], False, big)
     out2 = trk.step(video[:, 0:1])   # the session still works
     assert torch.isfinite(out2['tracks']).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_tapnet_head_vs_oracle_gpu(dtype):
+  """tapnet_amd.tapnet_model.TAPNet (mirror of tapnet/models/tapnet_model.py:45-290
+  from a precomputed feature grid) at the TAP-Vid-Kubric shape (24 frames, 256x256 -> 32x32 grid):
+  query-feature sampling + cost-volume head on the GPU against the numpy restatement."""
+  from tapnet_amd import tapnet_model
+  w = synthetic.make_tapnet_head_weights(5)
+  m = tapnet_model.TAPNet(weights=w, dtype=dtype, device='cuda:0')
+  rng = np.random.default_rng(2)
+  B, T, Q, H = 1, 24, 40, 256
+  grid = O.l2_normalize(rng.standard_normal((B, T, 32, 32, 256)).astype(np.float32))
+  qp = synthetic.make_queries(3, Q, T, H, H)
+  out = m((B, T, H, H, 3), False, qp, query_chunk_size=16, get_query_feats=True, feature_grid=grid)
+  ql, _ = O.get_query_features([grid], [grid[..., :128]], [(H, H)], qp, (B, T, H, H, 3))
+  np.testing.assert_allclose(out['query_feats'], ql[0], atol=2e-6)
+  g_ref, q_ref = (bf16_round(grid), bf16_round(ql[0])) if dtype == 'bfloat16' else (grid, ql[0])
+  rp, ro, st = O.tapnet_tracks_from_cost_volume(w, q_ref, g_ref, qp, (H, H), return_stages=True)
+  ok = st['top2_rel_gap'] > 1e-3
+  assert ok.mean() > 0.9
+  np.testing.assert_allclose(out['occlusion'], ro, atol=1e-4 if dtype == 'float32' else 3e-2)
+  np.testing.assert_allclose(out['tracks'][ok], rp[ok], atol=1e-3 if dtype == 'float32' else 5e-3)
+  assert out['tracks'].shape == (B, Q, T, 2) and out['occlusion'].shape == (B, Q, T)
+  with pytest.raises(NotImplementedError):
+    m(np.zeros((B, T, H, H, 3), np.float32), False, qp)
+  with pytest.raises(ValueError):
+    tapnet_model.TAPNet(num_heads=2, weights=w, device='cuda:0')

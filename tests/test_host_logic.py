@@ -97,3 +97,22 @@ def test_haiku_name_conversion_shapes():
   for k, v in back.items():
     np.testing.assert_array_equal(v, w[k])
   assert 'torch_pips_mixer.blocks.1.mlp1_up.weight' in back
+
+
+def test_tapnet_haiku_param_conversion():
+  """tapnet_amd.tapnet_model.from_haiku_params: hk.Conv3D kernels [1,3,3,in,out] / hk.Linear [in,out]
+  (tapnet/models/tapnet_model.py:64-107) -> the torch layout of the TAPIR head the engine loads."""
+  import numpy as np
+  from tapnet_amd import tapnet_model
+  rng = np.random.default_rng(0)
+  shapes = {'cost_volume_regression_1': (1, 3, 3, 1, 16), 'cost_volume_regression_2': (1, 3, 3, 16, 1),
+            'cost_volume_occlusion_1': (1, 3, 3, 16, 32), 'cost_volume_occlusion_2': (32, 16),
+            'occlusion_out': (16, 1)}
+  params = {f'tap_net/{k}': {'w': rng.standard_normal(s).astype(np.float32),
+                             'b': rng.standard_normal(s[-1]).astype(np.float32)} for k, s in shapes.items()}
+  flat = tapnet_model.from_haiku_params(params)
+  assert flat['tapnet_cost_volume_track_mods.hid3.weight'].shape == (32, 16, 3, 3)
+  assert flat['tapnet_cost_volume_track_mods.occ_out.weight'].shape == (1, 16)
+  w = params['tap_net/cost_volume_occlusion_1']['w']
+  assert flat['tapnet_cost_volume_track_mods.hid3.weight'][5, 7, 2, 1] == w[0, 2, 1, 7, 5]
+  assert flat['tapnet_cost_volume_track_mods.hid4.weight'][3, 9] == params['tap_net/cost_volume_occlusion_2']['w'][9, 3]

@@ -3,6 +3,8 @@
 reference-generated golden fixtures.  This validates indexing / fragment
 layouts / halo logic without a GPU; the `-m gpu` tests repeat the same checks
 on the real gfx950 library."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -277,4 +279,34 @@ def test_cost_volume_fused_matches_workspace_path(dtype):
     np.testing.assert_allclose(expd, expd1, atol=2e-2)
     d = np.linalg.norm(pts - pts1, axis=-1)
     assert np.median(d) < 1e-3 and np.mean(d < 0.05) > 0.97, (np.median(d), d.max())
+  e.close()
+
+
+@pytest.mark.parametrize('dtype,hw', [(_ffi.TAPIR_F32, (32, 32)), (_ffi.TAPIR_F32, (9, 5)), (_ffi.TAPIR_BF16, (16, 16))])
+def test_tapnet_head_vs_oracle(dtype, hw):
+  """TAPNet.tracks_from_cost_volume (tapnet_model.py:111-171) on the fused cost-volume
+  kernel -- no ReLU after the stride-2 convolution, one occlusion logit, temperature 10 -- against the
+  numpy restatement; a context that holds ONLY the TAP-Net head weights."""
+  w = synthetic.make_tapnet_head_weights(3)
+  h, wd = hw
+  e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(8 * h, 8 * wd), dtype=dtype)
+  rng = np.random.default_rng(11)
+  B, Q, T = 1, 9, 3
+  grid = O.l2_normalize(rng.standard_normal((B, T, h, wd, 256)).astype(np.float32))
+  qf = O.l2_normalize(rng.standard_normal((B, Q, 256)).astype(np.float32))
+  qp = np.stack([rng.integers(0, T, (B, Q)), rng.uniform(0, 8 * h, (B, Q)),
+                 rng.uniform(0, 8 * wd, (B, Q))], -1).astype(np.float32)
+  pts, occ = e.tapnet_tracks_from_cost_volume(qf, grid, qp)
+  if dtype == _ffi.TAPIR_BF16:
+    qf, grid = bf16_round(qf), bf16_round(grid)
+  rp, ro, st = O.tapnet_tracks_from_cost_volume(w, qf, grid, qp, (8 * h, 8 * wd), return_stages=True)
+  ok = st['top2_rel_gap'] > 1e-3
+  np.testing.assert_allclose(occ, ro, atol=1e-4 if dtype == _ffi.TAPIR_F32 else 3e-2)
+  np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3 if dtype == _ffi.TAPIR_F32 else 2e-3)
+  # a TAP-Net-only context refuses the TAPIR entry points with an error code
+  out = np.zeros((B, Q, T, 2), np.float32)
+  rc = e.lib.tapir_tracks_from_cost_volume(e.ctx, qf.ctypes.data_as(ctypes.c_void_p), grid.ctypes.data_as(ctypes.c_void_p),
+                                           None, B, Q, T, h, wd, out.ctypes.data_as(ctypes.c_void_p),
+                                           out.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), None)
+  assert rc == _ffi.TAPIR_ERR_WEIGHTS
   e.close()
