@@ -15,12 +15,12 @@
 // Layout.  512 threads = 8 waves.  Wave w owns output channels [64 w, 64 w + 64) of every
 // 512-wide tensor.  The residual x[t][ch] lives in MFMA accumulator layout (v_mfma 16x16, weights
 // on the A port, tokens on the B port): register xr[a][i][r] of lane l (c = l & 15, g = l >> 4)
-// is channel 64 w + 16 a + 4 g + r of token t = 16 i + c.  In this layout
+// is channel 64 w + 16 a + 4 g + r of token t = NT c + i (NT = token tiles).  In this layout
 //   * the channel MLP's second GEMM accumulates straight into the residual (+ skip for free),
 //   * a lane holds 4 consecutive channels of one token: LayerNorm / GELU outputs go to LDS as
 //     8-byte (bf16) stores in the [token][channel] image the next GEMM reads as its B operand,
-//   * the time axis runs along the 16 lanes of a DPP row: the temporal convolutions shift by
-//     row_shr / row_shl and patch the row edge from the neighbouring token tile (row_ror).
+//   * tokens are interleaved over the token tiles (column c of tile i = token NT c + i), so the
+//     temporal convolutions find t-1 / t+1 in the same lane, one DPP row shift at the tile ends.
 // Weights are never shared between waves (a wave multiplies ITS 64 output rows, or its slice of the
 // hidden rows, by all tokens), so they do not go through LDS at all: the host packs them per wave
 // into one linear stream of 1-KiB MFMA A-fragments in exactly the order the wave consumes them
@@ -90,31 +90,28 @@ inline long fused_frags_per_wave(int k0_pad, int nblocks) {
   return in + nblocks * blk + out + FM_RING;   // + one ring of padding (prefetched, never used)
 }
 
-// ---- time shifts along the token axis of the MFMA column layout (token = 16 i + (lane & 15)) ----
-// value of token t-1: lane c <- lane c-1 of v, lane 0 <- lane 15 of vprev (the previous token tile;
-// pass 0 for the first tile: SAME padding).  Two DPP moves: row_ror:1 of vprev as the fill value,
-// row_shr:1 of v over it (bound_ctrl off: lanes whose source falls off the row keep the fill).
-__device__ __forceinline__ float tok_prev(float v, float vprev, int lane) {
+// ---- time shifts.  Tokens are INTERLEAVED over the token tiles: column c of tile i holds token
+// NT * c + i, so the neighbours t-1 / t+1 of a token sit in the same lane (tiles i-1 / i+1) except at
+// the first / last tile, where they are tile NT-1 of lane c-1 / tile 0 of lane c+1: ONE DPP row shift
+// with zero fill (bound_ctrl), which is also exactly the SAME zero padding at both clip ends.  (With
+// contiguous tiles, token = 16 i + c, every shifted value took two DPP moves plus their wait states.)
+// lane_up(v): lane c <- lane c-1 (0 into lane 0);  lane_dn(v): lane c <- lane c+1 (0 into lane 15)
+__device__ __forceinline__ float lane_up(float v, int lane) {
 #ifdef TAPIR_HIPEMU
   const float a = __shfl(v, (lane & 48) | ((lane - 1) & 15));
-  const float b = __shfl(vprev, (lane & 48) | 15);
-  return (lane & 15) ? a : b;
+  return (lane & 15) ? a : 0.f;
 #else
   (void)lane;
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(vprev), 0x121, 0xf, 0xf, false);
-  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x111, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
 #endif
 }
-// value of token t+1: lane c <- lane c+1 of v, lane 15 <- lane 0 of vnext
-__device__ __forceinline__ float tok_next(float v, float vnext, int lane) {
+__device__ __forceinline__ float lane_dn(float v, int lane) {
 #ifdef TAPIR_HIPEMU
   const float a = __shfl(v, (lane & 48) | ((lane + 1) & 15));
-  const float b = __shfl(vnext, (lane & 48));
-  return ((lane & 15) != 15) ? a : b;
+  return ((lane & 15) != 15) ? a : 0.f;
 #else
   (void)lane;
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(vnext), 0x12F, 0xf, 0xf, false);
-  return __int_as_float(__builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x101, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
 #endif
 }
 
@@ -242,9 +239,9 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   // temporal-convolution parameters of a block (64 KiB) while its token mixing runs
   constexpr int PAR_BYTES = kHidden * FM_MIXW * 4;
   constexpr int ACT_BYTES = XN_BYTES + 2 * H_BYTES > PAR_BYTES ? XN_BYTES + 2 * H_BYTES : PAR_BYTES;
-  static_assert(ACT_BYTES + 2 * ROWS * 8 * 4 + kHidden4 * 4 <= 160 * 1024, "LDS budget");
+  static_assert(ACT_BYTES + 2 * ROWS * 8 * 8 + kHidden4 * 4 <= 160 * 1024, "LDS budget");
   __shared__ uint4 s_act[ACT_BYTES / 16];
-  __shared__ float s_stat[2][ROWS][8];      // per-wave partial sums of the LayerNorm statistics
+  __shared__ __attribute__((aligned(16))) float2 s_stat[2][ROWS][8];   // per-wave (sum, M2) LayerNorm summaries
   __shared__ float s_bup[kHidden4];         // up-projection bias of the current block (see below)
 
   const int tid = threadIdx.x;
@@ -285,8 +282,9 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
         reinterpret_cast<const char*>(a.mlp_in) + (long)n * T * in_stride);
     for (int id = tid; id < ROWS * cpr; id += FM_THREADS) {
       const int row = id / cpr, q = id - row * cpr;
+      const int tok = NT * (row & 15) + (row >> 4);   // LDS row 16 i + c holds token NT c + i
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (row < T) v = src[id];
+      if (tok < T) v = src[tok * cpr + q];
       s_act[row * cpr + (q ^ (row & 15))] = v;
     }
   }
@@ -305,11 +303,17 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 
   float valid[NT];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) valid[i] = (16 * i + c < T) ? 1.0f : 0.0f;
+  for (int i = 0; i < NT; ++i) valid[i] = (NT * c + i < T) ? 1.0f : 0.0f;
 
-  // per-token LayerNorm statistics over the 512 channels spread over lane groups and waves
+  // per-token LayerNorm statistics over the 512 channels spread over lane groups and waves: every
+  // wave reduces its 64 channels to (sum, M2 about ITS mean) -- two-pass inside the wave -- and the
+  // eight summaries merge with Chan's formula (equal counts): ONE barrier per LayerNorm and the
+  // numerics of the two-pass form.  Two summary buffers alternate between consecutive LayerNorms.
+  int ln_phase = 0;
   auto ln_stats = [&](float (&mean)[NT], float (&rstd)[NT]) {
-    float s[NT];
+    float2 (*stat)[8] = s_stat[ln_phase];
+    ln_phase ^= 1;
+    float s[NT], m2[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       float t = 0.f;
@@ -321,41 +325,45 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 16);
 #pragma unroll
     for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 32);
-    if (g == 0) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) s_stat[0][16 * i + c][wave] = s[i];
-    }
-    lds_barrier();
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&s_stat[0][16 * i + c][0]);
-      const float4 p1 = *reinterpret_cast<const float4*>(&s_stat[0][16 * i + c][4]);
-      mean[i] = (((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w))) * (1.0f / kHidden);
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
+      const float mw = s[i] * (1.0f / 64.0f);
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = xr[q][i][r] - mean[i]; t = fmaf(d, d, t); }
-      s[i] = t;
+        for (int r = 0; r < 4; ++r) { const float d = xr[q][i][r] - mw; t = fmaf(d, d, t); }
+      m2[i] = t;
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 16);
+    for (int i = 0; i < NT; ++i) m2[i] += __shfl_xor(m2[i], 16);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) s[i] += __shfl_xor(s[i], 32);
+    for (int i = 0; i < NT; ++i) m2[i] += __shfl_xor(m2[i], 32);
     if (g == 0) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i) s_stat[1][16 * i + c][wave] = s[i];
+      for (int i = 0; i < NT; ++i) stat[16 * i + c][wave] = make_float2(s[i], m2[i]);
     }
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&s_stat[1][16 * i + c][0]);
-      const float4 p1 = *reinterpret_cast<const float4*>(&s_stat[1][16 * i + c][4]);
-      const float var = (((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w))) * (1.0f / kHidden);
-      rstd[i] = 1.0f / sqrtf(var + kLnEps);
+      float2 p[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(&stat[16 * i + c][2 * k]);
+        p[2 * k] = make_float2(v.x, v.y); p[2 * k + 1] = make_float2(v.z, v.w);
+      }
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tot += p[k].x;
+      const float mu = tot * (1.0f / kHidden);
+      float M2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = p[k].x * (1.0f / 64.0f) - mu;
+        M2 += p[k].y + 64.0f * d * d;
+      }
+      mean[i] = mu;
+      rstd[i] = 1.0f / sqrtf(M2 * (1.0f / kHidden) + kLnEps);
     }
   };
 
@@ -422,9 +430,8 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-          const f32x2 xa = i > 0 ? xc[i - 1] : zero, xb = i + 1 < NT ? xc[i + 1] : zero;
-          xp[i] = f32x2{tok_prev(xc[i].x, xa.x, lane), tok_prev(xc[i].y, xa.y, lane)};
-          xq[i] = f32x2{tok_next(xc[i].x, xb.x, lane), tok_next(xc[i].y, xb.y, lane)};
+          xp[i] = i > 0 ? xc[i - 1] : f32x2{lane_up(xc[NT - 1].x, lane), lane_up(xc[NT - 1].y, lane)};
+          xq[i] = i + 1 < NT ? xc[i + 1] : f32x2{lane_dn(xc[0].x, lane), lane_dn(xc[0].y, lane)};
           s0[i] = zero; s1[i] = zero; s2[i] = zero;
         }
         f32x2 bsum = zero;
@@ -453,9 +460,9 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
         // of the four GELU outputs: 2 shifted values per token tile instead of 8)
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-          const f32x2 pa = i > 0 ? s0[i - 1] : zero, pb = i + 1 < NT ? s2[i + 1] : zero;
-          const f32x2 y = bsum + f32x2{tok_prev(s0[i].x, pa.x, lane), tok_prev(s0[i].y, pa.y, lane)} + s1[i] +
-                          f32x2{tok_next(s2[i].x, pb.x, lane), tok_next(s2[i].y, pb.y, lane)};
+          const f32x2 pa = i > 0 ? s0[i - 1] : f32x2{lane_up(s0[NT - 1].x, lane), lane_up(s0[NT - 1].y, lane)};
+          const f32x2 pb = i + 1 < NT ? s2[i + 1] : f32x2{lane_dn(s2[0].x, lane), lane_dn(s2[0].y, lane)};
+          const f32x2 y = bsum + pa + s1[i] + pb;
           xr[q][i][2 * rp] += y.x;
           xr[q][i][2 * rp + 1] += y.y;
         }
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
       const int o0 = ch_lane + 16 * q;
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const int t = 16 * i + c;
+        const int t = NT * c + i;
         if (o0 < kMixOut && t < T)
           *reinterpret_cast<f32x4*>(a.res + ((long)n * T + t) * kMixOut + o0) = oa[q][i];
       }
