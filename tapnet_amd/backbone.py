@@ -53,8 +53,9 @@ class Backbone:
                          '(libtapir_hip.so); there is no CPU path')
     # MIOpen exhaustive solver search per convolution shape (first call only): the default
     # heuristic picks atomic split-K implicit-GEMM kernels that need a zero-fill pass per call;
-    # measured 3.12 -> 2.66 ms per 48-frame clip
-    torch.backends.cudnn.benchmark = True
+    # measured 3.12 -> 2.66 ms per 48-frame clip.  The flag is process-wide in PyTorch, so it is set
+    # only around this backbone's own convolutions (features()) and restored afterwards.
+    self.miopen_exhaustive_search = True
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
@@ -189,21 +190,31 @@ class Backbone:
     chunk = n if not chunk else chunk
     run = self._features_hip
     lows, his = [], []
-    for s in range(0, n, chunk):
-      lo, hi = run(frames_nhwc[s:s + chunk])
-      lows.append(lo)
-      his.append(hi)
+    saved = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = bool(self.miopen_exhaustive_search)
+    try:
+      for s in range(0, n, chunk):
+        lo, hi = run(frames_nhwc[s:s + chunk])
+        lows.append(lo)
+        his.append(hi)
+    finally:
+      torch.backends.cudnn.benchmark = saved
     return (torch.cat(lows) if len(lows) > 1 else lows[0],
             torch.cat(his) if len(his) > 1 else his[0])
 
 
-def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int]) -> torch.Tensor:
+def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int], antialias: bool = False) -> torch.Tensor:
   """[B,T,H,W,3] -> [B,T,h,w,3].  The reference's torch twin uses
-  F.interpolate(bilinear, align_corners=False) (tapnet/torch/utils.py:26-42); the JAX
-  model's jax.image.resize additionally anti-aliases when DOWN-sampling
-  (tapir_model.py:670) -- identical for up-sampling and for the no-op 256->256 case
-  (SURVEY.md 8c)."""
+  F.interpolate(bilinear, align_corners=False) (tapnet/torch/utils.py:26-42) -- the default here,
+  and what the fixtures pin.  The JAX model's jax.image.resize(method='bilinear')
+  (tapir_model.py:670) additionally anti-aliases when DOWN-sampling (triangle kernel widened by the
+  scale factor); `antialias=True` selects that behaviour through F.interpolate(antialias=True), the
+  same filter family.  Identical for up-sampling and for the no-op 256->256 case; it matters for
+  inputs larger than initial_resolution (e.g. 512 -> 256, BASELINE configs[4]).  The JAX variant
+  cannot be pinned offline (no jax), hence opt-in: TAPIR(..., jax_antialias_resize=True)."""
   b, t, h, w, c = video.shape
   x = video.permute(0, 1, 4, 2, 3).reshape(b, t * c, h, w)
-  x = F.interpolate(x, size=tuple(resolution), mode='bilinear', align_corners=False)
+  down = resolution[0] < h or resolution[1] < w
+  x = F.interpolate(x, size=tuple(resolution), mode='bilinear', align_corners=False,
+                    antialias=bool(antialias and down))
   return x.reshape(b, t, c, resolution[0], resolution[1]).permute(0, 1, 3, 4, 2)

@@ -117,6 +117,7 @@ class TAPIR:
       device: Any = None,
       haiku_state_names: bool = False,
       use_casual_conv: Optional[bool] = None,
+      jax_antialias_resize: bool = False,
   ):
     del bilinear_interp_with_depthwise_conv, parallelize_query_extraction, name
     if use_casual_conv is not None:   # the torch twin spells the argument this way (torch/tapir_model.py:84)
@@ -140,6 +141,9 @@ class TAPIR:
     self.highres_dim, self.lowres_dim = HIRES_DIM, LOWRES_DIM
     self.dtype = dtype
     self.haiku_state_names = haiku_state_names
+    # jax.image.resize anti-aliases when down-sampling (tapir_model.py:670), the torch twin does not
+    # (tapnet/torch/utils.py:39): False = the torch twin (pinned by the fixtures), True = the JAX text
+    self.jax_antialias_resize = bool(jax_antialias_resize)
 
     if device is None:
       device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
@@ -288,7 +292,7 @@ class TAPIR:
         if model_utils.is_same_res(curr, video.shape[-3:-1]):
           video_resize = video
         else:
-          video_resize = backbone_lib.resize_bilinear(video, resolution)
+          video_resize = backbone_lib.resize_bilinear(video, resolution, self.jax_antialias_resize)
         curr = resolution
         b, t, h, w, c = video_resize.shape
         low, hi = self._backbone.features(video_resize.reshape(b * t, h, w, c),

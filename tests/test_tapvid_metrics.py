@@ -48,3 +48,33 @@ def test_postprocess_occlusions():
   occ = np.array([-5.0, 5.0, -5.0, 0.0])
   expd = np.array([-5.0, -5.0, 5.0, 0.0])
   np.testing.assert_array_equal(tapvid.postprocess_occlusions(occ, expd), [False, True, True, True])
+
+
+def test_evaluate_driver_with_a_perfect_tracker():
+  """tapvid.evaluate (evaluation_datasets.py:48-192 metrics + the strided / first query samplers) end
+  to end on synthetic ground truth: a stand-in model that returns the ground truth scores AJ = 1,
+  one that predicts everything occluded scores AJ = 0."""
+  import numpy as np
+  from tapnet_amd import tapvid
+  rng = np.random.default_rng(0)
+  T, N, H = 12, 7, 64
+  pts = rng.uniform(4, H - 4, (N, T, 2))
+  occ = rng.random((N, T)) < 0.2
+  occ[:, 0] = False
+  video = rng.uniform(-1, 1, (T, H, H, 3)).astype(np.float32)
+
+  class Oracle:   # answers every query with its ground-truth track
+    def __init__(self, ex, blind=False): self.ex, self.blind = ex, blind
+    def get_feature_grids(self, video): return None
+    def __call__(self, video, is_training, qp, feature_grids=None):
+      ex = self.ex
+      idx = [int(np.argmin(np.abs(ex['query_points'][0] - q).sum(-1))) for q in qp[0]]
+      occl = np.where(ex['occluded'][0][idx] | self.blind, 20.0, -20.0)
+      return dict(tracks=ex['target_points'][:, idx], occlusion=occl[None], expected_dist=np.full_like(occl, -20.0)[None])
+
+  for mode, sampler in (('strided', tapvid.sample_queries_strided), ('first', tapvid.sample_queries_first)):
+    ex = sampler(occ, pts, video)
+    good = tapvid.evaluate(Oracle(ex), [('clip', ex)], query_mode=mode, query_chunk=5)
+    assert abs(good['average_jaccard'] - 1.0) < 1e-9 and abs(good['occlusion_accuracy'] - 1.0) < 1e-9
+    bad = tapvid.evaluate(Oracle(ex, blind=True), [('clip', ex)], query_mode=mode)
+    assert bad['average_jaccard'] == 0.0
