@@ -17,6 +17,7 @@
 #include "gemm.hpp"
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
+#include "mixer_fused_wide.hpp"
 #include "pips.hpp"
 
 using namespace tapir;
@@ -61,6 +62,7 @@ struct tapir_ctx {
   void* Wout = nullptr; float* bout = nullptr;    // [388, 512]
   // track-resident fused mixer (mixer_fused.hpp): per-wave A-fragment streams + per-block vectors
   uint4* fused_stream = nullptr; long fused_fpw = 0;
+  uint4* fused_wide_stream = nullptr; long fused_wide_fpw = 0;   // bf16: the 6-tile kernel's chunking (mixer_fused_wide.hpp)
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
@@ -327,6 +329,53 @@ int build_fused_weights(tapir_ctx* c) {
   return TAPIR_OK;
 }
 
+// the same matrices in the order / chunking of the wide kernel (mixer_fused_wide.hpp): chunks of 256
+// hidden units, sequential U0 D0 U1 D1 ..., output Linear in two passes of two row tiles
+int build_fused_wide_weights(tapir_ctx* c) {
+  typedef bf16_t TA;
+  const int nb = c->cfg.num_mixer_blocks;
+  const long fpw = fused_wide_frags_per_wave(c->k0_pad, nb);
+  std::vector<uint8_t> host((size_t)FM_WAVES * fpw * 1024, 0);
+  const std::string mx = "torch_pips_mixer.";
+  const HostTensor *w0, *wout;
+  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
+  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
+  constexpr int HC = FMW_HC, RAU = HC / 8 / 16, NC = kHidden4 / HC;
+  for (int w = 0; w < FM_WAVES; ++w) {
+    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
+    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
+      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
+      q += 1024;
+    };
+    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
+      for (int a = 0; a < 4; ++a) put(w0, kHidden, c->in_dim, 64 * w + 16 * a, ks * 32);
+    for (int b = 0; b < nb; ++b) {
+      const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
+      const HostTensor *wup, *wdn;
+      TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup));
+      TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn));
+      for (int hc = 0; hc < NC; ++hc) {
+        for (int ks = 0; ks < kHidden / 32; ++ks)
+          for (int a = 0; a < RAU; ++a) put(wup, kHidden4, kHidden, hc * HC + w * (HC / 8) + 16 * a, ks * 32);
+        for (int ks = 0; ks < HC / 32; ++ks)
+          for (int a = 0; a < 4; ++a) put(wdn, kHidden, kHidden4, 64 * w + 16 * a, hc * HC + ks * 32);
+      }
+    }
+    for (int half = 0; half < 2; ++half)
+      for (int ks = 0; ks < kHidden / 32; ++ks)
+        for (int a = 0; a < 2; ++a) put(wout, kMixOut, kHidden, 64 * w + 16 * (2 * half + a), ks * 32);
+    if (q + (size_t)FMW_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
+      return fail(c, TAPIR_ERR_WEIGHTS, "wide fused stream layout mismatch");
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  c->fused_wide_stream = (uint4*)d;
+  c->fused_wide_fpw = fpw;
+  return TAPIR_OK;
+}
+
 // ----------------------------------------------------------------------------
 // small helper kernels
 // ----------------------------------------------------------------------------
@@ -498,24 +547,40 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   // chip is mostly idle and the split-K / tiled GEMMs on all rows are faster)
   {
     const bool has_ctx = ctx1_in || ctx2_in || ctx1_out || ctx2_out;
-    bool fused = c->fused_stream != nullptr &&
-                 fused_mixer_supported<TA>(T, c->k0_pad, c->cfg.use_causal_conv != 0, has_ctx);
+    const bool causal = c->cfg.use_causal_conv != 0;
+    bool fused = c->fused_stream != nullptr && fused_mixer_supported<TA>(T, c->k0_pad, causal, has_ctx);
+    // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
+    bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
+                fused_wide_supported(T, c->k0_pad, causal, has_ctx);
     if (c->mixer_mode == 2 && !fused)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
-    if (c->mixer_mode == 1) fused = false;
-    if (c->mixer_mode == 0 && fused) fused = N >= 128 && R >= 4096;
-    if (fused) {
+    if (c->mixer_mode == 3 && !wide)
+      return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
+    if (c->mixer_mode == 1) fused = wide = false;
+    if (c->mixer_mode == 2) wide = false;
+    if (c->mixer_mode == 3) fused = false;
+    if (c->mixer_mode == 0) {
+      // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
+      // share the weight stream (MFMA-bound instead of L2-fill-bound); below ~128 tracks the tiled /
+      // split-K GEMMs on all rows are faster than a mostly idle chip
+      if (fused) fused = N >= 128 && R >= 4096;
+      if (wide) wide = T > 48 ? N >= 64 : N > 256;
+      if (wide) fused = false;
+    }
+    if (fused || wide) {
       TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
       FusedArgs fa{};
       fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
-      fa.stream = c->fused_stream; fa.frags_per_wave = c->fused_fpw;
+      fa.stream = wide ? c->fused_wide_stream : c->fused_stream;
+      fa.frags_per_wave = wide ? c->fused_wide_fpw : c->fused_fpw;
       fa.b0 = c->b0; fa.nblocks = nb;
       for (int i = 0; i < nb; ++i) fa.blocks[i] = c->fused_blocks[i];
       fa.dbg_times = (long long*)c->dbg_times;
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
-      launch_mixer_fused<TA>(fa, s);
+      if (wide) launch_mixer_fused_wide(fa, s);
+      else launch_mixer_fused<TA>(fa, s);
       return TAPIR_OK;
     }
   }
@@ -875,6 +940,7 @@ int tapir_finalize_weights(tapir_ctx* c) {
   c->blocks.clear();
   c->tapnet_ready = false; c->tapir_ready = false;
   c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
+  c->fused_wide_stream = nullptr; c->fused_wide_fpw = 0;
   const bool has_tapnet = c->host_w.count("tapnet_cost_volume_track_mods.hid1.weight") != 0;
   bool has_tapir = !has_tapnet;   // a context without TAP-Net head weights must be a complete TAPIR
   for (const auto& kv : c->host_w)
@@ -921,7 +987,7 @@ static int finalize_tapir(tapir_ctx* c) {
     c->blocks.push_back(b);
   }
   if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
-    if (c->cfg.dtype == TAPIR_BF16) TRY(build_fused_weights<bf16_t>(c));
+    if (c->cfg.dtype == TAPIR_BF16) { TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c)); }
     else TRY(build_fused_weights<float>(c));
   }
   return TAPIR_OK;
@@ -1157,7 +1223,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 }
 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
+  if (!c || mode < 0 || mode > 3) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
   return TAPIR_OK;
 }

@@ -173,12 +173,12 @@ struct NoEpilogue {
 // group to the bottom of the loop body, i.e. issues each fragment load right before its use):
 //   B fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (one step ahead);
 //   each A fragment is refilled right after its last MFMA, so FM_RING - 1 loads stay in flight.
-template <typename TA, int RA, int NT, int GROUPS = 0, typename Epi = NoEpilogue>
-__device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RING],
+template <typename TA, int RA, int NT, int GROUPS = 0, typename Epi = NoEpilogue, int RING = FM_RING, bool DB = true>
+__device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[RING],
                                            const char* bbase, int bstride, int groups, int c, int g,
                                            f32x4 (&acc)[RA][NT], Epi epi = Epi()) {
-  constexpr int G = FM_RING / RA;
-  static_assert(FM_RING % RA == 0, "ring must hold whole k-steps");
+  constexpr int G = RING / RA;
+  static_assert(RING % RA == 0, "ring must hold whole k-steps");
   const char* brow = bbase + c * bstride;
   auto read_b = [&](int ks, uint4 (&fb)[NT]) {
     const int chunk = (ks * 4 + g) ^ c;
@@ -188,16 +188,22 @@ __device__ __forceinline__ void fused_gemm(const uint4*& wp, uint4 (&ring)[FM_RI
   };
   if (GROUPS > 0) groups = GROUPS;
   const int ksteps = groups * G;
-  uint4 fb0[NT], fb1[NT];
-  read_b(0, fb0);
+  uint4 fb0[NT], fb1[NT];   // (fb1 is dead when !DB)
+  if (DB) read_b(0, fb0);
   auto group = [&](int kg) {
 #pragma unroll
     for (int kk = 0; kk < G; ++kk) {
-      uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
-      uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
-      int ks1 = kg * G + kk + 1;
-      ks1 = ks1 < ksteps ? ks1 : 0;   // past the end: any valid address (the values are not used)
-      read_b(ks1, nxt);
+      if constexpr (DB) {
+        uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
+        int ks1 = kg * G + kk + 1;
+        ks1 = ks1 < ksteps ? ks1 : 0;   // past the end: any valid address (the values are not used)
+        read_b(ks1, nxt);
+      } else {
+        // (NT > 3: no registers for a second set of B fragments; the other wave of the SIMD covers
+        // the LDS round trip)
+        read_b(kg * G + kk, fb0);
+      }
+      uint4 (&cur)[NT] = (DB && (kk & 1)) ? fb1 : fb0;
       sched_fence();
 #pragma unroll
       for (int r = 0; r < RA; ++r) {

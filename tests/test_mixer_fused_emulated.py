@@ -62,3 +62,35 @@ def test_fused_mixer_rejects_unsupported_shapes():
   rc = e.lib.tapir_pips_mixer(e.ctx, p(x), 1, 49, p(out), None, None, None, None, None)
   assert rc == _ffi.TAPIR_ERR_UNSUPPORTED
   e.close()
+
+
+@pytest.mark.parametrize('T,N', [(48, 3), (40, 2), (20, 5), (70, 1), (96, 2)])
+def test_wide_fused_mixer_bf16(T, N):
+  """Wide form (mixer_fused_wide.hpp, mode 3): two tracks of up to 48 frames per workgroup (an odd
+  track count leaves the last workgroup half empty; T = 40 / 20 are ragged) or one track of 49..96
+  frames (5 and 6 token tiles); its own weight-stream packing (chunks of 256 hidden units, output
+  Linear in two passes).  Same roundings as the separate-launch path."""
+  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
+  rng = np.random.default_rng(T + N)
+  x = rng.standard_normal((N, T, 535)).astype(np.float32)
+  wide = _mixer(e, x, 3)
+  sep = _mixer(e, x, 1)
+  assert np.isfinite(wide).all()
+  assert np.abs(wide - sep).max() < 2e-2, np.abs(wide - sep).max()
+  assert np.median(np.abs(wide - sep)) < 2e-3
+  if T <= 48:
+    narrow = _mixer(e, x, 2)
+    assert np.abs(wide - narrow).max() < 2e-2
+  e.close()
+
+
+def test_wide_fused_mixer_needs_bf16():
+  w = synthetic.make_weights(3, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64))   # f32 build
+  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, 3) == 0
+  x = np.zeros((1, 48, 535), np.float32)
+  out = np.zeros((1, 48, 388), np.float32)
+  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+  assert e.lib.tapir_pips_mixer(e.ctx, p(x), 1, 48, p(out), None, None, None, None, None) == _ffi.TAPIR_ERR_UNSUPPORTED
+  e.close()

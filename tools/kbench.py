@@ -306,7 +306,7 @@ def bench_norm(model, reps, results):
         print(json.dumps(row), flush=True)
 
 
-def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (128, 48), (256, 24), (256, 40))):
+def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (512, 48), (384, 48), (128, 48), (256, 24), (256, 40), (256, 96), (1024, 96))):
   """whole PIPSMLPMixer (12 blocks) through the public C ABI (tapir_pips_mixer: staging of the input
   rows + mixer + copy of the result), A/B: separate launches (mode 1) vs the track-resident fused
   kernel (mode 2), same inputs; max |fused - separate| is the cross-check."""
@@ -317,7 +317,12 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (128, 48), 
   for N, T in shapes:
     x = torch.randn(N, T, cin, device=dev)
     outs = {}
-    for mode, name in ((1, 'separate'), (2, 'fused')):
+    modes = [(1, 'separate')]
+    if T <= 48:
+      modes.append((2, 'fused'))
+    if model.dtype == 'bfloat16' and T > 16:
+      modes.append((3, 'fused_wide'))
+    for mode, name in modes:
       assert lib.tapir_debug_set_mixer_mode(ctx, mode) == 0
       out = torch.empty(N, T, 388, device=dev)
 
@@ -330,11 +335,11 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (128, 48), 
       row = dict(kernel=f'pips_mixer_12blocks_{name}', N=N, T=T, dtype=model.dtype, **t,
                  tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
                  us_per_block=round(t['med_us'] / 12, 2))
-      if name == 'fused':
-        d = (outs['fused'] - outs['separate']).abs()
+      if name != 'separate':
+        d = (outs[name] - outs['separate']).abs()
         row['max_abs_diff_vs_separate'] = float(d.max())
         row['median_abs_diff_vs_separate'] = float(d.median())
-        row['finite'] = bool(torch.isfinite(outs['fused']).all())
+        row['finite'] = bool(torch.isfinite(outs[name]).all())
       results.append(row)
       print(json.dumps(row), flush=True)
     assert lib.tapir_debug_set_mixer_mode(ctx, 0) == 0
