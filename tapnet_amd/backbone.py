@@ -56,6 +56,13 @@ class Backbone:
     # measured 3.12 -> 2.66 ms per 48-frame clip.  The flag is process-wide in PyTorch, so it is set
     # only around this backbone's own convolutions (features()) and restored afterwards.
     self.miopen_exhaustive_search = True
+    # Frames are independent through the whole backbone, so a clip can be cut into `streams` groups of
+    # frames that run on separate HIP streams: the HBM-bound glue kernels of one group (norm
+    # statistics, normalise + ReLU, residual add) then overlap the MFMA-bound convolutions of the
+    # other instead of alternating with them.  1 = everything on the caller's stream.
+    self.streams = 1
+    self._side_streams = []
+    self._lane = 0
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
@@ -99,6 +106,7 @@ class Backbone:
   def _buf(self, key, shape, dtype, zero=False):
     """Stream-ordered scratch reused across layers and calls (a zero border stays zero: the
     kernels never write it)."""
+    key = (self._lane,) + tuple(key)    # groups of frames in flight on different streams do not share scratch
     t = self._bufs.get(key)
     if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
       t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
@@ -155,15 +163,17 @@ class Backbone:
     part2, slabs2 = self._hip_stats(y, shortcut)   # y += shortcut, fused with the next norm's statistics
     return y, part2, slabs2
 
-  def _hip_l2norm(self, x_nhwc):
+  def _hip_l2norm(self, x_nhwc, out=None):
     lib, ctx = self.engine
     n, h, w, c = x_nhwc.shape
-    out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+    if out is None:
+      out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+    assert out.shape == (n, h, w, c) and out.is_contiguous() and out.dtype == torch.float32
     self._check(lib.tapir_l2_normalize(ctx, x_nhwc.data_ptr(), out.data_ptr(), n * h * w, c,
                                        self._stream()), 'tapir_l2_normalize')
     return out
 
-  def _features_hip(self, frames_nhwc):
+  def _features_hip(self, frames_nhwc, out_low=None, out_hi=None):
     x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     w0 = self.w['resnet_torch.initial_conv.weight']
     x = F.conv2d(_same_pad(x, w0.shape[-1], 2), w0, None, stride=2).permute(0, 2, 3, 1).contiguous()
@@ -178,7 +188,7 @@ class Backbone:
         unit1 = x
     if self.extra_convs:
       x = self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
-    return self._hip_l2norm(x), self._hip_l2norm(unit1)
+    return self._hip_l2norm(x, out_low), self._hip_l2norm(unit1, out_hi)
 
   # -- public ---------------------------------------------------------------
   @torch.no_grad()
@@ -186,21 +196,45 @@ class Backbone:
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """frames [N,H,W,3] f32 in [-1,1] -> (lowres [N,H/8,W/8,256], hires [N,H/4,W/4,128]) f32,
     L2-normalised, contiguous channels-last."""
-    n = frames_nhwc.shape[0]
-    chunk = n if not chunk else chunk
-    run = self._features_hip
-    lows, his = [], []
+    n, H, W = frames_nhwc.shape[:3]
+    half = lambda v: -(-v // 2)
+    last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
+    c_low = self.w[last(3)].shape[0]
+    if self.extra_convs:
+      c_low = self.w['extra_convs.blocks.4.conv_1.weight'].shape[0]
+    c_hi = self.w[last(1)].shape[0]
+    low = torch.empty((n, half(half(half(H))), half(half(half(W))), c_low), dtype=torch.float32, device=self.device)
+    hi = torch.empty((n, half(half(H)), half(half(W)), c_hi), dtype=torch.float32, device=self.device)
+    if n == 0:
+      return low, hi
+    streams = max(1, min(int(self.streams), n))
+    if chunk:
+      bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
+    else:
+      per = -(-n // streams)
+      bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
+    cur = torch.cuda.current_stream(self.device)
+    while len(self._side_streams) < streams - 1:
+      self._side_streams.append(torch.cuda.Stream(self.device))
     saved = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = bool(self.miopen_exhaustive_search)
     try:
-      for s in range(0, n, chunk):
-        lo, hi = run(frames_nhwc[s:s + chunk])
-        lows.append(lo)
-        his.append(hi)
+      if streams > 1:
+        fork = cur.record_event()
+      for i, (s, e) in enumerate(bounds):
+        lane = i % streams
+        st = cur if lane == 0 else self._side_streams[lane - 1]
+        if lane and i < streams:
+          st.wait_event(fork)
+        self._lane = lane
+        with torch.cuda.stream(st):
+          self._features_hip(frames_nhwc[s:e], low[s:e], hi[s:e])
+      for st in self._side_streams[:streams - 1]:
+        cur.wait_stream(st)
     finally:
+      self._lane = 0
       torch.backends.cudnn.benchmark = saved
-    return (torch.cat(lows) if len(lows) > 1 else lows[0],
-            torch.cat(his) if len(his) > 1 else his[0])
+    return low, hi
 
 
 def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int], antialias: bool = False) -> torch.Tensor:

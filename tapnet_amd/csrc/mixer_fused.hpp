@@ -591,6 +591,10 @@ inline bool fused_mixer_supported(int T, int k0_pad, bool causal, bool has_ctx) 
   if (causal || has_ctx || T < 1 || T > 16 * CF::MAX_NT) return false;
   if ((k0_pad * (int)sizeof(TA)) % 256 != 0) return false;
   if ((k0_pad / CF::KS) % (FM_RING / 4) != 0) return false;
+  // the staged input image has to fit the activation region of the kernel instance (ACT_BYTES there)
+  const long rows = 16L * ((T + 15) / 16), es = (long)sizeof(TA);
+  const long images = rows * kHidden * es + 2 * rows * CF::HC * es, par = (long)kHidden * FM_MIXW * 4;
+  if (rows * k0_pad * es > (images > par ? images : par)) return false;
   return true;
 }
 

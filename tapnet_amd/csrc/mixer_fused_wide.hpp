@@ -89,6 +89,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
     for (int i = 0; i < NT; ++i) xr[q][i] = b;
   }
   fused_gemm<TA, 4, NT, 0, NoEpilogue, RING, false>(wp, ring, s_xn, in_stride, a.ld_in / KS / (RING / 4), c, g, xr);
+  lds_barrier();   // the block parameters and the LN summaries overwrite the input image
 
   float valid[NTT];   // the same for every track of the workgroup
 #pragma unroll
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
 // to 48 frames
 inline bool fused_wide_supported(int T, int k0_pad, bool causal, bool has_ctx) {
   if (causal || has_ctx || T < 1 || T > 96) return false;
+  // the staged input image (96 rows of k0_pad bf16) has to fit the activation region (144 KiB)
+  if (96L * k0_pad * 2 > 96L * (kHidden + FMW_HC) * 2) return false;
   return (k0_pad * 2) % 256 == 0 && (k0_pad / 32) % (FMW_RING / 4) == 0;
 }
 

@@ -13,8 +13,16 @@
 // work-item) on one OS thread; __syncthreads and the wave collectives
 // (shuffles, MFMA) are rendezvous points.  Fibers are scheduled in a
 // pseudo-random order between rendezvous points so that a missing barrier
-// shows up as a wrong result instead of passing by luck.  Workgroups run in
-// parallel over OS threads (OpenMP).
+// shows up as a wrong result instead of passing by luck.  Two schedules:
+//   fair   -- every fiber advances to its next rendezvous each round: waves
+//             stay within one collective of each other;
+//   skewed -- one wave at a time runs alone until all its lanes wait at a
+//             workgroup barrier (or finish), waves in a random order: a wave
+//             gets a whole barrier interval ahead of the others, which is
+//             what a missing barrier between two phases needs to show up.
+// HIPEMU_SKEW=0/1 forces one schedule for every workgroup; unset, odd
+// workgroups run skewed and even ones fair.  Workgroups run in parallel
+// over OS threads (OpenMP).
 //
 // MFMA semantics follow /opt/skills/guides/cdna_hip_programming.md section 3:
 //   16x16x32 bf16 : A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][n=l&15], j<8
@@ -102,6 +110,8 @@ struct Fiber {
   void* sp = nullptr;
   char* stack = nullptr;
   bool done = false;
+  bool in_barrier = false;
+  long wait_gen = 0;
   unsigned tid = 0;
   Block* block = nullptr;
 };
@@ -173,6 +183,51 @@ inline void run_block(Block& b, const std::function<void()>& body) {
   std::vector<unsigned> order(b.nthreads);
   for (unsigned i = 0; i < b.nthreads; ++i) order[i] = i;
   uint32_t rng = 0x9e3779b9u ^ (b.bidx.x * 2654435761u);
+  auto run_fiber = [&](Fiber& f) {
+    b.cur = &f;
+    unsigned t = f.tid;
+    threadIdx_.x = t % b.bdim.x;
+    threadIdx_.y = (t / b.bdim.x) % b.bdim.y;
+    threadIdx_.z = t / (b.bdim.x * b.bdim.y);
+    hipemu_switch(&b.sched_sp, f.sp);
+  };
+  bool skew = (b.bidx.x & 1u) != 0;
+  if (const char* e = getenv("HIPEMU_SKEW")) skew = e[0] == '1';
+  const unsigned nwaves = (b.nthreads + 63) / 64;
+  if (skew && nwaves > 1) {
+    std::vector<unsigned> worder(nwaves);
+    for (unsigned i = 0; i < nwaves; ++i) worder[i] = i;
+    while (b.live > 0) {
+      for (unsigned i = nwaves - 1; i > 0; --i) {
+        rng = rng * 1664525u + 1013904223u;
+        unsigned j = (rng >> 8) % (i + 1);
+        unsigned tmp = worder[i]; worder[i] = worder[j]; worder[j] = tmp;
+      }
+      bool progress = false;
+      for (unsigned wi = 0; wi < nwaves; ++wi) {
+        const unsigned lo = worder[wi] * 64, hi = lo + 64 < b.nthreads ? lo + 64 : b.nthreads;
+        for (;;) {   // this wave alone, until every lane waits at a barrier or is done
+          bool runnable = false;
+          for (unsigned k = lo; k < hi; ++k) {
+            Fiber& f = b.fibers[lo + (k - lo + (rng >> 10)) % (hi - lo)];
+            if (f.done || (f.in_barrier && f.wait_gen == b.bar_gen)) continue;
+            runnable = true;
+            progress = true;
+            run_fiber(f);
+          }
+          rng = rng * 1664525u + 1013904223u;
+          if (!runnable) break;
+        }
+      }
+      // lanes that returned early can complete a barrier the waiters must re-evaluate
+      if (!progress)
+        for (unsigned k = 0; k < b.nthreads; ++k)
+          if (!b.fibers[k].done) run_fiber(b.fibers[k]);
+    }
+    free(stacks);
+    g_block = nullptr;
+    return;
+  }
   while (b.live > 0) {
     for (unsigned i = b.nthreads - 1; i > 0; --i) {
       rng = rng * 1664525u + 1013904223u;
@@ -205,7 +260,10 @@ inline void restore_tid() {
 inline void syncthreads() {
   Block* b = g_block;
   long gen = b->bar_gen;
+  Fiber* me = b->cur;
   b->bar_arrived++;
+  me->in_barrier = true;
+  me->wait_gen = gen;
   for (;;) {
     if (b->bar_gen != gen) break;
     if (b->bar_arrived >= (int)b->live) {  // everyone alive has arrived
@@ -215,6 +273,7 @@ inline void syncthreads() {
     }
     yield();
   }
+  me->in_barrier = false;
 }
 
 // Wave collective: every live lane of the wave deposits, the last arriver runs

@@ -1,0 +1,45 @@
+"""Times Backbone.features (R7) for one clip: the frames on one stream, or cut into groups of frames on
+several HIP streams (tapnet_amd/backbone.py: `streams`).  usage: python tools/bench_backbone.py [--frames 48]"""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tapnet_amd import TAPIR, synthetic
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--frames', type=int, default=48)
+  ap.add_argument('--size', type=int, default=256)
+  ap.add_argument('--dtype', default='bfloat16')
+  ap.add_argument('--reps', type=int, default=20)
+  a = ap.parse_args()
+  w = synthetic.make_weights(seed=0)
+  m = TAPIR(weights=w, device='cuda:0', dtype=a.dtype)
+  bb = m._backbone
+  frames = torch.rand(a.frames, a.size, a.size, 3, device='cuda:0') * 2 - 1
+  ref = None
+  for streams in (1, 2, 3, 4):
+    bb.streams = streams
+    for _ in range(3):
+      out = bb.features(frames)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+      out = bb.features(frames)
+    e1.record()
+    torch.cuda.synchronize()
+    if ref is None:
+      ref = out
+    same = all(torch.equal(x, y) for x, y in zip(out, ref))
+    print(json.dumps({'workload': f'Backbone.features {a.frames}x{a.size}x{a.size} {a.dtype}', 'streams': streams,
+                      'ms': round(e0.elapsed_time(e1) / a.reps, 3), 'bit_identical_to_1_stream': same}), flush=True)
+
+
+if __name__ == '__main__':
+  main()
