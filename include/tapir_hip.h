@@ -196,8 +196,9 @@ int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 
 /* Feature backbone, the memory-bound half (TAPIR.get_feature_grids, tapir_model.py:626-729; ResNet
- * blocks, tapnet/models/resnet.py:152-257).  The convolutions stay on PyTorch-ROCm / MIOpen
- * (north_star); these three entry points are everything between them.  Tensors are NHWC in the
+ * blocks, tapnet/models/resnet.py:152-257).  The stem, the strided and the 1x1 convolutions stay on
+ * PyTorch-ROCm / MIOpen (north_star); these three entry points are everything between them (the 3x3
+ * stride-1 convolutions have their own fused entry point below).  Tensors are NHWC in the
  * context's element type (f32, or bf16 bits for TAPIR_BF16); channel counts: C / (8 bf16 | 4 f32)
  * must be a power of two <= 256 (<= 64 for tapir_l2_normalize).
  *
@@ -206,7 +207,8 @@ int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* laun
  *   a block, resnet.py:256, fused with the statistics of the next block's first norm; sum_out may
  *   alias a or b).  part [N, slabs, C, 2] f32 receives one (mean, M2) summary per slab of pixels.
  * tapir_inorm_relu: y = relu((x - mean) / sqrt(var + 1e-5) * gamma + beta) (resnet.py:241-249) from
- *   those summaries.  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
+ *   those summaries (slabs of per_s pixels; per_s = 0: ceil(HW / slabs), what tapir_inorm_stats
+ *   writes; the part_out of tapir_conv3x3_fused has per_s = rows * W).  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
  *   H / W are not written (pass a zero-initialised buffer with out_h = H+1, out_w = W+1 to get the
  *   XLA "SAME" padding of a stride-2 3x3 convolution, which pads on the high side only).
  *   y_sub, if not NULL, [N, H/2, W/2, C] receives the pixels with even h and w (input of the
@@ -216,8 +218,29 @@ int tapir_inorm_stats(tapir_ctx* ctx, const void* a, const void* b, void* sum_ou
                       int N, int HW, int C, int slabs, void* stream);
 int tapir_inorm_relu(tapir_ctx* ctx, const void* x, const float* part, const float* gamma,
                      const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
-                     int out_h, int out_w, void* stream);
+                     int per_s, int out_h, int out_w, void* stream);
 int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, int C, void* stream);
+
+/* The 3x3 / stride-1 / SAME convolutions of the ResNet blocks (C -> C channels, C in {64,128,256};
+ * tapnet/models/resnet.py:185-257: self.conv_0 / self.conv_1 of BlockV2 and the InstanceNorm + relu in
+ * front of each, :241-242 / :248-249, and the residual add :256), bf16 contexts only: one HIP
+ * implicit-GEMM kernel per convolution with the normalisation of its INPUT folded into the operand
+ * load and the residual add + the statistics of its OUTPUT (for the next norm) into the epilogue.
+ * tapir_conv3x3_plan : rows per workgroup tile and tiles per image for an [H, W, C] map
+ *   (TAPIR_ERR_UNSUPPORTED when the shape does not fit: keep that convolution on MIOpen).
+ * tapir_conv3x3_pack : w = the reference's [C_out, C_in, 3, 3] f32 kernel (torch OIHW, host memory)
+ *   -> device-resident packed fragment streams (owned by the context).
+ * tapir_conv3x3_fused: y [N,H,W,C] = conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut),
+ *   rounded to bf16.  part_in [N, slabs_in, C, 2] are (mean, M2) summaries of x per slab of per_s_in
+ *   pixels (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
+ *   ss [N, C, 2] f32 scratch of the caller (the merged scale / shift); part_out, if not NULL,
+ *   [N, tiles, C, 2] receives the summaries of y per tile (rows * W pixels each). */
+int tapir_conv3x3_plan(tapir_ctx* ctx, int H, int W, int C, int* rows, int* tiles);
+int tapir_conv3x3_pack(tapir_ctx* ctx, const float* w, int C, void** wstream);
+int tapir_conv3x3_fused(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                        const float* gamma, const float* beta, float* ss, const void* wstream,
+                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int C,
+                        void* stream);
 
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):

@@ -23,10 +23,18 @@ lives in oracle/backbone_torch.py.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
+
+
+class _Stats(NamedTuple):
+  """InstanceNorm summaries of a tensor: part [N, slabs, C, 2] (mean, M2) per slab of per_s pixels
+  (0: ceil(HW / slabs))."""
+  part: torch.Tensor
+  slabs: int
+  per_s: int
 
 
 def _same_pad(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
@@ -63,6 +71,12 @@ class Backbone:
     self.streams = 1
     self._side_streams = []
     self._lane = 0
+    # 'auto': the 3x3 stride-1 C -> C convolutions (13 of the 16 3x3 convolutions, 85 % of the
+    # backbone's flops) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it
+    # (bf16 contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
+    self.conv_mode = 'auto'
+    self._plans: Dict[tuple, Optional[tuple]] = {}
+    self._wstream: Dict[str, int] = {}
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
@@ -77,6 +91,19 @@ class Backbone:
       else:             # norm scales / biases stay f32
         t = t.float()
       self.w[k] = t
+    if dtype == torch.bfloat16:
+      import ctypes
+      import numpy as np
+      lib, ctx = engine
+      for k, v in weights.items():
+        if not (k.startswith('resnet_torch.block_groups.') and k.endswith(('conv_0.weight', 'conv_1.weight'))):
+          continue
+        a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+        if a.ndim == 4 and a.shape[0] == a.shape[1] and a.shape[2:] == (3, 3) and a.shape[0] in (64, 128, 256):
+          h = ctypes.c_void_p()
+          self._check(lib.tapir_conv3x3_pack(ctx, a.ctypes.data_as(ctypes.c_void_p), a.shape[0], ctypes.byref(h)),
+                      'tapir_conv3x3_pack')
+          self._wstream[k[:-len('.weight')]] = h.value
     need = ['resnet_torch.initial_conv.weight']
     if extra_convs:
       need.append('extra_convs.blocks.0.conv.weight')
@@ -121,7 +148,7 @@ class Backbone:
     import ctypes
     return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-  def _hip_stats(self, a: torch.Tensor, b: Optional[torch.Tensor] = None):
+  def _hip_stats(self, a: torch.Tensor, b: Optional[torch.Tensor] = None) -> '_Stats':
     """InstanceNorm summaries of a (NHWC), or of a + b with the sum written over a."""
     lib, ctx = self.engine
     n, h, w, c = a.shape
@@ -130,18 +157,18 @@ class Backbone:
     self._check(lib.tapir_inorm_stats(ctx, a.data_ptr(), b.data_ptr() if b is not None else None,
                                       a.data_ptr() if b is not None else None, part.data_ptr(),
                                       n, h * w, c, slabs, self._stream()), 'tapir_inorm_stats')
-    return part, slabs
+    return _Stats(part, slabs, 0)
 
-  def _hip_norm_relu(self, x, part, slabs, name, tag, pad=False, sub=False):
+  def _hip_norm_relu(self, x, st: '_Stats', name, tag, pad=False, sub=False):
     lib, ctx = self.engine
     n, h, w, c = x.shape
     oh, ow = (h + 1, w + 1) if pad else (h, w)
     y = self._buf(('y', tag, n, oh, ow, c), (n, oh, ow, c), self.dtype, zero=pad)
     ys = self._buf(('ysub', tag, n, h // 2, w // 2, c), (n, h // 2, w // 2, c), self.dtype) if sub else None
-    self._check(lib.tapir_inorm_relu(ctx, x.data_ptr(), part.data_ptr(),
+    self._check(lib.tapir_inorm_relu(ctx, x.data_ptr(), st.part.data_ptr(),
                                      self.w[name + '.weight'].data_ptr(), self.w[name + '.bias'].data_ptr(),
-                                     y.data_ptr(), ys.data_ptr() if sub else None, n, h, w, c, slabs,
-                                     oh, ow, self._stream()), 'tapir_inorm_relu')
+                                     y.data_ptr(), ys.data_ptr() if sub else None, n, h, w, c, st.slabs,
+                                     st.per_s, oh, ow, self._stream()), 'tapir_inorm_relu')
     return y, ys
 
   def _hip_conv(self, x_nhwc, name, stride=1, padding=0):
@@ -150,18 +177,61 @@ class Backbone:
                  padding=padding)
     return y.permute(0, 2, 3, 1).contiguous()   # no-op for a channels-last result
 
-  def _hip_block(self, x, part, slabs, p, stride, use_projection, tag):
+  # -- the 3x3 / stride-1 C -> C convolutions: one HIP kernel each (csrc/conv_fused.hpp) ------------
+  def _plan(self, h, w, c):
+    """(rows per tile, tiles per image) of the fused convolution, or None: that shape stays on MIOpen."""
+    key = (h, w, c)
+    if key not in self._plans:
+      import ctypes
+      lib, ctx = self.engine
+      rows, tiles = ctypes.c_int(), ctypes.c_int()
+      ok = (self.dtype == torch.bfloat16 and
+            lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0)
+      self._plans[key] = (rows.value, tiles.value) if ok else None
+    return self._plans[key]
+
+  def _fusable(self, conv_name, h, w, c):
+    return self.conv_mode != 'miopen' and conv_name in self._wstream and self._plan(h, w, c) is not None
+
+  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag):
+    """conv(relu(instance_norm(x))) (+ shortcut) and the summaries of the result, one launch
+    (+ the tiny merge of the input summaries)."""
+    lib, ctx = self.engine
+    n, h, w, c = x.shape
+    rows, tiles = self._plan(h, w, c)
+    y = self._buf(('fy', tag, n, h, w, c), (n, h, w, c), self.dtype)
+    part = self._buf(('fpart', tag, n, tiles, c), (n, tiles, c, 2), torch.float32)
+    ss = self._buf(('ss', n, c), (n, c, 2), torch.float32)
+    assert y.data_ptr() != x.data_ptr() and (shortcut is None or y.data_ptr() != shortcut.data_ptr())
+    self._check(lib.tapir_conv3x3_fused(
+        ctx, x.data_ptr(), st.part.data_ptr(), st.slabs, st.per_s, self.w[norm_name + '.weight'].data_ptr(),
+        self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), self._wstream[conv_name],
+        shortcut.data_ptr() if shortcut is not None else None, y.data_ptr(), part.data_ptr(), n, h, w, c,
+        self._stream()), 'tapir_conv3x3_fused')
+    return y, _Stats(part, tiles, rows * w)
+
+  def _hip_block(self, x, st: '_Stats', p, stride, use_projection, tag, parity):
+    """One BlockV2 (resnet.py:185-257).  x: the raw residual stream, st: its InstanceNorm summaries."""
     strided = stride == 2
-    y, ysub = self._hip_norm_relu(x, part, slabs, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
+    n, h, w, cin = x.shape
+    cout = self.w[p + 'conv_0.weight'].shape[0]
+    f0 = not strided and cin == cout and self._fusable(p + 'conv_0', h, w, cout)
+    if use_projection or not f0:
+      y, ysub = self._hip_norm_relu(x, st, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
     shortcut = x
     if use_projection:
       shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
-    y = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
-    part1, slabs1 = self._hip_stats(y)
-    y, _ = self._hip_norm_relu(y, part1, slabs1, p + 'bn_1', tag + 'b')
-    y = self._hip_conv(y, p + 'conv_1', 1, 1)
-    part2, slabs2 = self._hip_stats(y, shortcut)   # y += shortcut, fused with the next norm's statistics
-    return y, part2, slabs2
+    if f0:
+      y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c')
+    else:
+      y0 = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
+      st0 = self._hip_stats(y0)
+    if self._fusable(p + 'conv_1', y0.shape[1], y0.shape[2], cout):
+      # the result becomes the next block's residual stream: it may not alias this block's (the shortcut)
+      return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}')
+    y, _ = self._hip_norm_relu(y0, st0, p + 'bn_1', tag + 'b')
+    y1 = self._hip_conv(y, p + 'conv_1', 1, 1)
+    return y1, self._hip_stats(y1, shortcut)   # y1 += shortcut, fused with the next norm's statistics
 
   def _hip_l2norm(self, x_nhwc, out=None):
     lib, ctx = self.engine
@@ -177,13 +247,13 @@ class Backbone:
     x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     w0 = self.w['resnet_torch.initial_conv.weight']
     x = F.conv2d(_same_pad(x, w0.shape[-1], 2), w0, None, stride=2).permute(0, 2, 3, 1).contiguous()
-    part, slabs = self._hip_stats(x)
+    st = self._hip_stats(x)
     strides = (1, 2, 2, 1)
     unit1 = None
     for g in range(4):
       for b in range(self.blocks_per_group[g]):
-        x, part, slabs = self._hip_block(x, part, slabs, f'resnet_torch.block_groups.{g}.blocks.{b}.',
-                                         strides[g] if b == 0 else 1, b == 0, f'g{g}')
+        x, st = self._hip_block(x, st, f'resnet_torch.block_groups.{g}.blocks.{b}.',
+                                strides[g] if b == 0 else 1, b == 0, f'g{g}', b & 1)
       if g == 1:
         unit1 = x
     if self.extra_convs:

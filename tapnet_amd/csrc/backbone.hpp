@@ -184,12 +184,13 @@ struct NormFinalizeArgs {
   const float* beta;    // [C] offset
   float* ss;            // [N, C, 2]: (rstd * gamma, beta - mean * rstd * gamma)
   int HW, C, slabs;
+  int per_s;            // pixels per slab (the last one may be shorter); 0 = ceil(HW / slabs)
 };
 
 // grid (N), one thread per channel: merges the slab summaries once per (image, channel).
 __global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinalizeArgs a) {
   const int n = blockIdx.x;
-  const int per_s = (a.HW + a.slabs - 1) / a.slabs;
+  const int per_s = a.per_s > 0 ? a.per_s : (a.HW + a.slabs - 1) / a.slabs;
   for (int c = threadIdx.x; c < a.C; c += NORM_THREADS) {
     float cn = 0.f, mean = 0.f, m2 = 0.f;
     for (int s0 = 0; s0 < a.slabs; s0 += 8) {   // 8 summaries in flight per round trip

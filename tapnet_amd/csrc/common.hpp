@@ -191,6 +191,26 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
   for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 #endif
 }
+// K independent sums over the 16 lanes of each DPP row (lanes 16 g .. 16 g + 15), every lane of
+// the row receives its row's total: the four row-local steps of wave_sum_n.
+template <int K>
+__device__ __forceinline__ void row_sum_n(float (&v)[K]) {
+#ifdef TAPIR_HIPEMU
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], m);
+#else
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0xB1, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x4E, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x141, 0xf>(0.f, v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f32<0x140, 0xf>(0.f, v[k]);
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #ifdef TAPIR_HIPEMU
   v = fmaxf(v, __shfl_xor(v, 32));

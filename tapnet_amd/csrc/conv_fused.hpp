@@ -1,0 +1,368 @@
+// 3x3 / stride 1 / SAME convolution of the feature backbone (tapnet/models/resnet.py:185-257: the
+// two convolutions of a ResNet-v2 block, C -> C channels) as ONE kernel with everything the block
+// does around it folded in:
+//   operand load : relu(instance_norm(x)) (resnet.py:241-242, 248-249) -- the raw tensor is read,
+//                  normalised with the per-(image, channel) pair (a, b) of inorm_finalize_kernel,
+//                  rectified and rounded to bf16 on its way into LDS; the zero padding of the
+//                  convolution is applied AFTER that (out-of-image pixels are literal zeros);
+//   epilogue     : + shortcut (resnet.py:256), rounding to bf16, and the per-(image, channel)
+//                  (mean, M2) summary of the stored tensor for the NEXT InstanceNorm.
+// The normalised activations, the pre-add convolution result and the separate statistics pass never
+// exist in HBM (they were five of the seven memory passes of a block).
+//
+// Implicit GEMM on the matrix cores, the layout of the track-resident mixer (mixer_fused.hpp):
+//   A = weights: per-wave packed stream of 1-KiB fragments (16 output channels x 32 input channels of
+//       one tap), global -> register ring, never through LDS;
+//   B = pixels : the haloed input tile [(rows + 2) x (W + 2) pixels][C] bf16 in LDS, 16-byte chunks
+//       XOR-swizzled by the pixel index; the nine taps are nine constant offsets into it.
+// Workgroup = 4 or 8 waves = (C / 64) output-channel groups x pixel groups; a wave owns 64 output
+// channels x NT * 16 pixels (4 x NT accumulator fragments); the tile of a workgroup is `rows` full
+// image rows (rows * W <= pixel groups * NT * 16).  bf16 build only.
+#pragma once
+#include "backbone.hpp"
+#include "gemm.hpp"
+
+namespace tapir {
+
+constexpr int CV3_RING = 12;                 // A fragments in flight per wave (3 k-steps)
+constexpr int CV3_NT = 4;                    // pixel tiles (16 pixels) per wave
+// Two workgroup sizes: 4 waves with a 72-KiB tile -- two workgroups per CU, so that the VALU- and
+// memory-bound phases of one (staging, epilogue) run under the matrix phase of the other -- and
+// 8 waves with a 144-KiB tile for the maps whose rows are too long for that.
+constexpr int cv3_lds_bytes(int waves) { return waves * 18 * 1024; }
+
+struct Conv3Args {
+  const bf16_t* x;        // [N, H, W, C] raw input of the norm
+  const float* ss;        // [N, C, 2] (a, b): operand = relu(a * x + b)
+  const uint4* wstream;   // [C / 64][frags_per_cg][64 lanes] packed A fragments (conv3_pack_weights)
+  long frags_per_cg;
+  const bf16_t* shortcut; // null, or [N, H, W, C] added before rounding
+  bf16_t* y;              // [N, H, W, C]
+  float* part;            // null, or [N, tiles, C, 2]: (mean, M2) of the stored values of each tile
+  int N, H, W;
+  int TH, tiles;          // rows per tile, tiles per image = ceil(H / TH)
+  int waves;              // 4 or 8 (conv3_plan)
+  long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
+};
+
+inline long conv3_frags_per_cg(int C) { return 9L * (C / 32) * 4 + CV3_RING; }
+
+// rows per tile / tiles per image / waves per workgroup for an [H, W, C] map; false if the shape does
+// not fit the kernel
+inline bool conv3_plan(int H, int W, int C, int* rows, int* tiles, int* waves = nullptr) {
+  if (C != 64 && C != 128 && C != 256) return false;
+  if (H < 1 || W < 1) return false;
+  for (int wv = 4; wv <= 8; wv += 4) {
+    const int px = (wv * 64 / C) * CV3_NT * 16;    // pixels per workgroup
+    int th = px / W;
+    if (th > H) th = H;
+    while (th >= 1 && (long)(th + 2) * (W + 2) * C * 2 > cv3_lds_bytes(wv)) --th;
+    // (a one-row tile reads three rows per row of output: take the larger workgroup if it does better)
+    if (th < 1 || (th < 2 && wv == 4 && H > 1)) continue;
+    *rows = th;
+    *tiles = (H + th - 1) / th;
+    if (waves) *waves = wv;
+    return true;
+  }
+  return false;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// relu on two packed bf16: as 16-bit integers the negative values (sign bit) are below zero
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
+  const s16x2 v = __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0});
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int C, int NT, int WAVES, bool TRACE = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args a) {
+  constexpr int THREADS = WAVES * 64;
+  constexpr int CG = C / 64, PG = WAVES / CG;
+  static_assert(PG >= 1, "a wave owns 64 output channels");
+  constexpr int CB = C * 2;                        // bytes per pixel
+  constexpr int CPP = C / 8;                       // 16-byte chunks per pixel
+  constexpr int SWZ = (CPP < 16 ? CPP : 16) - 1;
+  constexpr int KPT = C / 32;                      // k-steps per tap
+  constexpr int RING = CV3_RING, G = RING / 4;   // k-steps per ring turn
+  constexpr int UNR = 2 * G;                     // k-steps per loop trip (even: the B buffers alternate)
+  static_assert((9 * KPT) % UNR == 0, "whole loop trips");
+  __shared__ uint4 s_tile[cv3_lds_bytes(WAVES) / 16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int cg = wave % CG, pg = wave / CG;
+  // Consecutive workgroup ids go round the 8 XCDs (each with its own L2): XCD x takes the x-th
+  // CONTIGUOUS eighth of the tiles, so that the halo rows two neighbouring tiles share are fetched into
+  // one L2 once instead of into two.
+  const int total = a.N * a.tiles;
+  const int per_xcd = (total + 7) >> 3;
+  const int bid = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (bid >= total) return;
+  const int n = bid / a.tiles, t = bid - n * a.tiles;
+  const int H = a.H, W = a.W, PW = W + 2;
+  const int r0 = t * a.TH;
+  const int rows = min(a.TH, H - r0);
+  const int HP = (rows + 2) * PW;                  // haloed pixels
+  const int TP = rows * W;                         // output pixels of this tile
+  char* const tile = reinterpret_cast<char*>(s_tile);
+
+  // TRACE (tools/kbench.py --what convtrace): shader cycles per phase, per wave
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto tick = [&](int k) {
+#ifndef TAPIR_HIPEMU
+    if (TRACE) {
+      unsigned long long t_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+      if (k >= 0) tph[k] += t_ - tlast;
+      tlast = t_;
+    }
+#endif
+  };
+  tick(-1);
+
+  // ---- the wave's weight stream: the first ring of fragments is in flight during the staging
+  const uint4* wp = a.wstream + ((long)cg * a.frags_per_cg) * 64 + lane;
+  uint4 ring[RING];
+#pragma unroll
+  for (int s = 0; s < RING; ++s) { ring[s] = *wp; wp += 64; }
+
+  // ---- this lane's pixel of each of the wave's pixel tiles: haloed index of the centre tap
+  int Pc[NT], qpix[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int q = (pg * NT + i) * 16 + c;
+    qpix[i] = q;
+    const int qq = q < TP ? q : 0;
+    const int yy = qq / W, xx = qq - yy * W;
+    Pc[i] = (yy + 1) * PW + xx + 1;
+  }
+  // the accumulators start from the shortcut (resnet.py:256): its loads complete under the staging
+  const long img = ((long)n * H + r0) * W;         // first pixel of the tile
+  // (lane g of a pixel column holds the 16 CONSECUTIVE channels cg * 64 + 16 g + 4 r + e of its pixel:
+  // the host packing permutes the rows of the A fragments accordingly, see tapir_conv3x3_pack)
+  f32x4 acc[4][NT];
+  auto bf4 = [](unsigned p, unsigned q) {
+    return f32x4{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u),
+                 __uint_as_float(q << 16), __uint_as_float(q & 0xffff0000u)};
+  };
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.shortcut != nullptr && qpix[i] < TP) {
+      const uint4* sp = reinterpret_cast<const uint4*>(a.shortcut + (img + qpix[i]) * C + cg * 64 + 16 * g);
+      const uint4 s0 = sp[0], s1 = sp[1];
+      acc[0][i] = bf4(s0.x, s0.y); acc[1][i] = bf4(s0.z, s0.w);
+      acc[2][i] = bf4(s1.x, s1.y); acc[3][i] = bf4(s1.z, s1.w);
+    }
+  }
+
+  // ---- stage relu(a x + b) of the haloed tile; a thread keeps one channel chunk (8 channels)
+  {
+    constexpr int PPS = THREADS / CPP;             // pixels per sweep
+    constexpr int U = WAVES == 4 ? 18 : 16;        // loads in flight per thread (one trip covers the usual tile)
+    const int chunk = tid % CPP, pl = tid / CPP;
+    f32x2 sa[4], sb[4];
+    {
+      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * C + 8 * chunk) * 2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 v = sp[k];
+        sa[k] = f32x2{v[0], v[2]}; sb[k] = f32x2{v[1], v[3]};
+      }
+    }
+    const bf16_t* xin = a.x + (long)n * H * W * C + 8 * chunk;
+    // haloed pixel P = hy * PW + hx walks in steps of PPS without a division per element
+    const int dq = PPS / PW, dr = PPS - dq * PW;
+    int hy = pl / PW, hx = pl - hy * PW;
+    for (int P0 = pl; P0 < HP; P0 += U * PPS) {
+      uint4 v[U];
+      int off[U];                                  // LDS byte offset, -1: past the tile; bit 30: outside the image
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int P = P0 + u * PPS;
+        const int y = r0 + hy - 1, x = hx - 1;
+        const bool in = P < HP && y >= 0 && y < H && x >= 0 && x < W;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (in) v[u] = *reinterpret_cast<const uint4*>(xin + (y * W + x) * C);
+        off[u] = P < HP ? ((P * CB + ((chunk ^ (P & SWZ)) << 4)) | (in ? 0 : (1 << 30))) : -1;
+        hx += dr; hy += dq;
+        if (hx >= PW) { hx -= PW; ++hy; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (off[u] < 0) continue;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (!(off[u] >> 30)) {
+          const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          unsigned r4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f32x2 xv = f32x2{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xffff0000u)};
+            const f32x2 yv = __builtin_elementwise_fma(xv, sa[k], sb[k]);
+            r4[k] = relu_bf16x2(pack_bf16x2(yv.x, yv.y));
+          }
+          o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        }
+        *reinterpret_cast<uint4*>(tile + (off[u] & 0x3fffffff)) = o;
+      }
+    }
+  }
+
+  tick(0);
+  lds_barrier();
+  tick(1);
+
+  // ---- 9 taps x KPT k-steps; B fragments one k-step ahead, A fragments refilled after their last MFMA
+  auto read_b = [&](int tap, int ks, uint4 (&fb)[NT]) {
+    const int dy = (tap * 11) >> 5;                // tap / 3 for tap < 9
+    const int toff = (dy - 1) * PW + (tap - 3 * dy - 1);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int P = Pc[i] + toff;
+      fb[i] = *reinterpret_cast<const uint4*>(tile + P * CB + (((4 * ks + g) ^ (P & SWZ)) << 4));
+    }
+  };
+  {
+    uint4 fb0[NT], fb1[NT];
+    read_b(0, 0, fb0);
+    int tap = 0, ks = 0;
+    for (int grp = 0; grp < 9 * KPT / UNR; ++grp) {
+#pragma unroll
+      for (int kk = 0; kk < UNR; ++kk) {
+        int ks1 = ks + 1, tap1 = tap;
+        if (ks1 == KPT) { ks1 = 0; tap1 = tap + 1; }
+        if (tap1 == 9) tap1 = 0;                   // past the end: any valid address (not used)
+        uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
+        uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
+        read_b(tap1, ks1, nxt);
+        sched_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint4 fa = ring[(kk % G) * 4 + r];
+#pragma unroll
+          for (int i = 0; i < NT; ++i) MfmaStep<bf16_t>::run(fa, cur[i], acc[r][i]);
+          ring[(kk % G) * 4 + r] = *wp;
+          wp += 64;
+          sched_fence();
+        }
+        tap = tap1; ks = ks1;
+      }
+    }
+  }
+  tick(2);
+  lds_barrier();   // every wave is done with the tile: the region is reused for the summaries
+  tick(3);
+
+  // ---- epilogue: + shortcut, round, store, per-channel (mean, M2) of what was stored
+  float2 (*const s_stat)[64] = reinterpret_cast<float2 (*)[64]>(tile);   // [wave][channel of the wave]
+  const int cnt_w = max(0, min(NT * 16, TP - pg * NT * 16));
+  const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
+  uint2 pk[4][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pk[r][i].x = pack_bf16x2(acc[r][i][0], acc[r][i][1]);
+      pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
+    }
+    if (qpix[i] < TP) {
+      uint4* yp = reinterpret_cast<uint4*>(a.y + (img + qpix[i]) * C + cg * 64 + 16 * g);
+      yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
+      yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bool ok = qpix[i] < TP;
+      const uint2 p = pk[r][i];
+      v[i][0] = ok ? __uint_as_float(p.x << 16) : 0.f;
+      v[i][1] = ok ? __uint_as_float(p.x & 0xffff0000u) : 0.f;
+      v[i][2] = ok ? __uint_as_float(p.y << 16) : 0.f;
+      v[i][3] = ok ? __uint_as_float(p.y & 0xffff0000u) : 0.f;
+    }
+    if (a.part) {
+      float mean[4], m2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) s += v[i][e];
+        mean[e] = s;
+      }
+      row_sum_n<4>(mean);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mean[e] *= inv_cnt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float d = qpix[i] < TP ? v[i][e] - mean[e] : 0.f;
+          s = fmaf(d, d, s);
+        }
+        m2[e] = s;
+      }
+      row_sum_n<4>(m2);
+      if (c == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_stat[wave][16 * g + 4 * r + e] = make_float2(mean[e], m2[e]);
+      }
+    }
+  }
+  tick(4);
+  if (a.part) {
+    lds_barrier();
+    if (tid < C) {
+      const int cgi = tid / 64, ch = tid % 64;
+      float cn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < PG; ++p) {
+        const float nb = (float)max(0, min(NT * 16, TP - p * NT * 16));
+        const float2 sv = s_stat[p * CG + cgi][ch];
+        merge_stats(cn, mean, m2, nb, sv.x, sv.y);
+      }
+      *reinterpret_cast<float2*>(a.part + (((long)n * a.tiles + t) * C + tid) * 2) = make_float2(mean, m2);
+    }
+  }
+  if (TRACE && a.dbg_times != nullptr && lane == 0) {
+    tick(5);
+    long long* o = a.dbg_times + ((long)bid * WAVES + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (long long)tph[k];
+  }
+}
+
+inline void launch_conv3x3_fused(const Conv3Args& a, int C, hipStream_t s) {
+  const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block((unsigned)(a.waves * 64));
+#define TAPIR_CV3(C_, W_)                                                                               \
+  do {                                                                                                  \
+    if (trace) hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, kTrace>), grid, block, 0, s, a); \
+    else TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_>), grid, block, s, a);                        \
+  } while (0)
+#ifdef TAPIR_EXPERIMENTS
+  constexpr bool kTrace = true;                    // phase trace (tools/kbench.py --what convtrace)
+  const bool trace = a.dbg_times != nullptr;
+#else
+  constexpr bool kTrace = false;
+  const bool trace = false;
+#endif
+  if (a.waves == 4) {
+    if (C == 64) TAPIR_CV3(64, 4);
+    else if (C == 128) TAPIR_CV3(128, 4);
+    else TAPIR_CV3(256, 4);
+  } else {
+    if (C == 64) TAPIR_CV3(64, 8);
+    else if (C == 128) TAPIR_CV3(128, 8);
+    else TAPIR_CV3(256, 8);
+  }
+#undef TAPIR_CV3
+}
+
+}  // namespace tapir

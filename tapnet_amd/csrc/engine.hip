@@ -12,6 +12,7 @@
 
 #include "backbone.hpp"
 #include "common.hpp"
+#include "conv_fused.hpp"
 #include "costvol.hpp"
 #include "costvol_fused.hpp"
 #include "gemm.hpp"
@@ -70,7 +71,7 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
-  DevBuf norm_ss;   // [N, C, 2] scale / shift of the InstanceNorm being applied
+  std::map<void*, DevBuf> norm_ss_by_stream;   // [N, C, 2] scale / shift of the InstanceNorm being applied, per caller stream
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
   int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
@@ -905,9 +906,11 @@ void tapir_destroy(tapir_ctx* c) {
   for (void* p : c->owned) (void)hipFree(p);
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
-                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->norm_ss, &c->splitk};
+                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (auto& kv : c->norm_ss_by_stream)
+    if (kv.second.p) (void)hipFree(kv.second.p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
     for (auto& ev : c->prof_ev[k]) c->prof_free.push_back(ev);
   for (auto& ev : c->prof_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -1149,18 +1152,20 @@ int tapir_inorm_stats(tapir_ctx* c, const void* a, const void* b, void* sum_out,
 
 int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float* gamma,
                      const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
-                     int out_h, int out_w, void* stream) {
+                     int per_s, int out_h, int out_w, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!x || !part || !gamma || !beta || !y || N < 1 || H < 1 || W < 1 || slabs < 1 || out_h < H ||
+  if (!x || !part || !gamma || !beta || !y || N < 1 || H < 1 || W < 1 || slabs < 1 || per_s < 0 || out_h < H ||
       out_w < W || (y_sub && ((H | W) & 1)))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
-  TRY(ensure(c, c->norm_ss, (size_t)N * C * 2 * sizeof(float)));
-  NormFinalizeArgs nf{part, gamma, beta, (float*)c->norm_ss.p, H * W, C, slabs};
+  // one scale / shift buffer per stream: groups of frames may be in flight on several streams
+  DevBuf* ssb = &c->norm_ss_by_stream[stream];
+  TRY(ensure(c, *ssb, (size_t)N * C * 2 * sizeof(float)));
+  NormFinalizeArgs nf{part, gamma, beta, (float*)ssb->p, H * W, C, slabs, per_s};
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   NormApplyArgs na{};
-  na.x = x; na.ss = (const float*)c->norm_ss.p; na.y = y; na.y_sub = y_sub;
+  na.x = x; na.ss = (const float*)ssb->p; na.y = y; na.y_sub = y_sub;
   na.H = H; na.W = W; na.C = C; na.oh = out_h; na.ow = out_w;
   na.pix_slabs = std::max(1, std::min(H * W / 64, (2048 + N - 1) / N));
   if (c->cfg.dtype == TAPIR_BF16)
@@ -1183,6 +1188,68 @@ int tapir_l2_normalize(tapir_ctx* c, const void* x, float* out, long pixels, int
     hipLaunchKernelGGL((l2norm_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
   else
     hipLaunchKernelGGL((l2norm_kernel<float>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+  return TAPIR_OK;
+}
+
+// ---- backbone convolutions (conv_fused.hpp): resnet.py:185-257, the 3x3 / stride-1 C -> C convolutions
+int tapir_conv3x3_plan(tapir_ctx* c, int H, int W, int C, int* rows, int* tiles) {
+  if (!c || !rows || !tiles) return TAPIR_ERR_INVALID;
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
+  if (!conv3_plan(H, W, C, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: shape");
+  return TAPIR_OK;
+}
+
+int tapir_conv3x3_pack(tapir_ctx* c, const float* w, int C, void** wstream) {
+  if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
+  if (C != 64 && C != 128 && C != 256) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: channel count");
+  // stream of channel group cg: for tap, k-step, row tile r: fragment row m = l & 15 holds output channel
+  // cg*64 + 16 (m >> 2) + 4 r + (m & 3) -- so that lane group g = m >> 2 of the accumulator layout
+  // (rows 4 g + e of tile r) owns the 16 consecutive channels 16 g + 4 r + e of its pixel --
+  // input channels 32 ks + 8 (l >> 4) + j
+  const long fpc = conv3_frags_per_cg(C);
+  std::vector<uint8_t> host((size_t)(C / 64) * fpc * 1024, 0);
+  for (int cg = 0; cg < C / 64; ++cg) {
+    uint16_t* q = (uint16_t*)(host.data() + (size_t)cg * fpc * 1024);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int ks = 0; ks < C / 32; ++ks)
+        for (int r = 0; r < 4; ++r, q += 512)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const int m = l & 15;
+              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = 32 * ks + 8 * (l >> 4) + j;
+              q[l * 8 + j] = host_f2bf(w[((size_t)co * C + ci) * 9 + tap]);
+            }
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  *wstream = d;
+  return TAPIR_OK;
+}
+
+int tapir_conv3x3_fused(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                        const float* gamma, const float* beta, float* ss, const void* wstream,
+                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int C,
+                        void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
+  if (!x || !part_in || !gamma || !beta || !ss || !wstream || !y || N < 1 || slabs_in < 1 || per_s_in < 0)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  int rows = 0, tiles = 0, waves = 0;
+  if (!conv3_plan(H, W, C, &rows, &tiles, &waves)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: shape");
+  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, C, slabs_in, per_s_in};
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
+  Conv3Args ca{};
+  ca.x = (const bf16_t*)x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(C);
+  ca.shortcut = (const bf16_t*)shortcut; ca.y = (bf16_t*)y; ca.part = part_out;
+  ca.N = N; ca.H = H; ca.W = W; ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
+  ca.dbg_times = (long long*)c->dbg_times;
+  launch_conv3x3_fused(ca, C, (hipStream_t)stream);
+  HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }
 

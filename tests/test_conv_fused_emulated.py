@@ -1,0 +1,141 @@
+"""The fused 3x3 backbone convolution (csrc/conv_fused.hpp: InstanceNorm + ReLU folded into the operand
+load, residual add and next-norm statistics in the epilogue) on the fiber emulator, against a plain
+numpy restatement of resnet.py:241-256 on the same bf16-rounded operands."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tapnet_amd import _ffi
+from tests.emu_engine import emu_lib
+from tests.test_gemm_tiles_emulated import from_bf16_bits, to_bf16_bits
+
+
+def _ctx(lib, dtype=_ffi.TAPIR_BF16):
+  cfg = _ffi.TapirCfg(1, 4, 1, 0, 20.0, 64, 64, dtype)
+  ctx = ctypes.c_void_p()
+  assert lib.tapir_create(ctypes.byref(ctx), ctypes.byref(cfg), 0) == 0
+  return ctx
+
+
+def _p(x):
+  return None if x is None else x.ctypes.data_as(ctypes.c_void_p)
+
+
+def _r(x):
+  return from_bf16_bits(to_bf16_bits(np.asarray(x, np.float32)))
+
+
+def _conv3x3_ref(xn, w):
+  """xn [N,H,W,C] (already normalised), w [Co,Ci,3,3]; zero SAME padding; float64 accumulation."""
+  N, H, W, C = xn.shape
+  xp = np.zeros((N, H + 2, W + 2, C), np.float64)
+  xp[:, 1:-1, 1:-1] = xn
+  out = np.zeros((N, H, W, w.shape[0]), np.float64)
+  for ky in range(3):
+    for kx in range(3):
+      out += xp[:, ky:ky + H, kx:kx + W] @ w[:, :, ky, kx].astype(np.float64).T
+  return out
+
+
+def run_conv(lib, ctx, x_bits, part_in, slabs_in, per_s_in, gamma, beta, wstream, shortcut_bits, N, H, W, C):
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv3x3_plan(ctx, H, W, C, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  y = np.zeros((N, H, W, C), np.uint16)
+  part = np.zeros((N, tiles.value, C, 2), np.float32)
+  ss = np.zeros((N, C, 2), np.float32)
+  rc = lib.tapir_conv3x3_fused(ctx, _p(x_bits), _p(part_in), slabs_in, per_s_in, _p(gamma), _p(beta), _p(ss),
+                               wstream, _p(shortcut_bits), _p(y), _p(part), N, H, W, C, None)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  return y, part, rows.value, tiles.value
+
+
+@pytest.mark.parametrize('C,H,W,shortcut', [(64, 8, 16, True), (64, 5, 24, False), (128, 6, 12, True),
+                                            (256, 9, 8, True), (256, 4, 32, False),
+                                            # rows too long for the 4-wave tile: the 8-wave workgroups
+                                            (64, 3, 200, True), (128, 3, 100, False), (256, 4, 40, True)])
+def test_conv3x3_fused(C, H, W, shortcut):
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  rng = np.random.default_rng(C + H + W)
+  N = 2
+  x = _r(rng.standard_normal((N, H, W, C)) * 1.5 + 0.5)
+  w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+  beta = (rng.standard_normal(C) * 0.3).astype(np.float32)
+  sc = _r(rng.standard_normal((N, H, W, C))) if shortcut else None
+  xb = to_bf16_bits(x)
+  slabs = 3
+  part_in = np.zeros((N, slabs, C, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, C, slabs, None) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv3x3_pack(ctx, _p(np.ascontiguousarray(w)), C, ctypes.byref(ws)) == 0
+  y, part, rows, tiles = run_conv(lib, ctx, xb, part_in, slabs, 0, gamma, beta, ws,
+                                  to_bf16_bits(sc) if shortcut else None, N, H, W, C)
+  # reference on the same rounded operands
+  mean = x.mean((1, 2), keepdims=True, dtype=np.float64)
+  var = x.astype(np.float64).var((1, 2), keepdims=True)
+  rstd = 1.0 / np.sqrt(var + 1e-5)
+  a = (rstd * gamma).astype(np.float32)
+  b = (beta - mean * rstd * gamma).astype(np.float32)
+  xn = _r(np.maximum(x * a + b, 0))
+  ref = _conv3x3_ref(xn, _r(w))
+  if shortcut:
+    ref = ref + sc
+  got = from_bf16_bits(y)
+  # bf16 output rounding (2^-9 relative) + the (a, b) pair computed in f32 from merged summaries
+  np.testing.assert_allclose(got, ref, atol=2e-2, rtol=1e-2)
+  assert np.abs(got - ref).mean() < 2e-3
+  # the summaries describe the STORED tensor exactly: merge them and compare with numpy
+  assert part.shape[1] == tiles and tiles == -(-H // rows)
+  cnt = np.array([min(rows, H - t * rows) * W for t in range(tiles)], np.float64)
+  pm, pM2 = part[..., 0].astype(np.float64), part[..., 1].astype(np.float64)
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  np.testing.assert_allclose(tot_mean, got.mean((1, 2), dtype=np.float64), atol=1e-5)
+  np.testing.assert_allclose(tot_M2 / (H * W), got.astype(np.float64).var((1, 2)), rtol=1e-4, atol=1e-6)
+  lib.tapir_destroy(ctx)
+
+
+def test_conv3x3_chain_uses_part_out():
+  """part_out of one call is a valid part_in of the next (slabs = tiles, per_s = rows * W)."""
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  rng = np.random.default_rng(3)
+  N, H, W, C = 1, 7, 16, 64
+  x = _r(rng.standard_normal((N, H, W, C)))
+  w0 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  w1 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  g = np.ones(C, np.float32)
+  z = np.zeros(C, np.float32)
+  xb = to_bf16_bits(x)
+  part_in = np.zeros((N, 1, C, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, C, 1, None) == 0
+  ws0, ws1 = ctypes.c_void_p(), ctypes.c_void_p()
+  assert lib.tapir_conv3x3_pack(ctx, _p(w0), C, ctypes.byref(ws0)) == 0
+  assert lib.tapir_conv3x3_pack(ctx, _p(w1), C, ctypes.byref(ws1)) == 0
+  y0, part0, rows, tiles = run_conv(lib, ctx, xb, part_in, 1, 0, g, z, ws0, None, N, H, W, C)
+  y1, _, _, _ = run_conv(lib, ctx, y0, part0, tiles, rows * W, g, z, ws1, xb, N, H, W, C)
+  # the same second convolution with summaries recomputed by the stand-alone statistics kernel
+  part_chk = np.zeros((N, 2, C, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(y0), None, None, _p(part_chk), N, H * W, C, 2, None) == 0
+  y1b, _, _, _ = run_conv(lib, ctx, y0, part_chk, 2, 0, g, z, ws1, xb, N, H, W, C)
+  d = np.abs(from_bf16_bits(y1) - from_bf16_bits(y1b))
+  assert d.max() <= 2e-2 and (d > 0).mean() < 0.02   # (a, b) differ in the last f32 bits at most
+  lib.tapir_destroy(ctx)
+
+
+def test_conv3x3_rejects_f32_and_bad_shapes():
+  lib = emu_lib()
+  ctx = _ctx(lib, _ffi.TAPIR_F32)
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv3x3_plan(ctx, 8, 8, 64, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  lib.tapir_destroy(ctx)
+  ctx = _ctx(lib)
+  assert lib.tapir_conv3x3_plan(ctx, 8, 8, 96, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_conv3x3_plan(ctx, 8, 2000, 256, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_conv3x3_plan(ctx, 128, 128, 64, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert (rows.value, tiles.value) == (2, 64)      # 4-wave workgroups: 256 pixels
+  assert lib.tapir_conv3x3_plan(ctx, 256, 256, 64, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert (rows.value, tiles.value) == (2, 128)     # rows too long for the 72-KiB tile: 8 waves, 512 pixels
+  lib.tapir_destroy(ctx)

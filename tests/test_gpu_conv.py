@@ -1,0 +1,103 @@
+"""-m gpu: the fused 3x3 backbone convolution (csrc/conv_fused.hpp) through the C ABI on the real
+gfx950 library against a plain PyTorch f32 reference of the same op (resnet.py:241-256: InstanceNorm,
+relu, 3x3 SAME convolution, residual add), and the backbone with / without it."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tapnet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def model():
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(21, 1, False)
+  return tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=w, device='cuda:0', dtype='bfloat16')
+
+
+@pytest.mark.parametrize('n,h,w,c,shortcut', [(4, 128, 128, 64, True), (3, 64, 64, 128, True), (5, 32, 32, 256, False),
+                                              (2, 30, 40, 128, True), (2, 17, 24, 256, True), (1, 256, 256, 64, False)])
+def test_conv3x3_fused_vs_torch(model, n, h, w, c, shortcut):
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  g = torch.Generator(device='cpu').manual_seed(n * 1000 + h + c)
+  x = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.5).to(torch.bfloat16).to(dev)
+  sc = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).to(dev) if shortcut else None
+  wt = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).contiguous()
+  gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+  beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  slabs = 5
+  part_in = torch.empty(n, slabs, c, 2, device=dev)
+  assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, slabs, stream) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wt.data_ptr()), c, ctypes.byref(ws)) == 0
+  y = torch.zeros(n, h, w, c, device=dev, dtype=torch.bfloat16)
+  part = torch.zeros(n, tiles.value, c, 2, device=dev)
+  ss = torch.empty(n, c, 2, device=dev)
+  rc = lib.tapir_conv3x3_fused(ctx, x.data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(), beta.data_ptr(),
+                               ss.data_ptr(), ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(),
+                               n, h, w, c, stream)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  torch.cuda.synchronize()
+  # f32 reference on the same bf16-rounded operands (normalised activations rounded to bf16 like the kernel's LDS image)
+  xf = x.float()
+  mean = xf.mean((1, 2), keepdim=True)
+  var = xf.var((1, 2), keepdim=True, unbiased=False)
+  xn = torch.relu((xf - mean) / torch.sqrt(var + 1e-5) * gamma + beta).to(torch.bfloat16).float()
+  ref = F.conv2d(xn.permute(0, 3, 1, 2), wt.to(torch.bfloat16).float().to(dev), padding=1).permute(0, 2, 3, 1)
+  if shortcut:
+    ref = ref + sc.float()
+  got = y.float()
+  d = (got - ref).abs()
+  # bf16 output rounding: half an ulp of values up to ~8 -> 1.6e-2; a normalised operand that rounds the other way
+  # (the (a, b) pair comes from merged f32 summaries) adds one more operand ulp
+  assert float(d.max()) < 4e-2, float(d.max())
+  assert float(d.mean()) < 2.5e-3, float(d.mean())
+  # the summaries describe the stored tensor
+  cnt = torch.tensor([min(rows.value, h - t * rows.value) * w for t in range(tiles.value)], device=dev,
+                     dtype=torch.float64)
+  pm, pM2 = part[..., 0].double(), part[..., 1].double()
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  gd = got.double()
+  assert torch.allclose(tot_mean, gd.mean((1, 2)), atol=1e-5)
+  assert torch.allclose(tot_M2 / (h * w), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('size', [256, 200])
+def test_backbone_fused_convs_vs_miopen(model, size):
+  """Backbone.features of the bf16 model with the HIP convolutions and with every convolution on MIOpen,
+  both against the f32 backbone (MIOpen f32) of the same weights.  The grids are unit vectors per pixel;
+  the gates are those of test_bf16_backbone_golden (cosine > 0.998, max component error 2.5e-2): the
+  fused path has to be as close to f32 as the all-MIOpen bf16 path is (it rounds the residual add once
+  instead of twice), and the two bf16 paths agree with each other to the same order."""
+  from tapnet_amd import tapir_model
+  bb = model._backbone
+  m32 = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=synthetic.make_weights(21, 1, False),
+                          device='cuda:0', dtype='float32')
+  frames = torch.as_tensor(synthetic.make_video(3, 6, size, size), device=model.device)
+  frames = frames.reshape(-1, size, size, 3).float()
+  assert bb._wstream, 'the 3x3 kernels were not packed for the HIP convolution'
+  ref = [t.clone() for t in m32._backbone.features(frames)]
+  bb.conv_mode = 'miopen'
+  mio = [t.clone() for t in bb.features(frames)]
+  bb.conv_mode = 'auto'
+  fused = bb.features(frames)
+  assert any(v is not None for v in bb._plans.values()), 'no shape ran on the HIP convolution'
+  for name, r, a, b in (('lowres', ref[0], mio[0], fused[0]), ('hires', ref[1], mio[1], fused[1])):
+    cos_m, cos_f, cos_mf = (r * a).sum(-1).min(), (r * b).sum(-1).min(), (a * b).sum(-1).min()
+    err_m, err_f = (r - a).abs().max(), (r - b).abs().max()
+    print(f'{name} {size}: min cos vs f32: miopen {float(cos_m):.5f} fused {float(cos_f):.5f}; fused vs miopen '
+          f'{float(cos_mf):.5f}; max err vs f32: miopen {float(err_m):.4f} fused {float(err_f):.4f}')
+    assert float(cos_f) > 0.998 and float(err_f) < 2.5e-2
+    assert float(cos_f) > float(cos_m) - 5e-4     # no further from f32 than the MIOpen bf16 path
+    assert float(cos_mf) > 0.997

@@ -8,7 +8,8 @@ import os
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tapnet_amd import TAPIR, synthetic
+from tapnet_amd import synthetic
+from tapnet_amd.tapir_model import TAPIR
 
 
 def main():
@@ -18,8 +19,8 @@ def main():
   ap.add_argument('--dtype', default='bfloat16')
   ap.add_argument('--reps', type=int, default=20)
   a = ap.parse_args()
-  w = synthetic.make_weights(seed=0)
-  m = TAPIR(weights=w, device='cuda:0', dtype=a.dtype)
+  w = synthetic.make_weights(0, 0, False)
+  m = TAPIR(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, weights=w, device='cuda:0', dtype=a.dtype)
   bb = m._backbone
   frames = torch.rand(a.frames, a.size, a.size, 3, device='cuda:0') * 2 - 1
   ref = None

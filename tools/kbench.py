@@ -297,7 +297,7 @@ def bench_norm(model, reps, results):
         assert lib.tapir_inorm_stats(ctx, x[i % 3].data_ptr(), b.data_ptr(), x[i % 3].data_ptr(), part.data_ptr(), n, h * w, c, slabs, stream) == 0
       def relu(i):
         assert lib.tapir_inorm_relu(ctx, x[i % 3].data_ptr(), part.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                    y.data_ptr(), None, n, h, w, c, slabs, h, w, stream) == 0
+                                    y.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
       for name, fn, passes in (('inorm_stats', stats, 1), ('inorm_stats_add', stats_add, 3), ('inorm_relu(+finalize)', relu, 2)):
         t = timeit(fn, reps)
         row = dict(kernel=name, shape=[n, h, w, c], slabs=slabs, **t,
@@ -437,6 +437,108 @@ def trace_fused(model):
           f'   waves min/max {per_wave.min():.0f}/{per_wave.max():.0f}')
 
 
+def trace_conv(model):
+  """per-phase shader-cycle totals of the fused 3x3 convolution (TRACE build: library built with
+  -DTAPIR_EXPERIMENTS, TAPIR_HIP_LIB=...): mean over waves and workgroups."""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  names = ['stage tile (norm+relu -> LDS)', 'barrier (tile visible)', 'k loop (9 taps)', 'barrier (tile free)',
+           'epilogue (add, store, stats)', 'summary merge']
+  for (n, h, w, c) in ((48, 128, 128, 64), (48, 64, 64, 128), (48, 32, 32, 256)):
+    rows, tiles = ctypes.c_int(), ctypes.c_int()
+    assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    x = (torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16)
+    sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+    wh = (torch.randn(c, c, 3, 3) / (9 * c) ** 0.5).contiguous()
+    gamma = torch.rand(c, device=dev) + 0.5
+    beta = torch.randn(c, device=dev) * 0.3
+    part_in = torch.empty(n, 4, c, 2, device=dev)
+    part_out = torch.empty(n, tiles.value, c, 2, device=dev)
+    ss = torch.empty(n, c, 2, device=dev)
+    y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    ws = ctypes.c_void_p()
+    assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, ctypes.byref(ws)) == 0
+    assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, 4, stream) == 0
+    nwg = n * tiles.value
+    buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+    for it in range(3):
+      buf.zero_()
+      assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
+      assert lib.tapir_conv3x3_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(),
+                                     ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c,
+                                     stream) == 0
+      torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, None)
+    waves = 4 if rows.value * w <= 16384 // c else 8
+    t = buf[:nwg * waves * 8].view(nwg, waves, 8).double().cpu().numpy()
+    tot = t.sum(-1).mean()
+    mf = 2.0 * rows.value * w * 9 * c * c
+    print(f'conv3x3 fused phase trace, [{n},{h},{w},{c}] ({nwg} workgroups of {rows.value} rows, {waves} waves): mean shader cycles per '
+          f'wave {tot:.0f}; MFMA floor {mf / 4069:.0f} cycles per workgroup')
+    for k, nm in enumerate(names):
+      pw = t[:, :, k].mean(0)
+      print(f'  {nm:32s} {t[:, :, k].mean():9.0f} cycles {100 * t[:, :, k].mean() / tot:5.1f} %   waves min/max {pw.min():.0f}/{pw.max():.0f}')
+
+
+def bench_conv(model, reps, results):
+  """the fused 3x3 backbone convolution (conv_fused.hpp) against the launches it replaces: finalize +
+  normalise/ReLU kernel, the MIOpen convolution, the statistics (+ residual add) kernel"""
+  import torch.nn.functional as F
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  torch.backends.cudnn.benchmark = True
+  for (n, h, w, c) in ((48, 128, 128, 64), (48, 64, 64, 128), (48, 32, 32, 256), (8, 256, 256, 64)):
+    rows, tiles = ctypes.c_int(), ctypes.c_int()
+    assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    x = [(torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16) for _ in range(3)]
+    sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+    wt = (torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5)
+    wcl = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gamma = torch.rand(c, device=dev) + 0.5
+    beta = torch.randn(c, device=dev) * 0.3
+    slabs = max(1, min(h * w // 64, -(-1024 // n), 64))
+    part_in = torch.empty(n, slabs, c, 2, device=dev)
+    part_out = torch.empty(n, tiles.value, c, 2, device=dev)
+    part2 = torch.empty(n, slabs, c, 2, device=dev)
+    ss = torch.empty(n, c, 2, device=dev)
+    y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    yn = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    ws = ctypes.c_void_p()
+    wh = wt.cpu().contiguous()
+    assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, ctypes.byref(ws)) == 0
+    for t_ in x:
+      assert lib.tapir_inorm_stats(ctx, t_.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, slabs, stream) == 0
+    def hip(i):
+      assert lib.tapir_conv3x3_fused(ctx, x[i % 3].data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(),
+                                     beta.data_ptr(), ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(),
+                                     part_out.data_ptr(), n, h, w, c, stream) == 0
+    conv_out = [None]
+    def miopen_conv(i):
+      conv_out[0] = F.conv2d(yn.permute(0, 3, 1, 2), wcl, None, padding=1)
+    def replaced(i):
+      assert lib.tapir_inorm_relu(ctx, x[i % 3].data_ptr(), part_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                  yn.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
+      o = F.conv2d(yn.permute(0, 3, 1, 2), wcl, None, padding=1).permute(0, 2, 3, 1)
+      assert lib.tapir_inorm_stats(ctx, o.data_ptr(), sc.data_ptr(), o.data_ptr(), part2.data_ptr(), n, h * w, c, slabs, stream) == 0
+      conv_out[0] = o
+    # correctness on the GPU: the fused kernel against the replaced sequence (same operand rounding;
+    # the sequence rounds the convolution to bf16 before the add, the fused kernel only after it)
+    assert lib.tapir_inorm_stats(ctx, x[0].data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, slabs, stream) == 0
+    hip(0); replaced(0)
+    torch.cuda.synchronize()
+    d = (y.float() - conv_out[0].float()).abs()
+    flops = 2.0 * n * h * w * c * c * 9
+    for name, fn in (('conv3x3_fused_hip', hip), ('miopen_conv_only', miopen_conv), ('norm_relu+miopen_conv+stats_add', replaced)):
+      t = timeit(fn, reps)
+      row = dict(kernel=name, shape=[n, h, w, c], tiles=tiles.value, rows=rows.value, **t,
+                 tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
+                 max_abs_diff_vs_replaced=round(float(d.max()), 4), mean_abs_diff=round(float(d.mean()), 6))
+      results.append(row)
+      print(json.dumps(row), flush=True)
+
+
 def bench_backbone(model, reps, results):
   if os.environ.get('TAPIR_CUDNN_BENCHMARK'):
     torch.backends.cudnn.benchmark = os.environ['TAPIR_CUDNN_BENCHMARK'] == '1'
@@ -480,6 +582,10 @@ def main():
       bench_norm(model, args.reps, results)
     if 'cv' in what:
       bench_cv(model, args.reps, results)
+    if 'conv' in what:
+      bench_conv(model, args.reps, results)
+    if 'convtrace' in what:
+      trace_conv(model)
     if 'cvfusedtrace' in what:
       trace_cv_fused(model)
     if 'fusedtrace' in what:
