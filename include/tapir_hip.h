@@ -233,7 +233,7 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * tapir_conv3x3_fused: y [N,H,W,C] = conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut),
  *   rounded to bf16.  part_in [N, slabs_in, C, 2] are (mean, M2) summaries of x per slab of per_s_in
  *   pixels (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
- *   ss [N, C, 2] f32 scratch of the caller (the merged scale / shift); part_out, if not NULL,
+ *   ss: N * C * 2 floats of scratch owned by the caller (the merged scale / shift); part_out, if not NULL,
  *   [N, tiles, C, 2] receives the summaries of y per tile (rows * W pixels each). */
 int tapir_conv3x3_plan(tapir_ctx* ctx, int H, int W, int C, int* rows, int* tiles);
 int tapir_conv3x3_pack(tapir_ctx* ctx, const float* w, int C, void** wstream);

@@ -185,6 +185,7 @@ struct NormFinalizeArgs {
   float* ss;            // [N, C, 2]: (rstd * gamma, beta - mean * rstd * gamma)
   int HW, C, slabs;
   int per_s;            // pixels per slab (the last one may be shorter); 0 = ceil(HW / slabs)
+  int planar8;          // 1: ss is [N, C / 8, 2, 8] (the 8 scales of a channel chunk, then its 8 shifts)
 };
 
 // grid (N), one thread per channel: merges the slab summaries once per (image, channel).
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinali
     }
     const float rstd = 1.0f / sqrtf(m2 / (float)a.HW + kInEps);
     const float sc = rstd * a.gamma[c];
-    a.ss[((long)n * a.C + c) * 2] = sc;
-    a.ss[((long)n * a.C + c) * 2 + 1] = a.beta[c] - mean * sc;
+    const long i0 = a.planar8 ? ((long)n * a.C + (c & ~7)) * 2 + (c & 7) : ((long)n * a.C + c) * 2;
+    a.ss[i0] = sc;
+    a.ss[i0 + (a.planar8 ? 8 : 1)] = a.beta[c] - mean * sc;
   }
 }
 

@@ -33,7 +33,7 @@ constexpr int cv3_lds_bytes(int waves) { return waves * 18 * 1024; }
 
 struct Conv3Args {
   const bf16_t* x;        // [N, H, W, C] raw input of the norm
-  const float* ss;        // [N, C, 2] (a, b): operand = relu(a * x + b)
+  const float* ss;        // [N, C / 8, 2, 8] (a of 8 channels, b of 8 channels): operand = relu(a * x + b)
   const uint4* wstream;   // [C / 64][frags_per_cg][64 lanes] packed A fragments (conv3_pack_weights)
   long frags_per_cg;
   const bf16_t* shortcut; // null, or [N, H, W, C] added before rounding
@@ -75,7 +75,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int C, int NT, int WAVES, bool TRACE = false>
+template <int C, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args a) {
   constexpr int THREADS = WAVES * 64;
   constexpr int CG = C / 64, PG = WAVES / CG;
@@ -144,35 +144,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
   // (lane g of a pixel column holds the 16 CONSECUTIVE channels cg * 64 + 16 g + 4 r + e of its pixel:
   // the host packing permutes the rows of the A fragments accordingly, see tapir_conv3x3_pack)
   f32x4 acc[4][NT];
+  // (the raw 32 bytes are parked in acc[0] / acc[1] and converted after the staging: a conversion
+  // right here would make the wave wait out the load latency once per pixel tile)
   auto bf4 = [](unsigned p, unsigned q) {
     return f32x4{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u),
                  __uint_as_float(q << 16), __uint_as_float(q & 0xffff0000u)};
   };
+  // All loads of the prologue are unconditional (clamped addresses, the mask is applied on use): a load
+  // under a lane condition costs a branch and, in hipcc's hands, a wait for it right behind the branch.
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.shortcut != nullptr && qpix[i] < TP) {
-      const uint4* sp = reinterpret_cast<const uint4*>(a.shortcut + (img + qpix[i]) * C + cg * 64 + 16 * g);
-      const uint4 s0 = sp[0], s1 = sp[1];
-      acc[0][i] = bf4(s0.x, s0.y); acc[1][i] = bf4(s0.z, s0.w);
-      acc[2][i] = bf4(s1.x, s1.y); acc[3][i] = bf4(s1.z, s1.w);
+    if (HAS_SC) {
+      const int qq = qpix[i] < TP ? qpix[i] : 0;
+      const f32x4* sp = reinterpret_cast<const f32x4*>(a.shortcut + (img + qq) * C + cg * 64 + 16 * g);
+      acc[0][i] = sp[0];
+      acc[1][i] = sp[1];
     }
   }
 
-  // ---- stage relu(a x + b) of the haloed tile; a thread keeps one channel chunk (8 channels)
+  // ---- stage relu(a x + b) of the haloed tile; a thread keeps one channel chunk (8 channels).
+  // (A row-by-row walk with loop-invariant column math has half the VALU instructions and was 15 %
+  // SLOWER on the GPU: the phase is bound by the memory system)
   {
     constexpr int PPS = THREADS / CPP;             // pixels per sweep
     constexpr int U = WAVES == 4 ? 18 : 16;        // loads in flight per thread (one trip covers the usual tile)
     const int chunk = tid % CPP, pl = tid / CPP;
-    f32x2 sa[4], sb[4];
+    f32x4 ssv[4];                                  // a[0..3], a[4..7], b[0..3], b[4..7] of this chunk
     {
       const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * C + 8 * chunk) * 2);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4 v = sp[k];
-        sa[k] = f32x2{v[0], v[2]}; sb[k] = f32x2{v[1], v[3]};
-      }
+      for (int k = 0; k < 4; ++k) ssv[k] = sp[k];
     }
     const bf16_t* xin = a.x + (long)n * H * W * C + 8 * chunk;
     // haloed pixel P = hy * PW + hx walks in steps of PPS without a division per element
@@ -186,32 +189,40 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
         const int P = P0 + u * PPS;
         const int y = r0 + hy - 1, x = hx - 1;
         const bool in = P < HP && y >= 0 && y < H && x >= 0 && x < W;
-        v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (in) v[u] = *reinterpret_cast<const uint4*>(xin + (y * W + x) * C);
+        const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+        v[u] = *reinterpret_cast<const uint4*>(xin + (yc * W + xc) * C);
         off[u] = P < HP ? ((P * CB + ((chunk ^ (P & SWZ)) << 4)) | (in ? 0 : (1 << 30))) : -1;
         hx += dr; hy += dq;
         if (hx >= PW) { hx -= PW; ++hy; }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (off[u] < 0) continue;
-        uint4 o = make_uint4(0u, 0u, 0u, 0u);
-        if (!(off[u] >> 30)) {
-          const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-          unsigned r4[4];
+        const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const unsigned m = (off[u] >> 30) ? 0u : 0xffffffffu;
+        unsigned r4[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const f32x2 xv = f32x2{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xffff0000u)};
-            const f32x2 yv = __builtin_elementwise_fma(xv, sa[k], sb[k]);
-            r4[k] = relu_bf16x2(pack_bf16x2(yv.x, yv.y));
-          }
-          o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        for (int k = 0; k < 4; ++k) {
+          const f32x2 xv = f32x2{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xffff0000u)};
+          const f32x2 sa = f32x2{ssv[k >> 1][2 * (k & 1)], ssv[k >> 1][2 * (k & 1) + 1]};
+          const f32x2 sb = f32x2{ssv[2 + (k >> 1)][2 * (k & 1)], ssv[2 + (k >> 1)][2 * (k & 1) + 1]};
+          const f32x2 yv = __builtin_elementwise_fma(xv, sa, sb);
+          r4[k] = relu_bf16x2(pack_bf16x2(yv.x, yv.y)) & m;
         }
-        *reinterpret_cast<uint4*>(tile + (off[u] & 0x3fffffff)) = o;
+        if (off[u] >= 0) *reinterpret_cast<uint4*>(tile + (off[u] & 0x3fffffff)) = make_uint4(r4[0], r4[1], r4[2], r4[3]);
       }
     }
   }
 
+  if (HAS_SC) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const uint4 s0 = __builtin_bit_cast(uint4, acc[0][i]), s1 = __builtin_bit_cast(uint4, acc[1][i]);
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = qpix[i] < TP;
+      acc[0][i] = ok ? bf4(s0.x, s0.y) : zero; acc[1][i] = ok ? bf4(s0.z, s0.w) : zero;
+      acc[2][i] = ok ? bf4(s1.x, s1.y) : zero; acc[3][i] = ok ? bf4(s1.z, s1.w) : zero;
+    }
+  }
   tick(0);
   lds_barrier();
   tick(1);
@@ -341,10 +352,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
 
 inline void launch_conv3x3_fused(const Conv3Args& a, int C, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block((unsigned)(a.waves * 64));
-#define TAPIR_CV3(C_, W_)                                                                               \
-  do {                                                                                                  \
-    if (trace) hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, kTrace>), grid, block, 0, s, a); \
-    else TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_>), grid, block, s, a);                        \
+#define TAPIR_CV3(C_, W_)                                                                                         \
+  do {                                                                                                            \
+    if (trace) {                                                                                                  \
+      if (a.shortcut) hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, true, kTrace>), grid, block, 0, s, a);  \
+      else hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, false, kTrace>), grid, block, 0, s, a);            \
+    } else if (a.shortcut) {                                                                                      \
+      TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_, true>), grid, block, s, a);                               \
+    } else {                                                                                                      \
+      TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_, false>), grid, block, s, a);                              \
+    }                                                                                                             \
   } while (0)
 #ifdef TAPIR_EXPERIMENTS
   constexpr bool kTrace = true;                    // phase trace (tools/kbench.py --what convtrace)

@@ -1162,7 +1162,7 @@ int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float
   // one scale / shift buffer per stream: groups of frames may be in flight on several streams
   DevBuf* ssb = &c->norm_ss_by_stream[stream];
   TRY(ensure(c, *ssb, (size_t)N * C * 2 * sizeof(float)));
-  NormFinalizeArgs nf{part, gamma, beta, (float*)ssb->p, H * W, C, slabs, per_s};
+  NormFinalizeArgs nf{part, gamma, beta, (float*)ssb->p, H * W, C, slabs, per_s, 0};
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   NormApplyArgs na{};
   na.x = x; na.ss = (const float*)ssb->p; na.y = y; na.y_sub = y_sub;
@@ -1241,7 +1241,7 @@ int tapir_conv3x3_fused(tapir_ctx* c, const void* x, const float* part_in, int s
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   int rows = 0, tiles = 0, waves = 0;
   if (!conv3_plan(H, W, C, &rows, &tiles, &waves)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: shape");
-  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, C, slabs_in, per_s_in};
+  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, C, slabs_in, per_s_in, 1};
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   Conv3Args ca{};
   ca.x = (const bf16_t*)x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(C);
