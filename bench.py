@@ -288,7 +288,9 @@ def main():
         dtype='bf16' if dtype == 'bfloat16' else 'f32', data='synthetic',
         config=dict(workload=f'TAPIR.__call__ ({args.model} kwargs), {S}x{S}x{T} clip, Q={Q}, '
                              f'4 refinement iters, random-init weights', clips=clips,
-                    shard=args.shard, backbone='MIOpen convolutions + HIP norm/add/L2 kernels',
+                    shard=args.shard, backbone=('HIP fused 3x3 convolutions (norm+ReLU in, add+statistics out) + MIOpen stem / strided / 1x1 '
+                              '+ HIP norm / L2 kernels, hipGraph replay' if dtype == 'bfloat16' else
+                              'MIOpen convolutions + HIP norm/add/L2 kernels'),
                     hot_path='HIP gfx950'),
         hot_path_ms=round(hot_s * 1e3, 3), backbone_ms=round(bb_s * 1e3, 3),
         hot_path_points_per_s=round(Q / hot_s, 2),

@@ -208,7 +208,9 @@ int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* laun
  *   alias a or b).  part [N, slabs, C, 2] f32 receives one (mean, M2) summary per slab of pixels.
  * tapir_inorm_relu: y = relu((x - mean) / sqrt(var + 1e-5) * gamma + beta) (resnet.py:241-249) from
  *   those summaries (slabs of per_s pixels; per_s = 0: ceil(HW / slabs), what tapir_inorm_stats
- *   writes; the part_out of tapir_conv3x3_fused has per_s = rows * W).  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
+ *   writes; the part_out of tapir_conv3x3_fused has per_s = rows * W); ss: N * C * 2 floats of scratch
+ *   owned by the caller (the merged scale / shift pairs; the context keeps no buffer of its own, so
+ *   calls on different streams do not share one).  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
  *   H / W are not written (pass a zero-initialised buffer with out_h = H+1, out_w = W+1 to get the
  *   XLA "SAME" padding of a stride-2 3x3 convolution, which pads on the high side only).
  *   y_sub, if not NULL, [N, H/2, W/2, C] receives the pixels with even h and w (input of the
@@ -217,8 +219,8 @@ int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* laun
 int tapir_inorm_stats(tapir_ctx* ctx, const void* a, const void* b, void* sum_out, float* part,
                       int N, int HW, int C, int slabs, void* stream);
 int tapir_inorm_relu(tapir_ctx* ctx, const void* x, const float* part, const float* gamma,
-                     const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
-                     int per_s, int out_h, int out_w, void* stream);
+                     const float* beta, float* ss, void* y, void* y_sub, int N, int H, int W, int C,
+                     int slabs, int per_s, int out_h, int out_w, void* stream);
 int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, int C, void* stream);
 
 /* The 3x3 / stride-1 / SAME convolutions of the ResNet blocks (C -> C channels, C in {64,128,256};

@@ -81,7 +81,7 @@ PROTOTYPES = {
     'tapir_estimate_trajectories': (c_int, [c_void_p, POINTER(TapirTrajArgs), c_void_p]),
     'tapir_inorm_stats': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_void_p]),
-    'tapir_inorm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    'tapir_inorm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'tapir_l2_normalize': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     'tapir_conv3x3_plan': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

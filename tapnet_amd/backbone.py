@@ -1,5 +1,5 @@
-"""Feature backbone (R7) on PyTorch-ROCm / MIOpen -- north_star keeps the ResNet
-convolutions on PyTorch; everything after the feature grids is HIP.
+"""Feature backbone (R7): HIP kernels + the remaining convolutions on PyTorch-ROCm / MIOpen
+(north_star keeps the ResNet convolutions on PyTorch; SURVEY.md 8 f1 moves them to HIP).
 
 Re-statement of TAPIR.get_feature_grids (tapnet/models/tapir_model.py:626-729):
 bilinear resize -> ResNet-v2 with InstanceNorm (tapnet/models/resnet.py:150-257,
@@ -13,13 +13,15 @@ state_dict names (tapnet/torch/nets.py).
 Runs channels-last (NHWC) so that the feature grids leave in the
 [B,T,h,w,C] layout the HIP kernels read, with no transpose.
 
-GPU only.  Only the convolutions run in PyTorch (MIOpen / CK implicit-GEMM, NHWC): everything
-between them -- InstanceNorm statistics, normalise + ReLU (+ the high-side zero border of XLA
-SAME padding and the 2x2 subsampling for the strided projections), the residual add and
-the final L2 normalisation -- are the HIP kernels of tapnet_amd/csrc/backbone.hpp, called
-through the C ABI (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  There is no CPU
-path here; the plain PyTorch restatement used by the CPU tests and by bench.py's cpu_baseline
-lives in oracle/backbone_torch.py.
+GPU only.  bf16 contexts: the 3x3 / stride-1 C -> C convolutions (13 of the 16 3x3 convolutions, 85 %
+of the flops) are the fused HIP kernel of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in
+its operand load, residual add and the next norm's statistics in its epilogue
+(tapir_conv3x3_fused); the 7x7 stem, the two stride-2 3x3 and the 1x1 projections run in PyTorch
+(MIOpen / CK implicit-GEMM, NHWC) with the HIP kernels of csrc/backbone.hpp between them
+(tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  f32 contexts: every convolution through
+MIOpen, the same glue kernels.  From the third call with one shape on, a clip's launches are replayed
+from a hipGraph.  There is no CPU path here; the plain PyTorch restatement used by the CPU tests and
+by bench.py's cpu_baseline lives in oracle/backbone_torch.py.
 """
 from __future__ import annotations
 
@@ -75,6 +77,10 @@ class Backbone:
     # backbone's flops) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it
     # (bf16 contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
     self.conv_mode = 'auto'
+    # clips of at least this many frames replay their launches from a hipGraph from the third call with
+    # the same shape on (features()); 0 = always launch eagerly
+    self.graph_min_frames = 8
+    self._graphs: Dict[tuple, dict] = {}
     self._plans: Dict[tuple, Optional[tuple]] = {}
     self._wstream: Dict[str, int] = {}
     self._bufs: Dict[tuple, torch.Tensor] = {}
@@ -165,9 +171,10 @@ class Backbone:
     oh, ow = (h + 1, w + 1) if pad else (h, w)
     y = self._buf(('y', tag, n, oh, ow, c), (n, oh, ow, c), self.dtype, zero=pad)
     ys = self._buf(('ysub', tag, n, h // 2, w // 2, c), (n, h // 2, w // 2, c), self.dtype) if sub else None
+    ss = self._buf(('ss', n, c), (n, c, 2), torch.float32)
     self._check(lib.tapir_inorm_relu(ctx, x.data_ptr(), st.part.data_ptr(),
                                      self.w[name + '.weight'].data_ptr(), self.w[name + '.bias'].data_ptr(),
-                                     y.data_ptr(), ys.data_ptr() if sub else None, n, h, w, c, st.slabs,
+                                     ss.data_ptr(), y.data_ptr(), ys.data_ptr() if sub else None, n, h, w, c, st.slabs,
                                      st.per_s, oh, ow, self._stream()), 'tapir_inorm_relu')
     return y, ys
 
@@ -278,11 +285,41 @@ class Backbone:
     if n == 0:
       return low, hi
     streams = max(1, min(int(self.streams), n))
+    # hipGraph replay: a clip's backbone is ~60 launches of 10-100 us kernels, which one Python thread
+    # cannot issue as fast as the GPU retires them (2.04 ms wall against 1.7 ms of kernels for 48 frames).
+    # From the third call with the same shape on, the launches are replayed from a captured graph.
+    key = (n, H, W, self.conv_mode)
+    if (self.graph_min_frames and n >= self.graph_min_frames and streams == 1 and (not chunk or chunk >= n)
+        and not torch.cuda.is_current_stream_capturing()):
+      ent = self._graphs.get(key)
+      if ent is None:
+        if len(self._graphs) >= 4:                 # a few shapes at most: the static buffers are large
+          self._graphs.pop(next(iter(self._graphs)))
+        ent = self._graphs[key] = {'seen': 0}
+      ent['seen'] += 1
+      if 'graph' not in ent and ent['seen'] >= 3:
+        ent['in'] = frames_nhwc.contiguous().clone()
+        ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+          self._run_groups(ent['in'], ent['low'], ent['hi'], [(0, n)], 1)
+        ent['graph'] = g
+      if 'graph' in ent:
+        ent['in'].copy_(frames_nhwc)
+        ent['graph'].replay()
+        low.copy_(ent['low'])
+        hi.copy_(ent['hi'])
+        return low, hi
     if chunk:
       bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
     else:
       per = -(-n // streams)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
+    self._run_groups(frames_nhwc, low, hi, bounds, streams)
+    return low, hi
+
+  def _run_groups(self, frames_nhwc, low, hi, bounds, streams):
     cur = torch.cuda.current_stream(self.device)
     while len(self._side_streams) < streams - 1:
       self._side_streams.append(torch.cuda.Stream(self.device))
@@ -304,7 +341,6 @@ class Backbone:
     finally:
       self._lane = 0
       torch.backends.cudnn.benchmark = saved
-    return low, hi
 
 
 def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int], antialias: bool = False) -> torch.Tensor:

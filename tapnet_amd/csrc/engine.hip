@@ -71,7 +71,6 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
-  std::map<void*, DevBuf> norm_ss_by_stream;   // [N, C, 2] scale / shift of the InstanceNorm being applied, per caller stream
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
   int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
@@ -909,8 +908,6 @@ void tapir_destroy(tapir_ctx* c) {
                     &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
-  for (auto& kv : c->norm_ss_by_stream)
-    if (kv.second.p) (void)hipFree(kv.second.p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
     for (auto& ev : c->prof_ev[k]) c->prof_free.push_back(ev);
   for (auto& ev : c->prof_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -1151,21 +1148,18 @@ int tapir_inorm_stats(tapir_ctx* c, const void* a, const void* b, void* sum_out,
 }
 
 int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float* gamma,
-                     const float* beta, void* y, void* y_sub, int N, int H, int W, int C, int slabs,
-                     int per_s, int out_h, int out_w, void* stream) {
+                     const float* beta, float* ss, void* y, void* y_sub, int N, int H, int W, int C,
+                     int slabs, int per_s, int out_h, int out_w, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!x || !part || !gamma || !beta || !y || N < 1 || H < 1 || W < 1 || slabs < 1 || per_s < 0 || out_h < H ||
+  if (!x || !part || !gamma || !beta || !ss || !y || N < 1 || H < 1 || W < 1 || slabs < 1 || per_s < 0 || out_h < H ||
       out_w < W || (y_sub && ((H | W) & 1)))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
-  // one scale / shift buffer per stream: groups of frames may be in flight on several streams
-  DevBuf* ssb = &c->norm_ss_by_stream[stream];
-  TRY(ensure(c, *ssb, (size_t)N * C * 2 * sizeof(float)));
-  NormFinalizeArgs nf{part, gamma, beta, (float*)ssb->p, H * W, C, slabs, per_s, 0};
+  NormFinalizeArgs nf{part, gamma, beta, ss, H * W, C, slabs, per_s, 0};
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   NormApplyArgs na{};
-  na.x = x; na.ss = (const float*)ssb->p; na.y = y; na.y_sub = y_sub;
+  na.x = x; na.ss = ss; na.y = y; na.y_sub = y_sub;
   na.H = H; na.W = W; na.C = C; na.oh = out_h; na.ow = out_w;
   na.pix_slabs = std::max(1, std::min(H * W / 64, (2048 + N - 1) / N));
   if (c->cfg.dtype == TAPIR_BF16)

@@ -52,7 +52,8 @@ def test_inorm_add_relu(dtype, C, H, W, slabs):
   oh, ow = (H + 1, W + 1) if pad else (H, W)
   y = _enc(np.zeros((N, oh, ow, C), np.float32), dtype)
   ys = _enc(np.zeros((N, H // 2, W // 2, C), np.float32), dtype) if pad else None
-  rc = lib.tapir_inorm_relu(ctx, _p(ea), _p(part), _p(gamma), _p(beta), _p(y), _p(ys), N, H, W, C,
+  ss = np.zeros((N, C, 2), np.float32)
+  rc = lib.tapir_inorm_relu(ctx, _p(ea), _p(part), _p(gamma), _p(beta), _p(ss), _p(y), _p(ys), N, H, W, C,
                             slabs, 0, oh, ow, None)
   assert rc == 0, lib.tapir_last_error(ctx)
   mean = x.mean((1, 2), keepdims=True, dtype=np.float64)

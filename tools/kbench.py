@@ -286,6 +286,7 @@ def bench_norm(model, reps, results):
     b = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
     y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
     gamma = torch.ones(c, device=dev); beta = torch.zeros(c, device=dev)
+    ss = torch.empty(n, c, 2, device=dev)
     nbytes = n * h * w * c * 2
     for slabs in (11, 22, 43, 64, 128):
       if slabs > h * w // 64:
@@ -297,7 +298,7 @@ def bench_norm(model, reps, results):
         assert lib.tapir_inorm_stats(ctx, x[i % 3].data_ptr(), b.data_ptr(), x[i % 3].data_ptr(), part.data_ptr(), n, h * w, c, slabs, stream) == 0
       def relu(i):
         assert lib.tapir_inorm_relu(ctx, x[i % 3].data_ptr(), part.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                    y.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
+                                    ss.data_ptr(), y.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
       for name, fn, passes in (('inorm_stats', stats, 1), ('inorm_stats_add', stats_add, 3), ('inorm_relu(+finalize)', relu, 2)):
         t = timeit(fn, reps)
         row = dict(kernel=name, shape=[n, h, w, c], slabs=slabs, **t,
@@ -519,7 +520,7 @@ def bench_conv(model, reps, results):
       conv_out[0] = F.conv2d(yn.permute(0, 3, 1, 2), wcl, None, padding=1)
     def replaced(i):
       assert lib.tapir_inorm_relu(ctx, x[i % 3].data_ptr(), part_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                  yn.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
+                                  ss.data_ptr(), yn.data_ptr(), None, n, h, w, c, slabs, 0, h, w, stream) == 0
       o = F.conv2d(yn.permute(0, 3, 1, 2), wcl, None, padding=1).permute(0, 2, 3, 1)
       assert lib.tapir_inorm_stats(ctx, o.data_ptr(), sc.data_ptr(), o.data_ptr(), part2.data_ptr(), n, h * w, c, slabs, stream) == 0
       conv_out[0] = o
