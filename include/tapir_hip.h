@@ -197,8 +197,8 @@ int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* laun
 
 /* Feature backbone, the memory-bound half (TAPIR.get_feature_grids, tapir_model.py:626-729; ResNet
  * blocks, tapnet/models/resnet.py:152-257).  The stem, the strided and the 1x1 convolutions stay on
- * PyTorch-ROCm / MIOpen (north_star); these three entry points are everything between them (the 3x3
- * stride-1 convolutions have their own fused entry point below).  Tensors are NHWC in the
+ * PyTorch-ROCm / MIOpen in f32 contexts (north_star); these three entry points are everything between
+ * them (bf16 contexts: the block convolutions have their own fused entry point below).  Tensors are NHWC in the
  * context's element type (f32, or bf16 bits for TAPIR_BF16); channel counts: C / (8 bf16 | 4 f32)
  * must be a power of two <= 256 (<= 64 for tapir_l2_normalize).
  *
@@ -208,7 +208,7 @@ int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* laun
  *   alias a or b).  part [N, slabs, C, 2] f32 receives one (mean, M2) summary per slab of pixels.
  * tapir_inorm_relu: y = relu((x - mean) / sqrt(var + 1e-5) * gamma + beta) (resnet.py:241-249) from
  *   those summaries (slabs of per_s pixels; per_s = 0: ceil(HW / slabs), what tapir_inorm_stats
- *   writes; the part_out of tapir_conv3x3_fused has per_s = rows * W); ss: N * C * 2 floats of scratch
+ *   writes; the part_out of tapir_conv_fused has per_s = rows * W); ss: N * C * 2 floats of scratch
  *   owned by the caller (the merged scale / shift pairs; the context keeps no buffer of its own, so
  *   calls on different streams do not share one).  y is [N, out_h, out_w, C] with out_h >= H, out_w >= W: rows / columns past
  *   H / W are not written (pass a zero-initialised buffer with out_h = H+1, out_w = W+1 to get the
@@ -223,26 +223,29 @@ int tapir_inorm_relu(tapir_ctx* ctx, const void* x, const float* part, const flo
                      int slabs, int per_s, int out_h, int out_w, void* stream);
 int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, int C, void* stream);
 
-/* The 3x3 / stride-1 / SAME convolutions of the ResNet blocks (C -> C channels, C in {64,128,256};
- * tapnet/models/resnet.py:185-257: self.conv_0 / self.conv_1 of BlockV2 and the InstanceNorm + relu in
- * front of each, :241-242 / :248-249, and the residual add :256), bf16 contexts only: one HIP
- * implicit-GEMM kernel per convolution with the normalisation of its INPUT folded into the operand
- * load and the residual add + the statistics of its OUTPUT (for the next norm) into the epilogue.
- * tapir_conv3x3_plan : rows per workgroup tile and tiles per image for an [H, W, C] map
+/* The convolutions of the ResNet blocks (tapnet/models/resnet.py:185-257: self.conv_0 / self.conv_1 /
+ * self.proj_conv of BlockV2 with the InstanceNorm + relu in front of them, :241-243 / :248-249, and the
+ * residual add :256), bf16 contexts only: one HIP implicit-GEMM kernel per convolution with the
+ * normalisation of its INPUT folded into the operand load and the residual add + the statistics of its
+ * OUTPUT (for the next norm) into the epilogue.  Supported: 3x3 stride 1 with C -> C channels,
+ * C in {64,128,256}; 1x1 stride 1 with 64 -> 64 / 256 -> 256; 3x3 and 1x1 stride 2 with 64 -> 128 /
+ * 128 -> 256; XLA "SAME" padding.  (The 7x7 stem stays on MIOpen.)
+ * tapir_conv_plan : output rows per workgroup tile and tiles per image for an [H, W, cin] INPUT map
  *   (TAPIR_ERR_UNSUPPORTED when the shape does not fit: keep that convolution on MIOpen).
- * tapir_conv3x3_pack : w = the reference's [C_out, C_in, 3, 3] f32 kernel (torch OIHW, host memory)
+ * tapir_conv_pack : w = the reference's [cout, cin, ks, ks] f32 kernel (torch OIHW, host memory)
  *   -> device-resident packed fragment streams (owned by the context).
- * tapir_conv3x3_fused: y [N,H,W,C] = conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut),
- *   rounded to bf16.  part_in [N, slabs_in, C, 2] are (mean, M2) summaries of x per slab of per_s_in
- *   pixels (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
- *   ss: N * C * 2 floats of scratch owned by the caller (the merged scale / shift); part_out, if not NULL,
- *   [N, tiles, C, 2] receives the summaries of y per tile (rows * W pixels each). */
-int tapir_conv3x3_plan(tapir_ctx* ctx, int H, int W, int C, int* rows, int* tiles);
-int tapir_conv3x3_pack(tapir_ctx* ctx, const float* w, int C, void** wstream);
-int tapir_conv3x3_fused(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
-                        const float* gamma, const float* beta, float* ss, const void* wstream,
-                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int C,
-                        void* stream);
+ * tapir_conv_fused: y [N, ceil(H/stride), ceil(W/stride), cout] =
+ *   conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut, 3x3 stride 1 only), rounded to bf16.
+ *   part_in [N, slabs_in, cin, 2] are (mean, M2) summaries of x per slab of per_s_in pixels
+ *   (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
+ *   ss: N * cin * 2 floats of scratch owned by the caller (the merged scale / shift); part_out, if not
+ *   NULL, [N, tiles, cout, 2] receives the summaries of y per tile (rows * W_out pixels each). */
+int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles);
+int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);
+int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                     const float* gamma, const float* beta, float* ss, const void* wstream,
+                     const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
+                     int cout, int ks, int stride, void* stream);
 
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):

@@ -84,11 +84,11 @@ PROTOTYPES = {
     'tapir_inorm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'tapir_l2_normalize': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
-    'tapir_conv3x3_plan': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
-    'tapir_conv3x3_pack': (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p)]),
-    'tapir_conv3x3_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_void_p]),
+    'tapir_conv_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tapir_conv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    'tapir_conv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),

@@ -13,11 +13,11 @@ state_dict names (tapnet/torch/nets.py).
 Runs channels-last (NHWC) so that the feature grids leave in the
 [B,T,h,w,C] layout the HIP kernels read, with no transpose.
 
-GPU only.  bf16 contexts: the 3x3 / stride-1 C -> C convolutions (13 of the 16 3x3 convolutions, 85 %
-of the flops) are the fused HIP kernel of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in
-its operand load, residual add and the next norm's statistics in its epilogue
-(tapir_conv3x3_fused); the 7x7 stem, the two stride-2 3x3 and the 1x1 projections run in PyTorch
-(MIOpen / CK implicit-GEMM, NHWC) with the HIP kernels of csrc/backbone.hpp between them
+GPU only.  bf16 contexts: the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2) are the
+fused HIP kernel of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in its operand load,
+residual add and the next norm's statistics in its epilogue (tapir_conv_fused); the 7x7 stem (and the
+ExtraConvs of BootsTAPIR) run in PyTorch (MIOpen / CK implicit-GEMM, NHWC); statistics of the stem
+output and the final L2 normalisation are the HIP kernels of csrc/backbone.hpp
 (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  f32 contexts: every convolution through
 MIOpen, the same glue kernels.  From the third call with one shape on, a clip's launches are replayed
 from a hipGraph.  There is no CPU path here; the plain PyTorch restatement used by the CPU tests and
@@ -67,16 +67,20 @@ class Backbone:
     # only around this backbone's own convolutions (features()) and restored afterwards.
     self.miopen_exhaustive_search = True
     # Frames are independent through the whole backbone, so a clip can be cut into `streams` groups of
-    # frames that run on separate HIP streams: the HBM-bound glue kernels of one group (norm
-    # statistics, normalise + ReLU, residual add) then overlap the MFMA-bound convolutions of the
-    # other instead of alternating with them.  1 = everything on the caller's stream.
-    self.streams = 1
+    # frames that run on separate HIP streams: the memory-bound phases of one group's kernels (tile
+    # staging, epilogues, the glue kernels) then overlap the MFMA-bound phases of the other's instead of
+    # alternating with them (1.67 -> 1.55 ms for a 48-frame clip, bit-identical: every kernel here is
+    # independent of how many frames a launch covers).  1 = everything on the caller's stream; applies
+    # to clips of at least 8 frames per stream.
+    self.streams = 2 if dtype == torch.bfloat16 else 1
     self._side_streams = []
     self._lane = 0
-    # 'auto': the 3x3 stride-1 C -> C convolutions (13 of the 16 3x3 convolutions, 85 % of the
-    # backbone's flops) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it
-    # (bf16 contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
+    # 'auto': the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2: everything but the 7x7
+    # stem) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it (bf16
+    # contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
     self.conv_mode = 'auto'
+    # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
+    self.hip_convs = {'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
     # clips of at least this many frames replay their launches from a hipGraph from the third call with
     # the same shape on (features()); 0 = always launch eagerly
     self.graph_min_frames = 8
@@ -102,14 +106,17 @@ class Backbone:
       import numpy as np
       lib, ctx = engine
       for k, v in weights.items():
-        if not (k.startswith('resnet_torch.block_groups.') and k.endswith(('conv_0.weight', 'conv_1.weight'))):
+        if not (k.startswith('resnet_torch.block_groups.') and
+                k.endswith(('conv_0.weight', 'conv_1.weight', 'proj_conv.weight'))):
           continue
         a = np.ascontiguousarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
-        if a.ndim == 4 and a.shape[0] == a.shape[1] and a.shape[2:] == (3, 3) and a.shape[0] in (64, 128, 256):
-          h = ctypes.c_void_p()
-          self._check(lib.tapir_conv3x3_pack(ctx, a.ctypes.data_as(ctypes.c_void_p), a.shape[0], ctypes.byref(h)),
-                      'tapir_conv3x3_pack')
-          self._wstream[k[:-len('.weight')]] = h.value
+        if a.ndim != 4 or a.shape[2] != a.shape[3]:
+          continue
+        h = ctypes.c_void_p()
+        rc = lib.tapir_conv_pack(ctx, a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.shape[2],
+                                 ctypes.byref(h))
+        if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
+          self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
     need = ['resnet_torch.initial_conv.weight']
     if extra_convs:
       need.append('extra_convs.blocks.0.conv.weight')
@@ -158,7 +165,9 @@ class Backbone:
     """InstanceNorm summaries of a (NHWC), or of a + b with the sum written over a."""
     lib, ctx = self.engine
     n, h, w, c = a.shape
-    slabs = max(1, min(h * w // 64, -(-1024 // n), 64))   # the finalize kernel walks them serially
+    # (independent of the number of frames: the summation order, and with it the result, must not
+    # depend on how a clip is cut into groups of frames or sharded over ranks)
+    slabs = max(1, min(h * w // 64, 32))   # the finalize kernel walks them serially
     part = self._buf(('part', n, slabs, c), (n, slabs, c, 2), torch.float32)
     self._check(lib.tapir_inorm_stats(ctx, a.data_ptr(), b.data_ptr() if b is not None else None,
                                       a.data_ptr() if b is not None else None, part.data_ptr(),
@@ -184,56 +193,67 @@ class Backbone:
                  padding=padding)
     return y.permute(0, 2, 3, 1).contiguous()   # no-op for a channels-last result
 
-  # -- the 3x3 / stride-1 C -> C convolutions: one HIP kernel each (csrc/conv_fused.hpp) ------------
-  def _plan(self, h, w, c):
+  # -- the block convolutions: one HIP kernel each (csrc/conv_fused.hpp) ------------------------------
+  def _plan(self, h, w, cin, cout, ks, stride):
     """(rows per tile, tiles per image) of the fused convolution, or None: that shape stays on MIOpen."""
-    key = (h, w, c)
+    key = (h, w, cin, cout, ks, stride)
     if key not in self._plans:
       import ctypes
       lib, ctx = self.engine
       rows, tiles = ctypes.c_int(), ctypes.c_int()
       ok = (self.dtype == torch.bfloat16 and
-            lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0)
+            lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0)
       self._plans[key] = (rows.value, tiles.value) if ok else None
     return self._plans[key]
 
-  def _fusable(self, conv_name, h, w, c):
-    return self.conv_mode != 'miopen' and conv_name in self._wstream and self._plan(h, w, c) is not None
+  def _fusable(self, conv_name, h, w, stride):
+    kind = conv_name.rsplit('.', 1)[-1] + ('_s2' if stride == 2 else '')
+    if self.conv_mode == 'miopen' or conv_name not in self._wstream or kind not in self.hip_convs:
+      return False
+    _, cin, cout, ks = self._wstream[conv_name]
+    return self._plan(h, w, cin, cout, ks, stride) is not None
 
-  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag):
+  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True):
     """conv(relu(instance_norm(x))) (+ shortcut) and the summaries of the result, one launch
     (+ the tiny merge of the input summaries)."""
     lib, ctx = self.engine
-    n, h, w, c = x.shape
-    rows, tiles = self._plan(h, w, c)
-    y = self._buf(('fy', tag, n, h, w, c), (n, h, w, c), self.dtype)
-    part = self._buf(('fpart', tag, n, tiles, c), (n, tiles, c, 2), torch.float32)
-    ss = self._buf(('ss', n, c), (n, c, 2), torch.float32)
+    n, h, w, _ = x.shape
+    ws, cin, cout, ks = self._wstream[conv_name]
+    rows, tiles = self._plan(h, w, cin, cout, ks, stride)
+    ho, wo = -(-h // stride), -(-w // stride)
+    y = self._buf(('fy', tag, n, ho, wo, cout), (n, ho, wo, cout), self.dtype)
+    part = self._buf(('fpart', tag, n, tiles, cout), (n, tiles, cout, 2), torch.float32) if stats else None
+    ss = self._buf(('ss', n, cin), (n, cin, 2), torch.float32)
     assert y.data_ptr() != x.data_ptr() and (shortcut is None or y.data_ptr() != shortcut.data_ptr())
-    self._check(lib.tapir_conv3x3_fused(
+    self._check(lib.tapir_conv_fused(
         ctx, x.data_ptr(), st.part.data_ptr(), st.slabs, st.per_s, self.w[norm_name + '.weight'].data_ptr(),
-        self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), self._wstream[conv_name],
-        shortcut.data_ptr() if shortcut is not None else None, y.data_ptr(), part.data_ptr(), n, h, w, c,
-        self._stream()), 'tapir_conv3x3_fused')
-    return y, _Stats(part, tiles, rows * w)
+        self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), ws,
+        shortcut.data_ptr() if shortcut is not None else None, y.data_ptr(),
+        part.data_ptr() if stats else None, n, h, w, cin, cout, ks, stride, self._stream()), 'tapir_conv_fused')
+    return y, (_Stats(part, tiles, rows * wo) if stats else None)
 
   def _hip_block(self, x, st: '_Stats', p, stride, use_projection, tag, parity):
-    """One BlockV2 (resnet.py:185-257).  x: the raw residual stream, st: its InstanceNorm summaries."""
-    strided = stride == 2
+    """One BlockV2 (resnet.py:185-257).  x: the raw residual stream, st: its InstanceNorm summaries.
+    Every convolution that has a HIP kernel for its shape reads x (or conv_0's raw output) directly;
+    the normalised tensor is only materialised for the ones that go through MIOpen."""
     n, h, w, cin = x.shape
-    cout = self.w[p + 'conv_0.weight'].shape[0]
-    f0 = not strided and cin == cout and self._fusable(p + 'conv_0', h, w, cout)
-    if use_projection or not f0:
+    f0 = self._fusable(p + 'conv_0', h, w, stride)
+    fp = use_projection and self._fusable(p + 'proj_conv', h, w, stride)
+    strided = stride == 2
+    if not f0 or (use_projection and not fp):
       y, ysub = self._hip_norm_relu(x, st, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
     shortcut = x
     if use_projection:
-      shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
+      if fp:
+        shortcut, _ = self._fused_conv(x, st, p + 'bn_0', p + 'proj_conv', None, tag + 'p', stride, stats=False)
+      else:
+        shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
     if f0:
-      y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c')
+      y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c', stride)
     else:
       y0 = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
       st0 = self._hip_stats(y0)
-    if self._fusable(p + 'conv_1', y0.shape[1], y0.shape[2], cout):
+    if self._fusable(p + 'conv_1', y0.shape[1], y0.shape[2], 1):
       # the result becomes the next block's residual stream: it may not alias this block's (the shortcut)
       return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}')
     y, _ = self._hip_norm_relu(y0, st0, p + 'bn_1', tag + 'b')
@@ -284,12 +304,12 @@ class Backbone:
     hi = torch.empty((n, half(half(H)), half(half(W)), c_hi), dtype=torch.float32, device=self.device)
     if n == 0:
       return low, hi
-    streams = max(1, min(int(self.streams), n))
+    streams = max(1, min(int(self.streams), n // 8))
     # hipGraph replay: a clip's backbone is ~60 launches of 10-100 us kernels, which one Python thread
     # cannot issue as fast as the GPU retires them (2.04 ms wall against 1.7 ms of kernels for 48 frames).
     # From the third call with the same shape on, the launches are replayed from a captured graph.
-    key = (n, H, W, self.conv_mode)
-    if (self.graph_min_frames and n >= self.graph_min_frames and streams == 1 and (not chunk or chunk >= n)
+    key = (n, H, W, self.conv_mode, tuple(sorted(self.hip_convs)), streams)
+    if (self.graph_min_frames and n >= self.graph_min_frames and (not chunk or chunk >= n)
         and not torch.cuda.is_current_stream_capturing()):
       ent = self._graphs.get(key)
       if ent is None:
@@ -302,8 +322,10 @@ class Backbone:
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-          self._run_groups(ent['in'], ent['low'], ent['hi'], [(0, n)], 1)
+        per = -(-n // streams)
+        with torch.cuda.graph(g):   # (the side streams fork from and join the capturing stream)
+          self._run_groups(ent['in'], ent['low'], ent['hi'], [(s0, min(s0 + per, n)) for s0 in range(0, n, per)],
+                           streams)
         ent['graph'] = g
       if 'graph' in ent:
         ent['in'].copy_(frames_nhwc)

@@ -1,6 +1,6 @@
-// 3x3 / stride 1 / SAME convolution of the feature backbone (tapnet/models/resnet.py:185-257: the
-// two convolutions of a ResNet-v2 block, C -> C channels) as ONE kernel with everything the block
-// does around it folded in:
+// The convolutions of the ResNet blocks of the feature backbone (tapnet/models/resnet.py:185-257:
+// conv_0 / conv_1 / proj_conv of BlockV2; 3x3 or 1x1, stride 1 or 2, XLA "SAME" padding) as ONE kernel
+// with everything the block does around a convolution folded in:
 //   operand load : relu(instance_norm(x)) (resnet.py:241-242, 248-249) -- the raw tensor is read,
 //                  normalised with the per-(image, channel) pair (a, b) of inorm_finalize_kernel,
 //                  rectified and rounded to bf16 on its way into LDS; the zero padding of the
@@ -13,54 +13,73 @@
 // Implicit GEMM on the matrix cores, the layout of the track-resident mixer (mixer_fused.hpp):
 //   A = weights: per-wave packed stream of 1-KiB fragments (16 output channels x 32 input channels of
 //       one tap), global -> register ring, never through LDS;
-//   B = pixels : the haloed input tile [(rows + 2) x (W + 2) pixels][C] bf16 in LDS, 16-byte chunks
-//       XOR-swizzled by the pixel index; the nine taps are nine constant offsets into it.
-// Workgroup = 4 or 8 waves = (C / 64) output-channel groups x pixel groups; a wave owns 64 output
+//   B = pixels : the input tile [in_rows x in_cols pixels][C_in] bf16 in LDS (halo / stride included),
+//       16-byte chunks XOR-swizzled by the pixel index; the taps are constant offsets into it.
+// Workgroup = 4 or 8 waves = (C_out / 64) output-channel groups x pixel groups; a wave owns 64 output
 // channels x NT * 16 pixels (4 x NT accumulator fragments); the tile of a workgroup is `rows` full
-// image rows (rows * W <= pixel groups * NT * 16).  bf16 build only.
+// rows of the OUTPUT image (rows * W_out <= pixel groups * NT * 16).  bf16 build only.
 #pragma once
 #include "backbone.hpp"
 #include "gemm.hpp"
 
 namespace tapir {
 
-constexpr int CV3_RING = 12;                 // A fragments in flight per wave (3 k-steps)
 constexpr int CV3_NT = 4;                    // pixel tiles (16 pixels) per wave
+// A fragments in flight per wave: 12 (3 k-steps) for the 3x3 kernels, 8 for the 1x1 (2, 4 or 8 k-steps in all)
+constexpr int cv3_ring(int ks) { return ks == 3 ? 12 : 8; }
 // Two workgroup sizes: 4 waves with a 72-KiB tile -- two workgroups per CU, so that the VALU- and
 // memory-bound phases of one (staging, epilogue) run under the matrix phase of the other -- and
 // 8 waves with a 144-KiB tile for the maps whose rows are too long for that.
 constexpr int cv3_lds_bytes(int waves) { return waves * 18 * 1024; }
 
 struct Conv3Args {
-  const bf16_t* x;        // [N, H, W, C] raw input of the norm
-  const float* ss;        // [N, C / 8, 2, 8] (a of 8 channels, b of 8 channels): operand = relu(a * x + b)
-  const uint4* wstream;   // [C / 64][frags_per_cg][64 lanes] packed A fragments (conv3_pack_weights)
+  const bf16_t* x;        // [N, H, W, C_in] raw input of the norm
+  const float* ss;        // [N, C_in / 8, 2, 8] (a of 8 channels, b of 8 channels): operand = relu(a * x + b)
+  const uint4* wstream;   // [C_out / 64][frags_per_cg][64 lanes] packed A fragments (tapir_conv_pack)
   long frags_per_cg;
-  const bf16_t* shortcut; // null, or [N, H, W, C] added before rounding
-  bf16_t* y;              // [N, H, W, C]
-  float* part;            // null, or [N, tiles, C, 2]: (mean, M2) of the stored values of each tile
-  int N, H, W;
-  int TH, tiles;          // rows per tile, tiles per image = ceil(H / TH)
+  const bf16_t* shortcut; // null, or [N, Ho, Wo, C_out] added before rounding
+  bf16_t* y;              // [N, Ho, Wo, C_out]
+  float* part;            // null, or [N, tiles, C_out, 2]: (mean, M2) of the stored values of each tile
+  int N, H, W;            // input image
+  int Ho, Wo;             // output image = ceil(H / stride), ceil(W / stride)
+  int pad_y, pad_x;       // SAME padding on the low side
+  int TH, tiles;          // output rows per tile, tiles per image = ceil(Ho / TH)
   int waves;              // 4 or 8 (conv3_plan)
   long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
 };
 
-inline long conv3_frags_per_cg(int C) { return 9L * (C / 32) * 4 + CV3_RING; }
+inline long conv3_frags_per_cg(int cin, int ks) { return (long)ks * ks * (cin / 32) * 4 + cv3_ring(ks); }
 
-// rows per tile / tiles per image / waves per workgroup for an [H, W, C] map; false if the shape does
-// not fit the kernel
-inline bool conv3_plan(int H, int W, int C, int* rows, int* tiles, int* waves = nullptr) {
-  if (C != 64 && C != 128 && C != 256) return false;
-  if (H < 1 || W < 1) return false;
+// XLA SAME: total = max((ceil(n / s) - 1) * s + k - n, 0), low = total / 2
+inline int conv3_pad_lo(int n, int k, int s) {
+  const int total = ((n + s - 1) / s - 1) * s + k - n;
+  return total > 0 ? total / 2 : 0;
+}
+
+inline bool conv3_supported(int cin, int cout, int ks, int stride) {
+  const bool c_ok = (cin == 64 || cin == 128 || cin == 256) && (cout == 64 || cout == 128 || cout == 256);
+  if (!c_ok || (ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return false;
+  if (stride == 1) return cin == cout && (ks == 3 || cin != 128);   // conv_0 / conv_1 / proj_conv of a stride-1 block
+  return cout == 2 * cin;                                    // conv_0 / proj_conv of the first block of a stride-2 group
+}
+
+// output rows per tile / tiles per image / waves per workgroup for an [H, W, C_in] input; false if the
+// shape does not fit the kernel
+inline bool conv3_plan(int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles,
+                       int* waves = nullptr) {
+  if (!conv3_supported(cin, cout, ks, stride) || H < 1 || W < 1) return false;
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const long in_cols = (long)stride * (Wo - 1) + ks;
   for (int wv = 4; wv <= 8; wv += 4) {
-    const int px = (wv * 64 / C) * CV3_NT * 16;    // pixels per workgroup
-    int th = px / W;
-    if (th > H) th = H;
-    while (th >= 1 && (long)(th + 2) * (W + 2) * C * 2 > cv3_lds_bytes(wv)) --th;
-    // (a one-row tile reads three rows per row of output: take the larger workgroup if it does better)
-    if (th < 1 || (th < 2 && wv == 4 && H > 1)) continue;
+    if (wv * 64 < cout) continue;                              // a wave owns 64 output channels
+    const int px = (wv * 64 / cout) * CV3_NT * 16;             // pixels per workgroup
+    int th = px / Wo;
+    if (th > Ho) th = Ho;
+    while (th >= 1 && ((long)stride * (th - 1) + ks) * in_cols * cin * 2 > cv3_lds_bytes(wv)) --th;
+    // (a one-row 3x3 tile reads three rows per row of output: take the larger workgroup if it does better)
+    if (th < 1 || (th < 2 && wv == 4 && Ho > 1 && ks == 3)) continue;
     *rows = th;
-    *tiles = (H + th - 1) / th;
+    *tiles = (Ho + th - 1) / th;
     if (waves) *waves = wv;
     return true;
   }
@@ -75,18 +94,19 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int C, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
-__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args a) {
+template <int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) {
   constexpr int THREADS = WAVES * 64;
-  constexpr int CG = C / 64, PG = WAVES / CG;
+  constexpr int CG = COUT / 64, PG = WAVES / CG;
   static_assert(PG >= 1, "a wave owns 64 output channels");
-  constexpr int CB = C * 2;                        // bytes per pixel
-  constexpr int CPP = C / 8;                       // 16-byte chunks per pixel
+  constexpr int CB = CIN * 2;                      // bytes per input pixel
+  constexpr int CPP = CIN / 8;                     // 16-byte chunks per input pixel
   constexpr int SWZ = (CPP < 16 ? CPP : 16) - 1;
-  constexpr int KPT = C / 32;                      // k-steps per tap
-  constexpr int RING = CV3_RING, G = RING / 4;   // k-steps per ring turn
-  constexpr int UNR = 2 * G;                     // k-steps per loop trip (even: the B buffers alternate)
-  static_assert((9 * KPT) % UNR == 0, "whole loop trips");
+  constexpr int TAPS = KS * KS;
+  constexpr int KPT = CIN / 32;                    // k-steps per tap
+  constexpr int RING = cv3_ring(KS), G = RING / 4; // k-steps per ring turn
+  constexpr int UNR = KS == 3 ? 2 * G : G;         // k-steps per loop trip (even: the B buffers alternate)
+  static_assert(UNR % 2 == 0 && UNR % G == 0 && (TAPS * KPT) % UNR == 0, "whole loop trips");
   __shared__ uint4 s_tile[cv3_lds_bytes(WAVES) / 16];
 
   const int tid = threadIdx.x;
@@ -102,11 +122,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
   const int bid = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
   if (bid >= total) return;
   const int n = bid / a.tiles, t = bid - n * a.tiles;
-  const int H = a.H, W = a.W, PW = W + 2;
-  const int r0 = t * a.TH;
-  const int rows = min(a.TH, H - r0);
-  const int HP = (rows + 2) * PW;                  // haloed pixels
-  const int TP = rows * W;                         // output pixels of this tile
+  const int H = a.H, W = a.W, Wo = a.Wo;
+  const int PW = STRIDE * (Wo - 1) + KS;           // columns of the input tile
+  const int r0 = t * a.TH;                         // first output row
+  const int rows = min(a.TH, a.Ho - r0);
+  const int HP = (STRIDE * (rows - 1) + KS) * PW;  // pixels of the input tile
+  const int TP = rows * Wo;                        // output pixels of this tile
+  const int y0 = STRIDE * r0 - a.pad_y, x0 = -a.pad_x;   // input coordinates of tile pixel (0, 0)
   char* const tile = reinterpret_cast<char*>(s_tile);
 
   // TRACE (tools/kbench.py --what convtrace): shader cycles per phase, per wave
@@ -129,18 +151,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
 #pragma unroll
   for (int s = 0; s < RING; ++s) { ring[s] = *wp; wp += 64; }
 
-  // ---- this lane's pixel of each of the wave's pixel tiles: haloed index of the centre tap
+  // ---- this lane's output pixel of each of the wave's pixel tiles: its first tap in the input tile
   int Pc[NT], qpix[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int q = (pg * NT + i) * 16 + c;
     qpix[i] = q;
     const int qq = q < TP ? q : 0;
-    const int yy = qq / W, xx = qq - yy * W;
-    Pc[i] = (yy + 1) * PW + xx + 1;
+    const int yy = qq / Wo, xx = qq - yy * Wo;
+    Pc[i] = STRIDE * (yy * PW + xx);               // tile pixel of tap (0, 0)
   }
   // the accumulators start from the shortcut (resnet.py:256): its loads complete under the staging
-  const long img = ((long)n * H + r0) * W;         // first pixel of the tile
+  const long img = ((long)n * a.Ho + r0) * Wo;     // first output pixel of the tile
   // (lane g of a pixel column holds the 16 CONSECUTIVE channels cg * 64 + 16 g + 4 r + e of its pixel:
   // the host packing permutes the rows of the A fragments accordingly, see tapir_conv3x3_pack)
   f32x4 acc[4][NT];
@@ -158,13 +180,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
     for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (HAS_SC) {
       const int qq = qpix[i] < TP ? qpix[i] : 0;
-      const f32x4* sp = reinterpret_cast<const f32x4*>(a.shortcut + (img + qq) * C + cg * 64 + 16 * g);
+      const f32x4* sp = reinterpret_cast<const f32x4*>(a.shortcut + (img + qq) * COUT + cg * 64 + 16 * g);
       acc[0][i] = sp[0];
       acc[1][i] = sp[1];
     }
   }
 
-  // ---- stage relu(a x + b) of the haloed tile; a thread keeps one channel chunk (8 channels).
+  // ---- stage relu(a x + b) of the input tile; a thread keeps one channel chunk (8 channels).
   // (A row-by-row walk with loop-invariant column math has half the VALU instructions and was 15 %
   // SLOWER on the GPU: the phase is bound by the memory system)
   {
@@ -173,12 +195,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
     const int chunk = tid % CPP, pl = tid / CPP;
     f32x4 ssv[4];                                  // a[0..3], a[4..7], b[0..3], b[4..7] of this chunk
     {
-      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * C + 8 * chunk) * 2);
+      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * CIN + 8 * chunk) * 2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) ssv[k] = sp[k];
     }
-    const bf16_t* xin = a.x + (long)n * H * W * C + 8 * chunk;
-    // haloed pixel P = hy * PW + hx walks in steps of PPS without a division per element
+    const bf16_t* xin = a.x + (long)n * H * W * CIN + 8 * chunk;
+    // tile pixel P = hy * PW + hx walks in steps of PPS without a division per element
     const int dq = PPS / PW, dr = PPS - dq * PW;
     int hy = pl / PW, hx = pl - hy * PW;
     for (int P0 = pl; P0 < HP; P0 += U * PPS) {
@@ -187,10 +209,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int P = P0 + u * PPS;
-        const int y = r0 + hy - 1, x = hx - 1;
+        const int y = y0 + hy, x = x0 + hx;
         const bool in = P < HP && y >= 0 && y < H && x >= 0 && x < W;
         const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-        v[u] = *reinterpret_cast<const uint4*>(xin + (yc * W + xc) * C);
+        v[u] = *reinterpret_cast<const uint4*>(xin + (yc * W + xc) * CIN);
         off[u] = P < HP ? ((P * CB + ((chunk ^ (P & SWZ)) << 4)) | (in ? 0 : (1 << 30))) : -1;
         hx += dr; hy += dq;
         if (hx >= PW) { hx -= PW; ++hy; }
@@ -227,10 +249,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
   lds_barrier();
   tick(1);
 
-  // ---- 9 taps x KPT k-steps; B fragments one k-step ahead, A fragments refilled after their last MFMA
+  // ---- TAPS x KPT k-steps; B fragments one k-step ahead, A fragments refilled after their last MFMA
   auto read_b = [&](int tap, int ks, uint4 (&fb)[NT]) {
     const int dy = (tap * 11) >> 5;                // tap / 3 for tap < 9
-    const int toff = (dy - 1) * PW + (tap - 3 * dy - 1);
+    const int toff = KS == 3 ? dy * PW + (tap - 3 * dy) : 0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int P = Pc[i] + toff;
@@ -241,12 +263,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
     uint4 fb0[NT], fb1[NT];
     read_b(0, 0, fb0);
     int tap = 0, ks = 0;
-    for (int grp = 0; grp < 9 * KPT / UNR; ++grp) {
+    for (int grp = 0; grp < TAPS * KPT / UNR; ++grp) {
 #pragma unroll
       for (int kk = 0; kk < UNR; ++kk) {
         int ks1 = ks + 1, tap1 = tap;
         if (ks1 == KPT) { ks1 = 0; tap1 = tap + 1; }
-        if (tap1 == 9) tap1 = 0;                   // past the end: any valid address (not used)
+        if (tap1 == TAPS) tap1 = 0;                // past the end: any valid address (not used)
         uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
         uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
         read_b(tap1, ks1, nxt);
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
       pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
     }
     if (qpix[i] < TP) {
-      uint4* yp = reinterpret_cast<uint4*>(a.y + (img + qpix[i]) * C + cg * 64 + 16 * g);
+      uint4* yp = reinterpret_cast<uint4*>(a.y + (img + qpix[i]) * COUT + cg * 64 + 16 * g);
       yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
       yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
     }
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
   tick(4);
   if (a.part) {
     lds_barrier();
-    if (tid < C) {
+    if (tid < COUT) {
       const int cgi = tid / 64, ch = tid % 64;
       float cn = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
         const float2 sv = s_stat[p * CG + cgi][ch];
         merge_stats(cn, mean, m2, nb, sv.x, sv.y);
       }
-      *reinterpret_cast<float2*>(a.part + (((long)n * a.tiles + t) * C + tid) * 2) = make_float2(mean, m2);
+      *reinterpret_cast<float2*>(a.part + (((long)n * a.tiles + t) * COUT + tid) * 2) = make_float2(mean, m2);
     }
   }
   if (TRACE && a.dbg_times != nullptr && lane == 0) {
@@ -350,19 +372,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_fused_kernel(Conv3Args 
   }
 }
 
-inline void launch_conv3x3_fused(const Conv3Args& a, int C, hipStream_t s) {
+inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int stride, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block((unsigned)(a.waves * 64));
-#define TAPIR_CV3(C_, W_)                                                                                         \
-  do {                                                                                                            \
-    if (trace) {                                                                                                  \
-      if (a.shortcut) hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, true, kTrace>), grid, block, 0, s, a);  \
-      else hipLaunchKernelGGL((conv3x3_fused_kernel<C_, CV3_NT, W_, false, kTrace>), grid, block, 0, s, a);            \
-    } else if (a.shortcut) {                                                                                      \
-      TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_, true>), grid, block, s, a);                               \
-    } else {                                                                                                      \
-      TAPIR_LAUNCH((conv3x3_fused_kernel<C_, CV3_NT, W_, false>), grid, block, s, a);                              \
-    }                                                                                                             \
-  } while (0)
 #ifdef TAPIR_EXPERIMENTS
   constexpr bool kTrace = true;                    // phase trace (tools/kbench.py --what convtrace)
   const bool trace = a.dbg_times != nullptr;
@@ -370,16 +381,43 @@ inline void launch_conv3x3_fused(const Conv3Args& a, int C, hipStream_t s) {
   constexpr bool kTrace = false;
   const bool trace = false;
 #endif
-  if (a.waves == 4) {
-    if (C == 64) TAPIR_CV3(64, 4);
-    else if (C == 128) TAPIR_CV3(128, 4);
-    else TAPIR_CV3(256, 4);
+#define TAPIR_CV3_SC(CI_, CO_, K_, S_, W_, SC_)                                                                       \
+  do {                                                                                                               \
+    if (trace) hipLaunchKernelGGL((conv_fused_kernel<CI_, CO_, K_, S_, CV3_NT, W_, SC_, kTrace>), grid, block, 0, s, a); \
+    else TAPIR_LAUNCH((conv_fused_kernel<CI_, CO_, K_, S_, CV3_NT, W_, SC_>), grid, block, s, a);                      \
+  } while (0)
+  // the shortcut is only ever added by conv_1 (3x3, stride 1, C -> C)
+#define TAPIR_CV3(CI_, CO_, K_, S_)                                                    \
+  do {                                                                                 \
+    if (CO_ <= 256 && a.waves == 4) {                                                  \
+      if ((K_) == 3 && (S_) == 1 && a.shortcut) TAPIR_CV3_SC(CI_, CO_, K_, S_, 4, (K_ == 3 && S_ == 1)); \
+      else TAPIR_CV3_SC(CI_, CO_, K_, S_, 4, false);                                   \
+    } else {                                                                           \
+      if ((K_) == 3 && (S_) == 1 && a.shortcut) TAPIR_CV3_SC(CI_, CO_, K_, S_, 8, (K_ == 3 && S_ == 1)); \
+      else TAPIR_CV3_SC(CI_, CO_, K_, S_, 8, false);                                   \
+    }                                                                                  \
+  } while (0)
+  if (stride == 1) {
+    if (ks == 3) {
+      if (cin == 64) TAPIR_CV3(64, 64, 3, 1);
+      else if (cin == 128) TAPIR_CV3(128, 128, 3, 1);
+      else TAPIR_CV3(256, 256, 3, 1);
+    } else {
+      if (cin == 64) TAPIR_CV3(64, 64, 1, 1);
+      else TAPIR_CV3(256, 256, 1, 1);
+    }
   } else {
-    if (C == 64) TAPIR_CV3(64, 8);
-    else if (C == 128) TAPIR_CV3(128, 8);
-    else TAPIR_CV3(256, 8);
+    if (ks == 3) {
+      if (cin == 64) TAPIR_CV3(64, 128, 3, 2);
+      else TAPIR_CV3(128, 256, 3, 2);
+    } else {
+      if (cin == 64) TAPIR_CV3(64, 128, 1, 2);
+      else TAPIR_CV3(128, 256, 1, 2);
+    }
   }
 #undef TAPIR_CV3
+#undef TAPIR_CV3_SC
+  (void)cout;
 }
 
 }  // namespace tapir

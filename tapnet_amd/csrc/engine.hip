@@ -1157,7 +1157,7 @@ int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (!norm_channels_ok(c, C, NORM_THREADS)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
   NormFinalizeArgs nf{part, gamma, beta, ss, H * W, C, slabs, per_s, 0};
-  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   NormApplyArgs na{};
   na.x = x; na.ss = ss; na.y = y; na.y_sub = y_sub;
   na.H = H; na.W = W; na.C = C; na.oh = out_h; na.ow = out_w;
@@ -1185,35 +1185,37 @@ int tapir_l2_normalize(tapir_ctx* c, const void* x, float* out, long pixels, int
   return TAPIR_OK;
 }
 
-// ---- backbone convolutions (conv_fused.hpp): resnet.py:185-257, the 3x3 / stride-1 C -> C convolutions
-int tapir_conv3x3_plan(tapir_ctx* c, int H, int W, int C, int* rows, int* tiles) {
+// ---- backbone convolutions (conv_fused.hpp): resnet.py:185-257, conv_0 / conv_1 / proj_conv of BlockV2
+int tapir_conv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles) {
   if (!c || !rows || !tiles) return TAPIR_ERR_INVALID;
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
-  if (!conv3_plan(H, W, C, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: shape");
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
+  if (!conv3_plan(H, W, cin, cout, ks, stride, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
   return TAPIR_OK;
 }
 
-int tapir_conv3x3_pack(tapir_ctx* c, const float* w, int C, void** wstream) {
+int tapir_conv_pack(tapir_ctx* c, const float* w, int cout, int cin, int ks, void** wstream) {
   if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
-  if (C != 64 && C != 128 && C != 256) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: channel count");
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
+  if (!conv3_supported(cin, cout, ks, 1) && !conv3_supported(cin, cout, ks, 2))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: channel counts / kernel size");
   // stream of channel group cg: for tap, k-step, row tile r: fragment row m = l & 15 holds output channel
   // cg*64 + 16 (m >> 2) + 4 r + (m & 3) -- so that lane group g = m >> 2 of the accumulator layout
   // (rows 4 g + e of tile r) owns the 16 consecutive channels 16 g + 4 r + e of its pixel --
   // input channels 32 ks + 8 (l >> 4) + j
-  const long fpc = conv3_frags_per_cg(C);
-  std::vector<uint8_t> host((size_t)(C / 64) * fpc * 1024, 0);
-  for (int cg = 0; cg < C / 64; ++cg) {
+  const long fpc = conv3_frags_per_cg(cin, ks);
+  const int taps = ks * ks;
+  std::vector<uint8_t> host((size_t)(cout / 64) * fpc * 1024, 0);
+  for (int cg = 0; cg < cout / 64; ++cg) {
     uint16_t* q = (uint16_t*)(host.data() + (size_t)cg * fpc * 1024);
-    for (int tap = 0; tap < 9; ++tap)
-      for (int ks = 0; ks < C / 32; ++ks)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int kstep = 0; kstep < cin / 32; ++kstep)
         for (int r = 0; r < 4; ++r, q += 512)
           for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
               const int m = l & 15;
-              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = 32 * ks + 8 * (l >> 4) + j;
-              q[l * 8 + j] = host_f2bf(w[((size_t)co * C + ci) * 9 + tap]);
+              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = 32 * kstep + 8 * (l >> 4) + j;
+              q[l * 8 + j] = host_f2bf(w[((size_t)co * cin + ci) * taps + tap]);
             }
   }
   void* d = nullptr;
@@ -1224,25 +1226,29 @@ int tapir_conv3x3_pack(tapir_ctx* c, const float* w, int C, void** wstream) {
   return TAPIR_OK;
 }
 
-int tapir_conv3x3_fused(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
-                        const float* gamma, const float* beta, float* ss, const void* wstream,
-                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int C,
-                        void* stream) {
+int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                     const float* gamma, const float* beta, float* ss, const void* wstream,
+                     const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
+                     int cout, int ks, int stride, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: bf16 build only");
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
   if (!x || !part_in || !gamma || !beta || !ss || !wstream || !y || N < 1 || slabs_in < 1 || per_s_in < 0)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (shortcut && !(ks == 3 && stride == 1)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shortcut on a 3x3 stride-1 convolution only");
   int rows = 0, tiles = 0, waves = 0;
-  if (!conv3_plan(H, W, C, &rows, &tiles, &waves)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv3x3_fused: shape");
-  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, C, slabs_in, per_s_in, 1};
-  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
+  if (!conv3_plan(H, W, cin, cout, ks, stride, &rows, &tiles, &waves))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
+  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, 1};
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   Conv3Args ca{};
-  ca.x = (const bf16_t*)x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(C);
+  ca.x = (const bf16_t*)x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(cin, ks);
   ca.shortcut = (const bf16_t*)shortcut; ca.y = (bf16_t*)y; ca.part = part_out;
-  ca.N = N; ca.H = H; ca.W = W; ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
+  ca.N = N; ca.H = H; ca.W = W; ca.Ho = (H + stride - 1) / stride; ca.Wo = (W + stride - 1) / stride;
+  ca.pad_y = conv3_pad_lo(H, ks, stride); ca.pad_x = conv3_pad_lo(W, ks, stride);
+  ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
   ca.dbg_times = (long long*)c->dbg_times;
-  launch_conv3x3_fused(ca, C, (hipStream_t)stream);
+  launch_conv_fused(ca, cin, cout, ks, stride, (hipStream_t)stream);
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }

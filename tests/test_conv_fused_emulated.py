@@ -26,26 +26,33 @@ def _r(x):
   return from_bf16_bits(to_bf16_bits(np.asarray(x, np.float32)))
 
 
-def _conv3x3_ref(xn, w):
-  """xn [N,H,W,C] (already normalised), w [Co,Ci,3,3]; zero SAME padding; float64 accumulation."""
+def _conv_ref(xn, w, stride=1):
+  """xn [N,H,W,Ci] (already normalised), w [Co,Ci,k,k]; XLA SAME zero padding; float64 accumulation."""
   N, H, W, C = xn.shape
-  xp = np.zeros((N, H + 2, W + 2, C), np.float64)
-  xp[:, 1:-1, 1:-1] = xn
-  out = np.zeros((N, H, W, w.shape[0]), np.float64)
-  for ky in range(3):
-    for kx in range(3):
-      out += xp[:, ky:ky + H, kx:kx + W] @ w[:, :, ky, kx].astype(np.float64).T
+  k = w.shape[2]
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  ty, tx = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+  xp = np.zeros((N, H + ty, W + tx, C), np.float64)
+  xp[:, ty // 2:ty // 2 + H, tx // 2:tx // 2 + W] = xn
+  out = np.zeros((N, Ho, Wo, w.shape[0]), np.float64)
+  for ky in range(k):
+    for kx in range(k):
+      out += xp[:, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride] @ \
+          w[:, :, ky, kx].astype(np.float64).T
   return out
 
 
-def run_conv(lib, ctx, x_bits, part_in, slabs_in, per_s_in, gamma, beta, wstream, shortcut_bits, N, H, W, C):
+def run_conv(lib, ctx, x_bits, part_in, slabs_in, per_s_in, gamma, beta, wstream, shortcut_bits, N, H, W, C,
+             cout=None, ks=3, stride=1):
+  cout = cout or C
   rows, tiles = ctypes.c_int(), ctypes.c_int()
-  assert lib.tapir_conv3x3_plan(ctx, H, W, C, ctypes.byref(rows), ctypes.byref(tiles)) == 0
-  y = np.zeros((N, H, W, C), np.uint16)
-  part = np.zeros((N, tiles.value, C, 2), np.float32)
+  assert lib.tapir_conv_plan(ctx, H, W, C, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  y = np.zeros((N, Ho, Wo, cout), np.uint16)
+  part = np.zeros((N, tiles.value, cout, 2), np.float32)
   ss = np.zeros((N, C, 2), np.float32)
-  rc = lib.tapir_conv3x3_fused(ctx, _p(x_bits), _p(part_in), slabs_in, per_s_in, _p(gamma), _p(beta), _p(ss),
-                               wstream, _p(shortcut_bits), _p(y), _p(part), N, H, W, C, None)
+  rc = lib.tapir_conv_fused(ctx, _p(x_bits), _p(part_in), slabs_in, per_s_in, _p(gamma), _p(beta), _p(ss),
+                            wstream, _p(shortcut_bits), _p(y), _p(part), N, H, W, C, cout, ks, stride, None)
   assert rc == 0, lib.tapir_last_error(ctx)
   return y, part, rows.value, tiles.value
 
@@ -69,7 +76,7 @@ def test_conv3x3_fused(C, H, W, shortcut):
   part_in = np.zeros((N, slabs, C, 2), np.float32)
   assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, C, slabs, None) == 0
   ws = ctypes.c_void_p()
-  assert lib.tapir_conv3x3_pack(ctx, _p(np.ascontiguousarray(w)), C, ctypes.byref(ws)) == 0
+  assert lib.tapir_conv_pack(ctx, _p(np.ascontiguousarray(w)), C, C, 3, ctypes.byref(ws)) == 0
   y, part, rows, tiles = run_conv(lib, ctx, xb, part_in, slabs, 0, gamma, beta, ws,
                                   to_bf16_bits(sc) if shortcut else None, N, H, W, C)
   # reference on the same rounded operands
@@ -79,7 +86,7 @@ def test_conv3x3_fused(C, H, W, shortcut):
   a = (rstd * gamma).astype(np.float32)
   b = (beta - mean * rstd * gamma).astype(np.float32)
   xn = _r(np.maximum(x * a + b, 0))
-  ref = _conv3x3_ref(xn, _r(w))
+  ref = _conv_ref(xn, _r(w))
   if shortcut:
     ref = ref + sc
   got = from_bf16_bits(y)
@@ -112,8 +119,8 @@ def test_conv3x3_chain_uses_part_out():
   part_in = np.zeros((N, 1, C, 2), np.float32)
   assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, C, 1, None) == 0
   ws0, ws1 = ctypes.c_void_p(), ctypes.c_void_p()
-  assert lib.tapir_conv3x3_pack(ctx, _p(w0), C, ctypes.byref(ws0)) == 0
-  assert lib.tapir_conv3x3_pack(ctx, _p(w1), C, ctypes.byref(ws1)) == 0
+  assert lib.tapir_conv_pack(ctx, _p(w0), C, C, 3, ctypes.byref(ws0)) == 0
+  assert lib.tapir_conv_pack(ctx, _p(w1), C, C, 3, ctypes.byref(ws1)) == 0
   y0, part0, rows, tiles = run_conv(lib, ctx, xb, part_in, 1, 0, g, z, ws0, None, N, H, W, C)
   y1, _, _, _ = run_conv(lib, ctx, y0, part0, tiles, rows * W, g, z, ws1, xb, N, H, W, C)
   # the same second convolution with summaries recomputed by the stand-alone statistics kernel
@@ -125,17 +132,63 @@ def test_conv3x3_chain_uses_part_out():
   lib.tapir_destroy(ctx)
 
 
-def test_conv3x3_rejects_f32_and_bad_shapes():
+@pytest.mark.parametrize('cin,cout,ks,stride,H,W', [
+    (64, 128, 3, 2, 8, 16), (64, 128, 3, 2, 7, 10), (128, 256, 3, 2, 6, 8), (64, 128, 1, 2, 8, 12),
+    (128, 256, 1, 2, 5, 6), (64, 64, 1, 1, 6, 20), (256, 256, 1, 1, 5, 8),
+    (64, 128, 3, 2, 4, 140)])      # rows too long for the 4-wave tile
+def test_strided_and_projection_convs(cin, cout, ks, stride, H, W):
+  """conv_0 / proj_conv of the first block of a group (resnet.py:243-247): 3x3 and 1x1, stride 1 and 2,
+  XLA SAME padding (one row / column on the HIGH side for even sizes at stride 2, one on each side for
+  odd sizes)."""
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  rng = np.random.default_rng(cin + cout + ks + H + W)
+  N = 2
+  x = _r(rng.standard_normal((N, H, W, cin)) * 1.5 + 0.5)
+  w = (rng.standard_normal((cout, cin, ks, ks)) / np.sqrt(ks * ks * cin)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+  beta = (rng.standard_normal(cin) * 0.3).astype(np.float32)
+  xb = to_bf16_bits(x)
+  part_in = np.zeros((N, 2, cin, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, cin, 2, None) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, _p(np.ascontiguousarray(w)), cout, cin, ks, ctypes.byref(ws)) == 0
+  y, part, rows, tiles = run_conv(lib, ctx, xb, part_in, 2, 0, gamma, beta, ws, None, N, H, W, cin, cout, ks, stride)
+  mean = x.mean((1, 2), keepdims=True, dtype=np.float64)
+  var = x.astype(np.float64).var((1, 2), keepdims=True)
+  rstd = 1.0 / np.sqrt(var + 1e-5)
+  xn = _r(np.maximum(x * (rstd * gamma).astype(np.float32) + (beta - mean * rstd * gamma).astype(np.float32), 0))
+  ref = _conv_ref(xn, _r(w), stride)
+  got = from_bf16_bits(y)
+  assert got.shape == ref.shape
+  np.testing.assert_allclose(got, ref, atol=2e-2, rtol=1e-2)
+  assert np.abs(got - ref).mean() < 2e-3
+  Ho, Wo = got.shape[1:3]
+  cnt = np.array([min(rows, Ho - t * rows) * Wo for t in range(tiles)], np.float64)
+  pm, pM2 = part[..., 0].astype(np.float64), part[..., 1].astype(np.float64)
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  np.testing.assert_allclose(tot_mean, got.mean((1, 2), dtype=np.float64), atol=1e-5)
+  np.testing.assert_allclose(tot_M2 / (Ho * Wo), got.astype(np.float64).var((1, 2)), rtol=1e-4, atol=1e-6)
+  lib.tapir_destroy(ctx)
+
+
+def test_conv_rejects_f32_and_bad_shapes():
   lib = emu_lib()
   ctx = _ctx(lib, _ffi.TAPIR_F32)
   rows, tiles = ctypes.c_int(), ctypes.c_int()
-  assert lib.tapir_conv3x3_plan(ctx, 8, 8, 64, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  plan = lambda c_, h, w, ci, co, k, s: lib.tapir_conv_plan(c_, h, w, ci, co, k, s, ctypes.byref(rows), ctypes.byref(tiles))
+  assert plan(ctx, 8, 8, 64, 64, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
   lib.tapir_destroy(ctx)
   ctx = _ctx(lib)
-  assert lib.tapir_conv3x3_plan(ctx, 8, 8, 96, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
-  assert lib.tapir_conv3x3_plan(ctx, 8, 2000, 256, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED
-  assert lib.tapir_conv3x3_plan(ctx, 128, 128, 64, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert plan(ctx, 8, 8, 96, 96, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert plan(ctx, 8, 8, 64, 256, 3, 2) == _ffi.TAPIR_ERR_UNSUPPORTED      # not a ResNet block shape
+  assert plan(ctx, 8, 8, 64, 64, 5, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert plan(ctx, 8, 2000, 256, 256, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert plan(ctx, 128, 128, 64, 64, 3, 1) == 0
   assert (rows.value, tiles.value) == (2, 64)      # 4-wave workgroups: 256 pixels
-  assert lib.tapir_conv3x3_plan(ctx, 256, 256, 64, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert plan(ctx, 256, 256, 64, 64, 3, 1) == 0
   assert (rows.value, tiles.value) == (2, 128)     # rows too long for the 72-KiB tile: 8 waves, 512 pixels
+  assert plan(ctx, 128, 128, 64, 128, 3, 2) == 0 and rows.value >= 2
+  assert plan(ctx, 128, 128, 64, 128, 1, 2) == 0
   lib.tapir_destroy(ctx)

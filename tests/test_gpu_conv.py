@@ -34,18 +34,18 @@ def test_conv3x3_fused_vs_torch(model, n, h, w, c, shortcut):
   gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
   beta = (torch.randn(c, generator=g) * 0.3).to(dev)
   rows, tiles = ctypes.c_int(), ctypes.c_int()
-  assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
   slabs = 5
   part_in = torch.empty(n, slabs, c, 2, device=dev)
   assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, slabs, stream) == 0
   ws = ctypes.c_void_p()
-  assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wt.data_ptr()), c, ctypes.byref(ws)) == 0
+  assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
   y = torch.zeros(n, h, w, c, device=dev, dtype=torch.bfloat16)
   part = torch.zeros(n, tiles.value, c, 2, device=dev)
   ss = torch.empty(n, c, 2, device=dev)
-  rc = lib.tapir_conv3x3_fused(ctx, x.data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(), beta.data_ptr(),
-                               ss.data_ptr(), ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(),
-                               n, h, w, c, stream)
+  rc = lib.tapir_conv_fused(ctx, x.data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(), beta.data_ptr(),
+                            ss.data_ptr(), ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(),
+                            n, h, w, c, c, 3, 1, stream)
   assert rc == 0, lib.tapir_last_error(ctx)
   torch.cuda.synchronize()
   # f32 reference on the same bf16-rounded operands (normalised activations rounded to bf16 like the kernel's LDS image)
@@ -71,6 +71,52 @@ def test_conv3x3_fused_vs_torch(model, n, h, w, c, shortcut):
   gd = got.double()
   assert torch.allclose(tot_mean, gd.mean((1, 2)), atol=1e-5)
   assert torch.allclose(tot_M2 / (h * w), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,ks,stride', [(3, 128, 128, 64, 128, 3, 2), (3, 64, 64, 128, 256, 3, 2),
+                                                      (3, 128, 128, 64, 128, 1, 2), (3, 64, 64, 128, 256, 1, 2),
+                                                      (3, 128, 128, 64, 64, 1, 1), (3, 32, 32, 256, 256, 1, 1),
+                                                      (2, 25, 31, 64, 128, 3, 2)])
+def test_strided_and_projection_convs_vs_torch(model, n, h, w, cin, cout, ks, stride):
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  g = torch.Generator(device='cpu').manual_seed(h + cin + ks)
+  x = (torch.randn(n, h, w, cin, generator=g) * 1.5 + 0.5).to(torch.bfloat16).to(dev)
+  wt = (torch.randn(cout, cin, ks, ks, generator=g) / (ks * ks * cin) ** 0.5).contiguous()
+  gamma = (torch.rand(cin, generator=g) + 0.5).to(dev)
+  beta = (torch.randn(cin, generator=g) * 0.3).to(dev)
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  part_in = torch.empty(n, 4, cin, 2, device=dev)
+  assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, cin, 4, stream) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), cout, cin, ks, ctypes.byref(ws)) == 0
+  ho, wo = -(-h // stride), -(-w // stride)
+  y = torch.zeros(n, ho, wo, cout, device=dev, dtype=torch.bfloat16)
+  part = torch.zeros(n, tiles.value, cout, 2, device=dev)
+  ss = torch.empty(n, cin, 2, device=dev)
+  rc = lib.tapir_conv_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(),
+                            ss.data_ptr(), ws, None, y.data_ptr(), part.data_ptr(), n, h, w, cin, cout, ks, stride, stream)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  torch.cuda.synchronize()
+  xf = x.float()
+  mean = xf.mean((1, 2), keepdim=True)
+  var = xf.var((1, 2), keepdim=True, unbiased=False)
+  xn = torch.relu((xf - mean) / torch.sqrt(var + 1e-5) * gamma + beta).to(torch.bfloat16).float()
+  from tapnet_amd.backbone import _same_pad
+  ref = F.conv2d(_same_pad(xn.permute(0, 3, 1, 2), ks, stride), wt.to(torch.bfloat16).float().to(dev),
+                 stride=stride).permute(0, 2, 3, 1)
+  d = (y.float() - ref).abs()
+  assert float(d.max()) < 4e-2 and float(d.mean()) < 2.5e-3, (float(d.max()), float(d.mean()))
+  cnt = torch.tensor([min(rows.value, ho - t * rows.value) * wo for t in range(tiles.value)], device=dev,
+                     dtype=torch.float64)
+  pm, pM2 = part[..., 0].double(), part[..., 1].double()
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  gd = y.double()
+  assert torch.allclose(tot_mean, gd.mean((1, 2)), atol=1e-5)
+  assert torch.allclose(tot_M2 / (ho * wo), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize('size', [256, 200])

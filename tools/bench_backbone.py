@@ -23,10 +23,31 @@ def main():
   m = TAPIR(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, weights=w, device='cuda:0', dtype=a.dtype)
   bb = m._backbone
   frames = torch.rand(a.frames, a.size, a.size, 3, device='cuda:0') * 2 - 1
+  ap_sets = [('all HIP', {'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}),
+             ('3x3 stride 1 only', {'conv_0', 'conv_1'}),
+             ('+ stride-2 3x3', {'conv_0', 'conv_1', 'conv_0_s2'}),
+             ('+ 1x1 stride 1', {'conv_0', 'conv_1', 'proj_conv'}),
+             ('+ 1x1 stride 2', {'conv_0', 'conv_1', 'proj_conv_s2'}),
+             ('none (MIOpen)', set())]
+  for name, kinds in ap_sets:
+    bb.hip_convs = kinds
+    bb.streams = 1
+    for _ in range(4):
+      bb.features(frames)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+      bb.features(frames)
+    e1.record()
+    torch.cuda.synchronize()
+    print(json.dumps({'workload': f'Backbone.features {a.frames}x{a.size}x{a.size} {a.dtype}', 'hip_convs': name,
+                      'ms': round(e0.elapsed_time(e1) / a.reps, 3)}), flush=True)
+  bb.hip_convs = ap_sets[0][1]
   ref = None
   for streams in (1, 2, 3, 4):
     bb.streams = streams
-    for _ in range(3):
+    for _ in range(4):
       out = bb.features(frames)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

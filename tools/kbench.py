@@ -448,7 +448,7 @@ def trace_conv(model):
            'epilogue (add, store, stats)', 'summary merge']
   for (n, h, w, c) in ((48, 128, 128, 64), (48, 64, 64, 128), (48, 32, 32, 256)):
     rows, tiles = ctypes.c_int(), ctypes.c_int()
-    assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
     x = (torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16)
     sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
     wh = (torch.randn(c, c, 3, 3) / (9 * c) ** 0.5).contiguous()
@@ -459,16 +459,16 @@ def trace_conv(model):
     ss = torch.empty(n, c, 2, device=dev)
     y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
     ws = ctypes.c_void_p()
-    assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, ctypes.byref(ws)) == 0
+    assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
     assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, 4, stream) == 0
     nwg = n * tiles.value
     buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
     for it in range(3):
       buf.zero_()
       assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
-      assert lib.tapir_conv3x3_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(),
-                                     ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c,
-                                     stream) == 0
+      assert lib.tapir_conv_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(),
+                                  ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c,
+                                  c, 3, 1, stream) == 0
       torch.cuda.synchronize()
     lib.tapir_debug_set_trace(ctx, None)
     waves = 4 if rows.value * w <= 16384 // c else 8
@@ -492,7 +492,7 @@ def bench_conv(model, reps, results):
   torch.backends.cudnn.benchmark = True
   for (n, h, w, c) in ((48, 128, 128, 64), (48, 64, 64, 128), (48, 32, 32, 256), (8, 256, 256, 64)):
     rows, tiles = ctypes.c_int(), ctypes.c_int()
-    assert lib.tapir_conv3x3_plan(ctx, h, w, c, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
     x = [(torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16) for _ in range(3)]
     sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
     wt = (torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5)
@@ -508,13 +508,13 @@ def bench_conv(model, reps, results):
     yn = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
     ws = ctypes.c_void_p()
     wh = wt.cpu().contiguous()
-    assert lib.tapir_conv3x3_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, ctypes.byref(ws)) == 0
+    assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
     for t_ in x:
       assert lib.tapir_inorm_stats(ctx, t_.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, slabs, stream) == 0
     def hip(i):
-      assert lib.tapir_conv3x3_fused(ctx, x[i % 3].data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(),
-                                     beta.data_ptr(), ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(),
-                                     part_out.data_ptr(), n, h, w, c, stream) == 0
+      assert lib.tapir_conv_fused(ctx, x[i % 3].data_ptr(), part_in.data_ptr(), slabs, 0, gamma.data_ptr(),
+                                  beta.data_ptr(), ss.data_ptr(), ws, sc.data_ptr(), y.data_ptr(),
+                                  part_out.data_ptr(), n, h, w, c, c, 3, 1, stream) == 0
     conv_out = [None]
     def miopen_conv(i):
       conv_out[0] = F.conv2d(yn.permute(0, 3, 1, 2), wcl, None, padding=1)
