@@ -229,7 +229,7 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * normalisation of its INPUT folded into the operand load and the residual add + the statistics of its
  * OUTPUT (for the next norm) into the epilogue.  Supported: 3x3 stride 1 with C -> C channels,
  * C in {64,128,256}; 1x1 stride 1 with 64 -> 64 / 256 -> 256; 3x3 and 1x1 stride 2 with 64 -> 128 /
- * 128 -> 256; XLA "SAME" padding.  (The 7x7 stem stays on MIOpen.)
+ * 128 -> 256; XLA "SAME" padding.  (The 7x7 stem has its own entry point below.)
  * tapir_conv_plan : output rows per workgroup tile and tiles per image for an [H, W, cin] INPUT map
  *   (TAPIR_ERR_UNSUPPORTED when the shape does not fit: keep that convolution on MIOpen).
  * tapir_conv_pack : w = the reference's [cout, cin, ks, ks] f32 kernel (torch OIHW, host memory)
@@ -246,6 +246,16 @@ int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int sl
                      const float* gamma, const float* beta, float* ss, const void* wstream,
                      const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                      int cout, int ks, int stride, void* stream);
+
+/* The stem of the ResNet (resnet.py:356-364: initial_conv, 7x7 / stride 2 / SAME, 3 -> 64 channels), bf16
+ * contexts: x = the f32 frames [N,H,W,3] as the model receives them (rounded to bf16 on load, as the
+ * library path's cast does), y [N, ceil(H/2), ceil(W/2), 64] bf16, part_out [N, tiles, 64, 2] the
+ * (mean, M2) summaries of y per tile of rows * W_out pixels (input of the first InstanceNorm).
+ * tapir_stem_pack takes the reference's [64, 3, 7, 7] f32 kernel (host memory). */
+int tapir_stem_plan(tapir_ctx* ctx, int H, int W, int* rows, int* tiles);
+int tapir_stem_pack(tapir_ctx* ctx, const float* w, void** wstream);
+int tapir_stem_conv(tapir_ctx* ctx, const float* x, const void* wstream, void* y, float* part_out, int N,
+                    int H, int W, void* stream);
 
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):

@@ -80,12 +80,13 @@ class Backbone:
     # contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
     self.conv_mode = 'auto'
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
-    self.hip_convs = {'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
+    self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
     # clips of at least this many frames replay their launches from a hipGraph from the third call with
     # the same shape on (features()); 0 = always launch eagerly
     self.graph_min_frames = 8
     self._graphs: Dict[tuple, dict] = {}
     self._plans: Dict[tuple, Optional[tuple]] = {}
+    self._stem_ws = None
     self._wstream: Dict[str, int] = {}
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
@@ -117,6 +118,14 @@ class Backbone:
                                  ctypes.byref(h))
         if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
           self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
+      k = 'resnet_torch.initial_conv.weight'
+      a = weights.get(k)
+      if a is not None:
+        a = np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+        if a.shape == (64, 3, 7, 7):
+          h = ctypes.c_void_p()
+          if lib.tapir_stem_pack(ctx, a.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == 0:
+            self._stem_ws = h.value
     need = ['resnet_torch.initial_conv.weight']
     if extra_convs:
       need.append('extra_convs.blocks.0.conv.weight')
@@ -271,10 +280,26 @@ class Backbone:
     return out
 
   def _features_hip(self, frames_nhwc, out_low=None, out_hi=None):
-    x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-    w0 = self.w['resnet_torch.initial_conv.weight']
-    x = F.conv2d(_same_pad(x, w0.shape[-1], 2), w0, None, stride=2).permute(0, 2, 3, 1).contiguous()
-    st = self._hip_stats(x)
+    st = None
+    if self.conv_mode != 'miopen' and 'stem' in self.hip_convs and self._stem_ws is not None:
+      import ctypes
+      lib, ctx = self.engine
+      n, h, w, _ = frames_nhwc.shape
+      rows, tiles = ctypes.c_int(), ctypes.c_int()
+      if (frames_nhwc.dtype == torch.float32 and
+          lib.tapir_stem_plan(ctx, h, w, ctypes.byref(rows), ctypes.byref(tiles)) == 0):
+        ho, wo = -(-h // 2), -(-w // 2)
+        fr = frames_nhwc.contiguous()
+        x = self._buf(('stem', n, ho, wo), (n, ho, wo, 64), self.dtype)
+        part = self._buf(('stempart', n, tiles.value), (n, tiles.value, 64, 2), torch.float32)
+        self._check(lib.tapir_stem_conv(ctx, fr.data_ptr(), self._stem_ws, x.data_ptr(), part.data_ptr(), n, h, w,
+                                        self._stream()), 'tapir_stem_conv')
+        st = _Stats(part, tiles.value, rows.value * wo)
+    if st is None:
+      x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+      w0 = self.w['resnet_torch.initial_conv.weight']
+      x = F.conv2d(_same_pad(x, w0.shape[-1], 2), w0, None, stride=2).permute(0, 2, 3, 1).contiguous()
+      st = self._hip_stats(x)
     strides = (1, 2, 2, 1)
     unit1 = None
     for g in range(4):

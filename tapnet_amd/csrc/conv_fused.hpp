@@ -94,6 +94,91 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// Epilogue shared by the block convolutions and the stem: the wave's 4 x NT accumulator fragments
+// (lane group g of pixel column c holds channels cg * 64 + 16 g + 4 r + e of pixel qpix[i]) are rounded
+// to bf16 and stored as 2 x 16 bytes per pixel and lane; the (mean, M2) summary of the STORED values of
+// the workgroup's TP pixels goes to part[COUT][2] (Chan merge of the per-wave two-pass summaries).
+// `scratch` = LDS nobody reads any more (WAVES x 64 float2).
+template <int COUT, int NT, int WAVES>
+__device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const int (&qpix)[NT], int TP,
+                                             bf16_t* ytile, float* part, char* scratch) {
+  constexpr int CG = COUT / 64, PG = WAVES / CG;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int cg = wave % CG, pg = wave / CG;
+  float2 (*const s_stat)[64] = reinterpret_cast<float2 (*)[64]>(scratch);   // [wave][channel of the wave]
+  const int cnt_w = max(0, min(NT * 16, TP - pg * NT * 16));
+  const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
+  uint2 pk[4][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pk[r][i].x = pack_bf16x2(acc[r][i][0], acc[r][i][1]);
+      pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
+    }
+    if (qpix[i] < TP) {
+      uint4* yp = reinterpret_cast<uint4*>(ytile + (long)qpix[i] * COUT + cg * 64 + 16 * g);
+      yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
+      yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
+    }
+  }
+  if (part == nullptr) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bool ok = qpix[i] < TP;
+      const uint2 p = pk[r][i];
+      v[i][0] = ok ? __uint_as_float(p.x << 16) : 0.f;
+      v[i][1] = ok ? __uint_as_float(p.x & 0xffff0000u) : 0.f;
+      v[i][2] = ok ? __uint_as_float(p.y << 16) : 0.f;
+      v[i][3] = ok ? __uint_as_float(p.y & 0xffff0000u) : 0.f;
+    }
+    float mean[4], m2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) s += v[i][e];
+      mean[e] = s;
+    }
+    row_sum_n<4>(mean);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mean[e] *= inv_cnt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const float d = qpix[i] < TP ? v[i][e] - mean[e] : 0.f;
+        s = fmaf(d, d, s);
+      }
+      m2[e] = s;
+    }
+    row_sum_n<4>(m2);
+    if (c == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_stat[wave][16 * g + 4 * r + e] = make_float2(mean[e], m2[e]);
+    }
+  }
+  lds_barrier();
+  if (tid < COUT) {
+    const int cgi = tid / 64, ch = tid % 64;
+    float cn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < PG; ++p) {
+      const float nb = (float)max(0, min(NT * 16, TP - p * NT * 16));
+      const float2 sv = s_stat[p * CG + cgi][ch];
+      merge_stats(cn, mean, m2, nb, sv.x, sv.y);
+    }
+    *reinterpret_cast<float2*>(part + tid * 2) = make_float2(mean, m2);
+  }
+}
+
 template <int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) {
   constexpr int THREADS = WAVES * 64;
@@ -290,80 +375,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
   lds_barrier();   // every wave is done with the tile: the region is reused for the summaries
   tick(3);
 
-  // ---- epilogue: + shortcut, round, store, per-channel (mean, M2) of what was stored
-  float2 (*const s_stat)[64] = reinterpret_cast<float2 (*)[64]>(tile);   // [wave][channel of the wave]
-  const int cnt_w = max(0, min(NT * 16, TP - pg * NT * 16));
-  const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
-  uint2 pk[4][NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pk[r][i].x = pack_bf16x2(acc[r][i][0], acc[r][i][1]);
-      pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
-    }
-    if (qpix[i] < TP) {
-      uint4* yp = reinterpret_cast<uint4*>(a.y + (img + qpix[i]) * COUT + cg * 64 + 16 * g);
-      yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
-      yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float v[NT][4];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const bool ok = qpix[i] < TP;
-      const uint2 p = pk[r][i];
-      v[i][0] = ok ? __uint_as_float(p.x << 16) : 0.f;
-      v[i][1] = ok ? __uint_as_float(p.x & 0xffff0000u) : 0.f;
-      v[i][2] = ok ? __uint_as_float(p.y << 16) : 0.f;
-      v[i][3] = ok ? __uint_as_float(p.y & 0xffff0000u) : 0.f;
-    }
-    if (a.part) {
-      float mean[4], m2[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) s += v[i][e];
-        mean[e] = s;
-      }
-      row_sum_n<4>(mean);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) mean[e] *= inv_cnt;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const float d = qpix[i] < TP ? v[i][e] - mean[e] : 0.f;
-          s = fmaf(d, d, s);
-        }
-        m2[e] = s;
-      }
-      row_sum_n<4>(m2);
-      if (c == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_stat[wave][16 * g + 4 * r + e] = make_float2(mean[e], m2[e]);
-      }
-    }
-  }
+  // ---- epilogue: round, store, per-channel (mean, M2) of what was stored
+  cv3_epilogue<COUT, NT, WAVES>(acc, qpix, TP, a.y + img * COUT,
+                                a.part ? a.part + ((long)n * a.tiles + t) * COUT * 2 : nullptr, tile);
   tick(4);
-  if (a.part) {
-    lds_barrier();
-    if (tid < COUT) {
-      const int cgi = tid / 64, ch = tid % 64;
-      float cn = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int p = 0; p < PG; ++p) {
-        const float nb = (float)max(0, min(NT * 16, TP - p * NT * 16));
-        const float2 sv = s_stat[p * CG + cgi][ch];
-        merge_stats(cn, mean, m2, nb, sv.x, sv.y);
-      }
-      *reinterpret_cast<float2*>(a.part + (((long)n * a.tiles + t) * COUT + tid) * 2) = make_float2(mean, m2);
-    }
-  }
   if (TRACE && a.dbg_times != nullptr && lane == 0) {
     tick(5);
     long long* o = a.dbg_times + ((long)bid * WAVES + wave) * 8;
@@ -418,6 +433,139 @@ inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int
 #undef TAPIR_CV3
 #undef TAPIR_CV3_SC
   (void)cout;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The stem: 7x7 / stride 2 / SAME convolution 3 -> 64 channels on the frames themselves
+// (resnet.py:356-364 initial_conv; its output feeds the first InstanceNorm, whose statistics the
+// epilogue emits).  K = 7 rows x (7 columns x 3 channels = 21 contiguous input values, padded to 32):
+// one k-step per kernel row.  The input rows [2 rows_out + 5][W x 3] sit in LDS as bf16, unswizzled: the
+// B fragment of (pixel x, kernel row ky, lane group g) is the 8 values at row 2 y + ky, element
+// 6 x + 8 g -- a 4-byte aligned address, read as four ds_read_b32; the values past the 21st multiply
+// zero weights.  Frames are f32 (the model's input), rounded to bf16 on the way into LDS like the
+// library path's cast; 4 waves x (64 output channels x 64 pixels), two workgroups per CU.
+constexpr int STEM_WAVES = 4;
+constexpr int STEM_LDS_BYTES = 32 * 1024;
+
+struct StemArgs {
+  const float* x;         // [N, H, W, 3] f32
+  const uint4* wstream;   // [7 + ring][4][64 lanes] packed A fragments (tapir_stem_pack)
+  bf16_t* y;              // [N, Ho, Wo, 64]
+  float* part;            // null, or [N, tiles, 64, 2]
+  int N, H, W, Ho, Wo, pad_y, pad_x, TH, tiles;
+};
+
+inline bool stem_plan(int H, int W, int* rows, int* tiles) {
+  if (H < 1 || W < 2 || (W & 1)) return false;     // (pairs of f32 are loaded: even rows of 3 W values)
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int th = (STEM_WAVES * CV3_NT * 16) / Wo;
+  if (th > Ho) th = Ho;
+  auto bytes = [&](int t) { return (long)(2 * (t - 1) + 7) * ((((2 * (Wo - 1) + 7) * 6 + 64) + 15) / 16 * 16); };
+  while (th >= 1 && bytes(th) > STEM_LDS_BYTES) --th;
+  if (th < 1) return false;
+  *rows = th;
+  *tiles = (Ho + th - 1) / th;
+  return true;
+}
+
+__global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs a) {
+  constexpr int NT = CV3_NT, WAVES = STEM_WAVES, THREADS = WAVES * 64, RING = 8;
+  __shared__ uint4 s_tile[STEM_LDS_BYTES / 16];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int total = a.N * a.tiles;
+  const int per_xcd = (total + 7) >> 3;
+  const int bid = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (bid >= total) return;
+  const int n = bid / a.tiles, t = bid - n * a.tiles;
+  const int H = a.H, W = a.W, Wo = a.Wo;
+  const int PW = 2 * (Wo - 1) + 7;                 // input columns of the tile
+  const int RS = ((PW * 6 + 64) + 15) / 16 * 16;   // bytes per LDS row (64 bytes of slack for the padded k)
+  const int r0 = t * a.TH;
+  const int rows = min(a.TH, a.Ho - r0);
+  const int in_rows = 2 * (rows - 1) + 7;
+  const int TP = rows * Wo;
+  const int y0 = 2 * r0 - a.pad_y, e0 = -3 * a.pad_x;   // first input row / first input ELEMENT of a tile row
+  char* const tile = reinterpret_cast<char*>(s_tile);
+
+  const uint4* wp = a.wstream + lane;
+  uint4 ring[RING];
+#pragma unroll
+  for (int s = 0; s < RING; ++s) { ring[s] = *wp; wp += 64; }
+
+  int Pb[NT], qpix[NT];                            // byte offset of tap (0, 0, channel 0) of this lane's pixels
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int q = (wave * NT + i) * 16 + c;
+    qpix[i] = q;
+    const int qq = q < TP ? q : 0;
+    const int yy = qq / Wo, xx = qq - yy * Wo;
+    Pb[i] = 2 * yy * RS + 12 * xx + 16 * g;
+  }
+
+  // ---- stage the input rows: pairs of f32 -> packed bf16 (zero outside the image and in the slack)
+  {
+    const int pairs = RS / 4;
+    const float* xin = a.x + (long)n * H * W * 3;
+    for (int hy = 0; hy < in_rows; ++hy) {
+      const int y = y0 + hy;
+      const bool yok = y >= 0 && y < H;
+      const float* rowp = xin + (long)min(max(y, 0), H - 1) * W * 3;
+      for (int p = tid; p < pairs; p += THREADS) {
+        const int ge = e0 + 2 * p;                 // even: a pair never straddles the image edge (3 W is even)
+        const bool ok = yok && ge >= 0 && ge + 1 < 3 * W && 2 * p < PW * 3 + 1;
+        float2 v = make_float2(0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float2*>(rowp + ge);
+        *reinterpret_cast<unsigned*>(tile + hy * RS + 4 * p) = pack_bf16x2(v.x, v.y);
+      }
+    }
+  }
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  lds_barrier();
+
+  // ---- 7 k-steps (kernel rows); B fragments one step ahead
+  auto read_b = [&](int ky, uint4 (&fb)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const unsigned* p = reinterpret_cast<const unsigned*>(tile + Pb[i] + ky * RS);
+      fb[i] = make_uint4(p[0], p[1], p[2], p[3]);
+    }
+  };
+  {
+    uint4 fb0[NT], fb1[NT];
+    read_b(0, fb0);
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      uint4 (&nxt)[NT] = (ky & 1) ? fb0 : fb1;
+      uint4 (&cur)[NT] = (ky & 1) ? fb1 : fb0;
+      read_b(ky < 6 ? ky + 1 : 0, nxt);
+      sched_fence();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint4 fa = ring[(ky & 1) * 4 + r];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) MfmaStep<bf16_t>::run(fa, cur[i], acc[r][i]);
+        ring[(ky & 1) * 4 + r] = *wp;
+        wp += 64;
+        sched_fence();
+      }
+    }
+  }
+  lds_barrier();
+  const long img = ((long)n * a.Ho + r0) * Wo;
+  cv3_epilogue<64, NT, WAVES>(acc, qpix, TP, a.y + img * 64,
+                              a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile);
+}
+
+inline void launch_stem_conv(const StemArgs& a, hipStream_t s) {
+  const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block(STEM_WAVES * 64);
+  TAPIR_LAUNCH(stem_conv_kernel, grid, block, s, a);
 }
 
 }  // namespace tapir

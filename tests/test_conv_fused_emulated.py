@@ -173,6 +173,38 @@ def test_strided_and_projection_convs(cin, cout, ks, stride, H, W):
   lib.tapir_destroy(ctx)
 
 
+@pytest.mark.parametrize('H,W', [(16, 32), (9, 12), (6, 300)])
+def test_stem_conv(H, W):
+  """7x7 / stride 2 / SAME stem (resnet.py:356-364) on f32 frames, against numpy on the bf16-rounded
+  operands; summaries of the stored output."""
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  rng = np.random.default_rng(H + W)
+  N = 2
+  x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+  w = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_stem_plan(ctx, H, W, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_stem_pack(ctx, _p(w), ctypes.byref(ws)) == 0
+  Ho, Wo = -(-H // 2), -(-W // 2)
+  y = np.zeros((N, Ho, Wo, 64), np.uint16)
+  part = np.zeros((N, tiles.value, 64, 2), np.float32)
+  rc = lib.tapir_stem_conv(ctx, _p(x), ws, _p(y), _p(part), N, H, W, None)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  ref = _conv_ref(_r(x), _r(w), 2)
+  got = from_bf16_bits(y)
+  np.testing.assert_allclose(got, ref, atol=1e-2, rtol=1e-2)
+  assert np.abs(got - ref).mean() < 1e-3
+  cnt = np.array([min(rows.value, Ho - t * rows.value) * Wo for t in range(tiles.value)], np.float64)
+  pm, pM2 = part[..., 0].astype(np.float64), part[..., 1].astype(np.float64)
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  np.testing.assert_allclose(tot_mean, got.mean((1, 2), dtype=np.float64), atol=1e-5)
+  np.testing.assert_allclose(tot_M2 / (Ho * Wo), got.astype(np.float64).var((1, 2)), rtol=1e-4, atol=1e-6)
+  lib.tapir_destroy(ctx)
+
+
 def test_conv_rejects_f32_and_bad_shapes():
   lib = emu_lib()
   ctx = _ctx(lib, _ffi.TAPIR_F32)

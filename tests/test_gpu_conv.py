@@ -119,6 +119,38 @@ def test_strided_and_projection_convs_vs_torch(model, n, h, w, cin, cout, ks, st
   assert torch.allclose(tot_M2 / (ho * wo), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('n,h,w', [(4, 256, 256), (2, 200, 136), (1, 512, 512), (3, 33, 50)])
+def test_stem_conv_vs_torch(model, n, h, w):
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  g = torch.Generator(device='cpu').manual_seed(h + w)
+  x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).to(dev)
+  wt = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).contiguous()
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_stem_plan(ctx, h, w, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_stem_pack(ctx, ctypes.c_void_p(wt.data_ptr()), ctypes.byref(ws)) == 0
+  ho, wo = -(-h // 2), -(-w // 2)
+  y = torch.zeros(n, ho, wo, 64, device=dev, dtype=torch.bfloat16)
+  part = torch.zeros(n, tiles.value, 64, 2, device=dev)
+  rc = lib.tapir_stem_conv(ctx, x.data_ptr(), ws, y.data_ptr(), part.data_ptr(), n, h, w, model._stream())
+  assert rc == 0, lib.tapir_last_error(ctx)
+  torch.cuda.synchronize()
+  from tapnet_amd.backbone import _same_pad
+  xr = x.to(torch.bfloat16).float().permute(0, 3, 1, 2)
+  ref = F.conv2d(_same_pad(xr, 7, 2), wt.to(torch.bfloat16).float().to(dev), stride=2).permute(0, 2, 3, 1)
+  d = (y.float() - ref).abs()
+  assert float(d.max()) < 1.6e-2 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))
+  cnt = torch.tensor([min(rows.value, ho - t * rows.value) * wo for t in range(tiles.value)], device=dev,
+                     dtype=torch.float64)
+  pm, pM2 = part[..., 0].double(), part[..., 1].double()
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  gd = y.double()
+  assert torch.allclose(tot_mean, gd.mean((1, 2)), atol=1e-5)
+  assert torch.allclose(tot_M2 / (ho * wo), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('size', [256, 200])
 def test_backbone_fused_convs_vs_miopen(model, size):
   """Backbone.features of the bf16 model with the HIP convolutions and with every convolution on MIOpen,

@@ -23,7 +23,8 @@ def main():
   m = TAPIR(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, weights=w, device='cuda:0', dtype=a.dtype)
   bb = m._backbone
   frames = torch.rand(a.frames, a.size, a.size, 3, device='cuda:0') * 2 - 1
-  ap_sets = [('all HIP', {'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}),
+  ap_sets = [('all HIP', {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}),
+             ('all block convolutions, MIOpen stem', {'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}),
              ('3x3 stride 1 only', {'conv_0', 'conv_1'}),
              ('+ stride-2 3x3', {'conv_0', 'conv_1', 'conv_0_s2'}),
              ('+ 1x1 stride 1', {'conv_0', 'conv_1', 'proj_conv'}),
