@@ -25,6 +25,7 @@ by bench.py's cpu_baseline lives in oracle/backbone_torch.py.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, NamedTuple, Optional, Sequence, Tuple
 
 import torch
@@ -69,10 +70,10 @@ class Backbone:
     # Frames are independent through the whole backbone, so a clip can be cut into `streams` groups of
     # frames that run on separate HIP streams: the memory-bound phases of one group's kernels (tile
     # staging, epilogues, the glue kernels) then overlap the MFMA-bound phases of the other's instead of
-    # alternating with them (1.67 -> 1.55 ms for a 48-frame clip, bit-identical: every kernel here is
+    # alternating with them (1.86 -> 1.64 / 1.57 ms with 2 / 4 streams for a 48-frame clip, bit-identical: every kernel here is
     # independent of how many frames a launch covers).  1 = everything on the caller's stream; applies
     # to clips of at least 8 frames per stream.
-    self.streams = 2 if dtype == torch.bfloat16 else 1
+    self.streams = 4 if dtype == torch.bfloat16 else 1
     self._side_streams = []
     self._lane = 0
     # 'auto': the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2: everything but the 7x7
@@ -334,7 +335,9 @@ class Backbone:
     # cannot issue as fast as the GPU retires them (2.04 ms wall against 1.7 ms of kernels for 48 frames).
     # From the third call with the same shape on, the launches are replayed from a captured graph.
     key = (n, H, W, self.conv_mode, tuple(sorted(self.hip_convs)), streams)
-    if (self.graph_min_frames and n >= self.graph_min_frames and (not chunk or chunk >= n)
+    if os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (profilers that need every dispatch on its own)
+      key = None
+    if (key is not None and self.graph_min_frames and n >= self.graph_min_frames and (not chunk or chunk >= n)
         and not torch.cuda.is_current_stream_capturing()):
       ent = self._graphs.get(key)
       if ent is None:

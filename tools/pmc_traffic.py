@@ -18,6 +18,18 @@ KERNELS = {
     'gemm_up': ('gemm_nt_kernel<unsigned short, unsigned short, 1', 'GemmTile<2, 4, 4, 2, 2'),   # 128x128, 8 waves
     'gemm_down': ('gemm_nt_kernel<unsigned short, float, 2', 'GemmTile<2, 2, 6, 2, 2'),          # 192x64
     'mix': ('mix_stream_kernel<unsigned short, 12, false', ''),
+    # round 2
+    'mixer_fused': ('mixer_fused_kernel<unsigned short, 3, false', ''),
+    'mixer_fused_wide': ('mixer_fused_wide_kernel<3, 2, false', ''),
+    'cv_fused': ('cv_fused_kernel<unsigned short', ''),
+    'patch_corr': ('patch_corr_kernel<unsigned short', ''),
+    'conv3x3_c64_shortcut': ('conv_fused_kernel<64, 64, 3, 1, 4, 4, true', ''),
+    'conv3x3_c64': ('conv_fused_kernel<64, 64, 3, 1, 4, 4, false', ''),
+    'conv3x3_c128_shortcut': ('conv_fused_kernel<128, 128, 3, 1, 4, 4, true', ''),
+    'conv3x3_c256_shortcut': ('conv_fused_kernel<256, 256, 3, 1, 4, 4, true', ''),
+    'conv3x3_c256': ('conv_fused_kernel<256, 256, 3, 1, 4, 4, false', ''),
+    'conv3x3_s2_64_128': ('conv_fused_kernel<64, 128, 3, 2', ''),
+    'stem': ('stem_conv_kernel', ''),
 }
 
 
@@ -48,8 +60,8 @@ def per_kernel(d, counter):
 def main():
   fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
   write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
-  out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on tools/kbench.py (config-2 shapes), '
-                   'FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes',
+  out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) on the command named in profiles/README.md, '
+                   'FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; averages per launch',
          'kernels': {}}
   for k in KERNELS:
     if k not in fetch:
