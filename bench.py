@@ -170,6 +170,10 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  # one-time setup, like loading the weights: scratch allocation and the hipGraph capture of the
+  # backbone's launches happen on the first three calls with a new clip shape (tapnet_amd/backbone.py)
+  for _ in range(3):
+    model.get_feature_grids(video)
   for _ in range(args.warmup):
     step()
   barrier()
