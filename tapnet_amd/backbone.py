@@ -334,10 +334,15 @@ class Backbone:
     # hipGraph replay: a clip's backbone is ~60 launches of 10-100 us kernels, which one Python thread
     # cannot issue as fast as the GPU retires them (2.04 ms wall against 1.7 ms of kernels for 48 frames).
     # From the third call with the same shape on, the launches are replayed from a captured graph.
-    key = (n, H, W, self.conv_mode, tuple(sorted(self.hip_convs)), streams)
+    if chunk:
+      bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
+    else:
+      per = -(-n // streams)
+      bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
+    key = (n, H, W, self.conv_mode, tuple(sorted(self.hip_convs)), streams, len(bounds))
     if os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (profilers that need every dispatch on its own)
       key = None
-    if (key is not None and self.graph_min_frames and n >= self.graph_min_frames and (not chunk or chunk >= n)
+    if (key is not None and self.graph_min_frames and n >= self.graph_min_frames
         and not torch.cuda.is_current_stream_capturing()):
       ent = self._graphs.get(key)
       if ent is None:
@@ -350,10 +355,8 @@ class Backbone:
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        per = -(-n // streams)
         with torch.cuda.graph(g):   # (the side streams fork from and join the capturing stream)
-          self._run_groups(ent['in'], ent['low'], ent['hi'], [(s0, min(s0 + per, n)) for s0 in range(0, n, per)],
-                           streams)
+          self._run_groups(ent['in'], ent['low'], ent['hi'], bounds, streams)
         ent['graph'] = g
       if 'graph' in ent:
         ent['in'].copy_(frames_nhwc)
@@ -361,11 +364,6 @@ class Backbone:
         low.copy_(ent['low'])
         hi.copy_(ent['hi'])
         return low, hi
-    if chunk:
-      bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
-    else:
-      per = -(-n // streams)
-      bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
     self._run_groups(frames_nhwc, low, hi, bounds, streams)
     return low, hi
 

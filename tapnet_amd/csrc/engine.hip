@@ -475,8 +475,10 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   const void* grid_op = grid;
   if (sizeof(TA) == 2) {   // stage bf16 copies of both operands
     TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
-    TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
-    c->cast_src[1] = nullptr;   // slot no longer mirrors a pyramid level
+    if (c->cast_src[1] != grid) {
+      TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
+      c->cast_src[1] = grid;    // the same layout as the low-res pyramid level: prepare_level reuses it
+    }
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
   }
   if (cv_fused_supported(h, w) && c->cv_mode != 1) {
@@ -1043,6 +1045,7 @@ int tapir_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float*
   if (!qfeat || !grid || !points || !occlusion || !expected_dist || B < 1 || Q < 1 || T < 1)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (((long)T * h * w) % 4 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
+  c->cast_src[1] = nullptr;   // (the cast cache is only valid within one API call: the caller may have rewritten the grid)
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points,
                   occlusion, expected_dist, (hipStream_t)stream);
 }
@@ -1056,6 +1059,7 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (c->cv_mode == 1 || !cv_fused_supported(h, w))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells (fused kernel only)");
+  c->cast_src[1] = nullptr;
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points, occlusion,
                   nullptr, (hipStream_t)stream, true);
 }

@@ -46,21 +46,21 @@ def main():
                       'ms': round(e0.elapsed_time(e1) / a.reps, 3)}), flush=True)
   bb.hip_convs = ap_sets[0][1]
   ref = None
-  for streams in (1, 2, 3, 4):
+  for streams, chunk in ((1, None), (2, None), (4, None), (1, 12), (2, 12)):
     bb.streams = streams
     for _ in range(4):
-      out = bb.features(frames)
+      out = bb.features(frames, chunk)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):
-      out = bb.features(frames)
+      out = bb.features(frames, chunk)
     e1.record()
     torch.cuda.synchronize()
     if ref is None:
       ref = out
     same = all(torch.equal(x, y) for x, y in zip(out, ref))
-    print(json.dumps({'workload': f'Backbone.features {a.frames}x{a.size}x{a.size} {a.dtype}', 'streams': streams,
+    print(json.dumps({'workload': f'Backbone.features {a.frames}x{a.size}x{a.size} {a.dtype}', 'streams': streams, 'frames_per_group': chunk,
                       'ms': round(e0.elapsed_time(e1) / a.reps, 3), 'bit_identical_to_1_stream': same}), flush=True)
 
 

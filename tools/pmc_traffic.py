@@ -35,13 +35,13 @@ KERNELS = {
 
 def rows_of(d):
   """(kernel name, counter name, value) of every dispatch: rocprofv3's CSV or rocpd (sqlite) output"""
-  f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))
+  f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
   if f:
     for r in csv.DictReader(open(f[0])):
       yield r['Kernel_Name'], r['Counter_Name'], float(r['Counter_Value'])
     return
   import sqlite3
-  db = sqlite3.connect(glob.glob(os.path.join(d, '*', '*results.db'))[0])
+  db = sqlite3.connect(glob.glob(os.path.join(d, '**', '*results.db'), recursive=True)[0])
   for row in db.execute('select kernel_name, counter_name, value from counters_collection'):
     yield row[0], row[1], float(row[2])
 
