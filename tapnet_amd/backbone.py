@@ -83,8 +83,8 @@ class Backbone:
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
     self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
     # clips of at least this many frames replay their launches from a hipGraph from the third call with
-    # the same shape on (features()); 0 = always launch eagerly
-    self.graph_min_frames = 8
+    # the same shape on (features()); 0 = always launch eagerly (the f32 build: parity tests, nothing timed)
+    self.graph_min_frames = 8 if dtype == torch.bfloat16 else 0
     self._graphs: Dict[tuple, dict] = {}
     self._plans: Dict[tuple, Optional[tuple]] = {}
     self._stem_ws = None
