@@ -79,7 +79,9 @@ class Backbone:
     # 'auto': the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2: everything but the 7x7
     # stem) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it (bf16
     # contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
-    self.conv_mode = 'auto'
+    self.conv_mode = 'auto'     # 'auto' | 'hip' (any number of frames) | 'miopen'
+    self.hip_min_frames = 4
+    self._hip_now = False
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
     self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
     # clips of at least this many frames replay their launches from a hipGraph from the third call with
@@ -216,9 +218,14 @@ class Backbone:
       self._plans[key] = (rows.value, tiles.value) if ok else None
     return self._plans[key]
 
+  def _use_hip_convs(self, n):
+    """'auto': the HIP convolutions from `hip_min_frames` frames per launch on -- a single frame (the
+    online model) gives them too few workgroups per launch, the library's kernels win there."""
+    return self.conv_mode == 'hip' or (self.conv_mode == 'auto' and n >= self.hip_min_frames)
+
   def _fusable(self, conv_name, h, w, stride):
     kind = conv_name.rsplit('.', 1)[-1] + ('_s2' if stride == 2 else '')
-    if self.conv_mode == 'miopen' or conv_name not in self._wstream or kind not in self.hip_convs:
+    if not self._hip_now or conv_name not in self._wstream or kind not in self.hip_convs:
       return False
     _, cin, cout, ks = self._wstream[conv_name]
     return self._plan(h, w, cin, cout, ks, stride) is not None
@@ -282,7 +289,8 @@ class Backbone:
 
   def _features_hip(self, frames_nhwc, out_low=None, out_hi=None):
     st = None
-    if self.conv_mode != 'miopen' and 'stem' in self.hip_convs and self._stem_ws is not None:
+    self._hip_now = self._use_hip_convs(frames_nhwc.shape[0])
+    if self._hip_now and 'stem' in self.hip_convs and self._stem_ws is not None:
       import ctypes
       lib, ctx = self.engine
       n, h, w, _ = frames_nhwc.shape

@@ -33,7 +33,10 @@ def main():
   video = torch.as_tensor(synthetic.make_video(1, 8, S, S)).cuda()
   qp = torch.as_tensor(synthetic.make_queries(2, Q, 1, S, S)).cuda()
   rows = []
-  for use_graph in (False, True):
+  for conv_mode, use_graph in (('auto', False), ('auto', True), ('miopen', True), ('hip', True)):
+    if m._backbone.dtype != torch.bfloat16 and conv_mode == 'hip':
+      continue
+    m._backbone.conv_mode = conv_mode
     trk = online.OnlineTracker(m, Q, (S, S), use_graph=use_graph)
     trk.init(video[:, :1], qp)
     for t in range(5):
@@ -45,7 +48,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.frames * 1e3
     assert torch.isfinite(out['tracks']).all()
-    rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', ms_per_frame=round(ms, 3),
+    rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', backbone_convs=conv_mode, ms_per_frame=round(ms, 3),
                      frames_per_s=round(1e3 / ms, 1), points_frames_per_s=round(Q * 1e3 / ms, 1)))
     print(json.dumps(dict(workload=f'online TAPIR {S}x{S}, Q={Q}, 4 iters/frame, {dtype}', **rows[-1])), flush=True)
 
