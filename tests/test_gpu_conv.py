@@ -179,3 +179,31 @@ def test_backbone_fused_convs_vs_miopen(model, size):
     assert float(cos_f) > 0.998 and float(err_f) < 2.5e-2
     assert float(cos_f) > float(cos_m) - 5e-4     # no further from f32 than the MIOpen bf16 path
     assert float(cos_mf) > 0.997
+
+
+def test_backbone_graph_replay_and_streams_match_eager(model):
+  """Backbone.features: the hipGraph replay (third call with a shape on) and the frame groups on several
+  streams return bit-for-bit what one eager launch sequence on one stream returns, for NEW frame contents
+  (the replay copies them into its static input) -- every kernel is independent of how many frames a
+  launch covers."""
+  bb = model._backbone
+  saved = (bb.graph_min_frames, bb.streams)
+  try:
+    f1 = torch.as_tensor(synthetic.make_video(5, 16, 128, 128), device=model.device).reshape(-1, 128, 128, 3).float()
+    f2 = torch.as_tensor(synthetic.make_video(6, 16, 128, 128), device=model.device).reshape(-1, 128, 128, 3).float()
+    bb.graph_min_frames, bb.streams = 0, 1
+    ref = [t.clone() for t in bb.features(f2)]
+    bb.graph_min_frames, bb.streams = 8, 2
+    for _ in range(3):
+      bb.features(f1)                       # the third call captures
+    key_has_graph = any('graph' in e for e in bb._graphs.values())
+    assert key_has_graph, 'no graph was captured'
+    out = bb.features(f2)                   # replay with other frames
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    out1 = [t.clone() for t in bb.features(f1)]
+    assert not torch.equal(out1[0], ref[0])
+    bb.graph_min_frames, bb.streams = 0, 2   # eager, two groups of frames on two streams
+    out = bb.features(f2)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+  finally:
+    bb.graph_min_frames, bb.streams = saved
