@@ -316,7 +316,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
   // eight summaries merge with Chan's formula (equal counts): ONE barrier per LayerNorm and the
   // numerics of the two-pass form.  Two summary buffers alternate between consecutive LayerNorms.
   int ln_phase = 0;
-  auto ln_stats = [&](float (&mean)[NT], float (&rstd)[NT]) {
+  auto ln_stats = [&](float (&mean)[NT], float (&rstd)[NT], bool wait_params = false) {
     float2 (*stat)[8] = s_stat[ln_phase];
     ln_phase ^= 1;
     float s[NT], m2[NT];
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) stat[16 * i + c][wave] = make_float2(s[i], m2[i]);
     }
+    if (wait_params) dma_wait<0>();   // LN1: the parameter copies of this block (params_dma) have landed; the ring is idle here
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -390,35 +391,33 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 
   // Temporal-convolution parameters of a block (64 KiB) go through LDS: read straight from global
   // memory, channel by channel, each read is a dependent L2 round trip with nothing to hide it
-  // behind (16 per lane and block).  The loads are ISSUED before the barrier that ends the previous
-  // block (their latency passes while the waves gather there) and the values stored into the
-  // activation region -- dead until LN2 -- after it; visible after ln_stats' first barrier.
+  // behind (16 per lane and block).  They are copied by LDS-DMA (global_load_lds: no registers) into
+  // the activation region -- dead from the barrier that ends a block until LN2 -- right after that
+  // barrier; ln_stats waits for the copies just before ITS barrier, so the latency passes under the
+  // LN1 statistics.  (The first version carried them across the barrier in 32 VGPRs: hipcc spilled all
+  // of them to scratch -- load, wait, spill, eight times over, then eight reloads with vmcnt(0) in
+  // front of each LDS write, every one of them draining the weight ring: 100 spilled VGPRs,
+  // 240 MB of scratch writes per launch.)
   constexpr int PARV = PAR_BYTES / 16 / FM_THREADS;
-  f32x4 parv[PARV];
-  auto params_load = [&](int blk) {
+  auto params_dma = [&](int blk) {
     const float* src = a.blocks[blk].mixw;
+    char* dst = reinterpret_cast<char*>(s_act) + 1024 * wave;     // 1 KiB per wave and instruction
 #pragma unroll
-    for (int k = 0; k < PARV; ++k) parv[k] = gload4(src + (tid + k * FM_THREADS) * 4);
+    for (int k = 0; k < PARV; ++k) glds16(src + (tid + k * FM_THREADS) * 4, dst + 8192 * k);
   };
-  auto params_commit = [&]() {
-    f32x4* dst = reinterpret_cast<f32x4*>(s_act);
-#pragma unroll
-    for (int k = 0; k < PARV; ++k) dst[tid + k * FM_THREADS] = parv[k];
-  };
-  if (a.nblocks > 0) params_load(0);
   lds_barrier();   // every wave is done with the input rows: the region is reused from here on
 
   for (int b = 0; b < a.nblocks; ++b) {
     const FusedBlockParams& bp = a.blocks[b];
     float mean[NT], rstd[NT];
-    params_commit();
+    params_dma(b);
 
     // ---- token mixing (tapir_model.py:39-89,111-119): LN1 -> depthwise conv k=3 (x4 channels) ->
     // GELU -> depthwise conv k=3 -> sum of each group of 4 -> + skip, per channel, along time.
     // Two adjacent channels of the lane at a time (registers 2 rp, 2 rp + 1 of a fragment), all
     // arithmetic on f32x2 -> packed f32 instructions; the parameters of a channel pair are
     // interleaved in LDS ([32][2] floats).
-    ln_stats(mean, rstd);
+    ln_stats(mean, rstd, true);
     tick(1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -543,7 +542,6 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     }
     fused_gemm<TA, 4, NT>(wp, ring, s_h0 + ((NC - 1) & 1) * H_BYTES, H_STRIDE, DN_GROUPS, c, g, xr);
     tick(6);
-    if (b + 1 < a.nblocks) params_load(b + 1);
     lds_barrier();   // every wave is done with the activation images before the next block reuses them
     tick(7);
   }
