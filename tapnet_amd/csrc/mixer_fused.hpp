@@ -24,8 +24,8 @@
 // Weights are never shared between waves (a wave multiplies ITS 64 output rows, or its slice of the
 // hidden rows, by all tokens), so they do not go through LDS at all: the host packs them per wave
 // into one linear stream of 1-KiB MFMA A-fragments in exactly the order the wave consumes them
-// (tapir_finalize_weights), and the wave keeps FM_RING = 16 fragment loads (global_load_dwordx4
-// straight to VGPRs, 64 VGPRs) in flight across phase boundaries and barriers.  LDS holds only what
+// (tapir_finalize_weights), and the wave keeps FM_RING = 8 fragment loads (global_load_dwordx4
+// straight to VGPRs, 32 VGPRs) in flight across phase boundaries and barriers.  LDS holds only what
 // waves exchange: LN2(x) [T,512] and one 512-wide (bf16; 256 f32) chunk of the hidden tensor.
 //
 // Roofline.  A CU streams both weight matrices of a block (4.2 MB bf16) from L2 for ONE track:
@@ -42,7 +42,13 @@ namespace tapir {
 
 constexpr int FM_WAVES = 8;
 constexpr int FM_THREADS = FM_WAVES * 64;
-constexpr int FM_RING = 16;          // weight fragments (1 KiB each) in flight per wave
+// weight fragments (1 KiB each) in flight per wave.  8, not 16: interleaved on one box the launch is
+// 2.5-3 % faster (757 / 749 against 782 / 770 us at 256 tracks) -- the 32 registers it frees take the
+// kernel from 38 spilled VGPRs to 5, and the fill-bound stream does not need the deeper queue.
+#ifndef TAPIR_FM_RING
+#define TAPIR_FM_RING 8
+#endif
+constexpr int FM_RING = TAPIR_FM_RING;
 constexpr int FM_MIXW = 32;          // floats per channel of packed temporal-conv parameters
 constexpr int FM_OUT_PAD = 512;      // output Linear rows padded to 8 waves x 64
 constexpr int FM_MAX_BLOCKS = 16;    // per-block parameter pointers travel in the kernel arguments
