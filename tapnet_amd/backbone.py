@@ -323,10 +323,11 @@ class Backbone:
 
   # -- public ---------------------------------------------------------------
   @torch.no_grad()
-  def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None
+  def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None, borrow: bool = False
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """frames [N,H,W,3] f32 in [-1,1] -> (lowres [N,H/8,W/8,256], hires [N,H/4,W/4,128]) f32,
-    L2-normalised, contiguous channels-last."""
+    L2-normalised, contiguous channels-last.  borrow=True: the caller consumes the grids before the
+    next call with this shape and may get the graph's own output buffers (no 150-MB copy per clip)."""
     n, H, W = frames_nhwc.shape[:3]
     half = lambda v: -(-v // 2)
     last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
@@ -369,6 +370,8 @@ class Backbone:
       if 'graph' in ent:
         ent['in'].copy_(frames_nhwc)
         ent['graph'].replay()
+        if borrow:
+          return ent['low'], ent['hi']
         low.copy_(ent['low'])
         hi.copy_(ent['hi'])
         return low, hi

@@ -270,9 +270,10 @@ class TAPIR:
 
   # ------------------------------------------------------------------ R7
   def get_feature_grids(self, video, is_training: bool = False,
-                        refinement_resolutions: Optional[List[Tuple[int, int]]] = None
-                        ) -> FeatureGrids:
-    """tapir_model.py:626-729."""
+                        refinement_resolutions: Optional[List[Tuple[int, int]]] = None,
+                        _borrow: bool = False) -> FeatureGrids:
+    """tapir_model.py:626-729.  (_borrow: internal -- __call__ consumes the grids before it returns
+    and lets the backbone hand out its graph's own output buffers.)"""
     del is_training
     if self._backbone is None:
       raise RuntimeError('backbone weights (resnet_torch.*) were not loaded')
@@ -296,7 +297,7 @@ class TAPIR:
         curr = resolution
         b, t, h, w, c = video_resize.shape
         low, hi = self._backbone.features(video_resize.reshape(b * t, h, w, c),
-                                          self.feature_extractor_chunk_size)
+                                          self.feature_extractor_chunk_size, borrow=_borrow)
         latent = low.reshape(b, t, *low.shape[1:])
         hires = hi.reshape(b, t, *hi.shape[1:])
       feature_grid.append(latent)
@@ -516,7 +517,7 @@ class TAPIR:
       raise ValueError('Get query feats not supported in TAPIR.')
     numpy_out = _is_numpy(video)
     if feature_grids is None:
-      feature_grids = self.get_feature_grids(video, is_training, refinement_resolutions)
+      feature_grids = self.get_feature_grids(video, is_training, refinement_resolutions, _borrow=True)
     query_features = self.get_query_features(video, is_training, query_points, feature_grids,
                                              refinement_resolutions)
     fg = FeatureGrids(tuple(self._dev(x) for x in feature_grids.lowres),
