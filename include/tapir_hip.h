@@ -225,7 +225,8 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
 
 /* The convolutions of the ResNet blocks (tapnet/models/resnet.py:185-257: self.conv_0 / self.conv_1 /
  * self.proj_conv of BlockV2 with the InstanceNorm + relu in front of them, :241-243 / :248-249, and the
- * residual add :256), bf16 contexts only: one HIP implicit-GEMM kernel per convolution with the
+ * residual add :256): one HIP implicit-GEMM kernel per convolution (bf16 MFMA in bf16 contexts, exact-f32
+ * MFMA in f32 contexts; tensors in the context's element type) with the
  * normalisation of its INPUT folded into the operand load and the residual add + the statistics of its
  * OUTPUT (for the next norm) into the epilogue.  Supported: 3x3 stride 1 with C -> C channels,
  * C in {64,128,256}; 1x1 stride 1 with 64 -> 64 / 256 -> 256; 3x3 and 1x1 stride 2 with 64 -> 128 /
@@ -235,7 +236,8 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * tapir_conv_pack : w = the reference's [cout, cin, ks, ks] f32 kernel (torch OIHW, host memory)
  *   -> device-resident packed fragment streams (owned by the context).
  * tapir_conv_fused: y [N, ceil(H/stride), ceil(W/stride), cout] =
- *   conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut, 3x3 stride 1 only), rounded to bf16.
+ *   conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut, 3x3 stride 1 only), rounded to the
+ *   context's element type.
  *   part_in [N, slabs_in, cin, 2] are (mean, M2) summaries of x per slab of per_s_in pixels
  *   (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
  *   ss: N * cin * 2 floats of scratch owned by the caller (the merged scale / shift); part_out, if not

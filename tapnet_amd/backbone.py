@@ -13,13 +13,13 @@ state_dict names (tapnet/torch/nets.py).
 Runs channels-last (NHWC) so that the feature grids leave in the
 [B,T,h,w,C] layout the HIP kernels read, with no transpose.
 
-GPU only.  bf16 contexts: the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2) are the
-fused HIP kernel of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in its operand load,
-residual add and the next norm's statistics in its epilogue (tapir_conv_fused); the 7x7 stem (and the
-ExtraConvs of BootsTAPIR) run in PyTorch (MIOpen / CK implicit-GEMM, NHWC); statistics of the stem
-output and the final L2 normalisation are the HIP kernels of csrc/backbone.hpp
-(tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  f32 contexts: every convolution through
-MIOpen, the same glue kernels.  From the third call with one shape on, a clip's launches are replayed
+GPU only.  The convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2) are the fused HIP kernel
+of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in its operand load, residual add and the next
+norm's statistics in its epilogue (tapir_conv_fused; bf16 MFMA in bf16 contexts, exact-f32 MFMA in f32
+contexts); the 7x7 stem is a HIP kernel in bf16 contexts and PyTorch (MIOpen) in f32 contexts, the
+ExtraConvs of BootsTAPIR run in PyTorch (MIOpen / CK implicit-GEMM, NHWC); statistics of a MIOpen
+stem's output and the final L2 normalisation are the HIP kernels of csrc/backbone.hpp
+(tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  From the third call with one shape on, a clip's launches are replayed
 from a hipGraph.  There is no CPU path here; the plain PyTorch restatement used by the CPU tests and
 by bench.py's cpu_baseline lives in oracle/backbone_torch.py.
 """
@@ -80,7 +80,7 @@ class Backbone:
     # stem) run as the fused HIP kernel of csrc/conv_fused.hpp where the shape fits it (bf16
     # contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
     self.conv_mode = 'auto'     # 'auto' | 'hip' (any number of frames) | 'miopen'
-    self.hip_min_frames = 4
+    self.hip_min_frames = 4 if dtype == torch.bfloat16 else 1   # (f32 = the parity build: nothing is timed)
     self._hip_now = False
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
     self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
@@ -105,7 +105,7 @@ class Backbone:
       else:             # norm scales / biases stay f32
         t = t.float()
       self.w[k] = t
-    if dtype == torch.bfloat16:
+    if dtype in (torch.bfloat16, torch.float32):
       import ctypes
       import numpy as np
       lib, ctx = engine
@@ -122,7 +122,7 @@ class Backbone:
         if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
           self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
       k = 'resnet_torch.initial_conv.weight'
-      a = weights.get(k)
+      a = weights.get(k) if dtype == torch.bfloat16 else None      # (the stem kernel: bf16 contexts only)
       if a is not None:
         a = np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
         if a.shape == (64, 3, 7, 7):
@@ -213,8 +213,7 @@ class Backbone:
       import ctypes
       lib, ctx = self.engine
       rows, tiles = ctypes.c_int(), ctypes.c_int()
-      ok = (self.dtype == torch.bfloat16 and
-            lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0)
+      ok = lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
       self._plans[key] = (rows.value, tiles.value) if ok else None
     return self._plans[key]
 

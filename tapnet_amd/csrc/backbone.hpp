@@ -185,7 +185,7 @@ struct NormFinalizeArgs {
   float* ss;            // [N, C, 2]: (rstd * gamma, beta - mean * rstd * gamma)
   int HW, C, slabs;
   int per_s;            // pixels per slab (the last one may be shorter); 0 = ceil(HW / slabs)
-  int planar8;          // 1: ss is [N, C / 8, 2, 8] (the 8 scales of a channel chunk, then its 8 shifts)
+  int planar;           // P = 8 | 4: ss is [N, C / P, 2, P] (the P scales of a channel chunk, then its P shifts); 0: [N, C, 2]
 };
 
 // grid (N, C / 64), 256 threads = 64 channels x 4 slab lanes: lane q of a channel merges the slabs
@@ -225,9 +225,10 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinali
     for (int k = 1; k < NORM_FIN_LANES; ++k) merge_stats(cn, mean, m2, s_sum[k][ch][0], s_sum[k][ch][1], s_sum[k][ch][2]);
     const float rstd = 1.0f / sqrtf(m2 / (float)a.HW + kInEps);
     const float sc = rstd * a.gamma[c];
-    const long i0 = a.planar8 ? ((long)n * a.C + (c & ~7)) * 2 + (c & 7) : ((long)n * a.C + c) * 2;
+    const int P = a.planar;
+    const long i0 = P ? ((long)n * a.C + (c & ~(P - 1))) * 2 + (c & (P - 1)) : ((long)n * a.C + c) * 2;
     a.ss[i0] = sc;
-    a.ss[i0 + (a.planar8 ? 8 : 1)] = a.beta[c] - mean * sc;
+    a.ss[i0 + (P ? P : 1)] = a.beta[c] - mean * sc;
   }
 }
 

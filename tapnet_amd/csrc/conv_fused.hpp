@@ -17,7 +17,8 @@
 //       16-byte chunks XOR-swizzled by the pixel index; the taps are constant offsets into it.
 // Workgroup = 4 or 8 waves = (C_out / 64) output-channel groups x pixel groups; a wave owns 64 output
 // channels x NT * 16 pixels (4 x NT accumulator fragments); the tile of a workgroup is `rows` full
-// rows of the OUTPUT image (rows * W_out <= pixel groups * NT * 16).  bf16 build only.
+// rows of the OUTPUT image (rows * W_out <= pixel groups * NT * 16).  Element type bf16 (16x16x32 MFMA) or
+// f32 (the parity build: exact-f32 16x16x4 MFMA, 16 input channels per k-step, tiles half as tall).
 #pragma once
 #include "backbone.hpp"
 #include "gemm.hpp"
@@ -32,13 +33,18 @@ constexpr int cv3_ring(int ks) { return ks == 3 ? 12 : 8; }
 // 8 waves with a 144-KiB tile for the maps whose rows are too long for that.
 constexpr int cv3_lds_bytes(int waves) { return waves * 18 * 1024; }
 
+// element type T = bf16 (the bench build) or float (the parity build: exact-f32 MFMA, same structure)
+template <typename T> struct CvT;
+template <> struct CvT<bf16_t> { static constexpr int EPC = 8, KSTEP = 32; };
+template <> struct CvT<float> { static constexpr int EPC = 4, KSTEP = 16; };
+
 struct Conv3Args {
-  const bf16_t* x;        // [N, H, W, C_in] raw input of the norm
-  const float* ss;        // [N, C_in / 8, 2, 8] (a of 8 channels, b of 8 channels): operand = relu(a * x + b)
+  const void* x;          // [N, H, W, C_in] raw input of the norm (T)
+  const float* ss;        // [N, C_in / EPC, 2, EPC] (a of a 16-byte chunk of channels, then its b): operand = relu(a * x + b)
   const uint4* wstream;   // [C_out / 64][frags_per_cg][64 lanes] packed A fragments (tapir_conv_pack)
   long frags_per_cg;
-  const bf16_t* shortcut; // null, or [N, Ho, Wo, C_out] added before rounding
-  bf16_t* y;              // [N, Ho, Wo, C_out]
+  const void* shortcut;   // null, or [N, Ho, Wo, C_out] added before rounding (T)
+  void* y;                // [N, Ho, Wo, C_out] (T)
   float* part;            // null, or [N, tiles, C_out, 2]: (mean, M2) of the stored values of each tile
   int N, H, W;            // input image
   int Ho, Wo;             // output image = ceil(H / stride), ceil(W / stride)
@@ -48,7 +54,7 @@ struct Conv3Args {
   long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
 };
 
-inline long conv3_frags_per_cg(int cin, int ks) { return (long)ks * ks * (cin / 32) * 4 + cv3_ring(ks); }
+inline long conv3_frags_per_cg(int cin, int ks, int kstep) { return (long)ks * ks * (cin / kstep) * 4 + cv3_ring(ks); }
 
 // XLA SAME: total = max((ceil(n / s) - 1) * s + k - n, 0), low = total / 2
 inline int conv3_pad_lo(int n, int k, int s) {
@@ -65,7 +71,7 @@ inline bool conv3_supported(int cin, int cout, int ks, int stride) {
 
 // output rows per tile / tiles per image / waves per workgroup for an [H, W, C_in] input; false if the
 // shape does not fit the kernel
-inline bool conv3_plan(int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles,
+inline bool conv3_plan(int H, int W, int cin, int cout, int ks, int stride, int esize, int* rows, int* tiles,
                        int* waves = nullptr) {
   if (!conv3_supported(cin, cout, ks, stride) || H < 1 || W < 1) return false;
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
@@ -75,7 +81,7 @@ inline bool conv3_plan(int H, int W, int cin, int cout, int ks, int stride, int*
     const int px = (wv * 64 / cout) * CV3_NT * 16;             // pixels per workgroup
     int th = px / Wo;
     if (th > Ho) th = Ho;
-    while (th >= 1 && ((long)stride * (th - 1) + ks) * in_cols * cin * 2 > cv3_lds_bytes(wv)) --th;
+    while (th >= 1 && ((long)stride * (th - 1) + ks) * in_cols * cin * esize > cv3_lds_bytes(wv)) --th;
     // (a one-row 3x3 tile reads three rows per row of output: take the larger workgroup if it does better)
     if (th < 1 || (th < 2 && wv == 4 && Ho > 1 && ks == 3)) continue;
     *rows = th;
@@ -96,12 +102,13 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
 
 // Epilogue shared by the block convolutions and the stem: the wave's 4 x NT accumulator fragments
 // (lane group g of pixel column c holds channels cg * 64 + 16 g + 4 r + e of pixel qpix[i]) are rounded
-// to bf16 and stored as 2 x 16 bytes per pixel and lane; the (mean, M2) summary of the STORED values of
+// to T and stored as 16-byte pieces (2 for bf16, 4 for f32) per pixel and lane; the (mean, M2) summary of the STORED values of
 // the workgroup's TP pixels goes to part[COUT][2] (Chan merge of the per-wave two-pass summaries).
 // `scratch` = LDS nobody reads any more (WAVES x 64 float2).
-template <int COUT, int NT, int WAVES>
+template <typename T, int COUT, int NT, int WAVES>
 __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const int (&qpix)[NT], int TP,
-                                             bf16_t* ytile, float* part, char* scratch) {
+                                             T* ytile, float* part, char* scratch) {
+  constexpr bool BF = sizeof(T) == 2;
   constexpr int CG = COUT / 64, PG = WAVES / CG;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -111,18 +118,27 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
   float2 (*const s_stat)[64] = reinterpret_cast<float2 (*)[64]>(scratch);   // [wave][channel of the wave]
   const int cnt_w = max(0, min(NT * 16, TP - pg * NT * 16));
   const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
-  uint2 pk[4][NT];
+  uint2 pk[4][NT];                                 // (bf16 only)
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
+    if (BF) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pk[r][i].x = pack_bf16x2(acc[r][i][0], acc[r][i][1]);
-      pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
+      for (int r = 0; r < 4; ++r) {
+        pk[r][i].x = pack_bf16x2(acc[r][i][0], acc[r][i][1]);
+        pk[r][i].y = pack_bf16x2(acc[r][i][2], acc[r][i][3]);
+      }
     }
     if (qpix[i] < TP) {
-      uint4* yp = reinterpret_cast<uint4*>(ytile + (long)qpix[i] * COUT + cg * 64 + 16 * g);
-      yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
-      yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
+      T* yq = ytile + (long)qpix[i] * COUT + cg * 64 + 16 * g;
+      if (BF) {
+        uint4* yp = reinterpret_cast<uint4*>(yq);
+        yp[0] = make_uint4(pk[0][i].x, pk[0][i].y, pk[1][i].x, pk[1][i].y);
+        yp[1] = make_uint4(pk[2][i].x, pk[2][i].y, pk[3][i].x, pk[3][i].y);
+      } else {
+        f32x4* yp = reinterpret_cast<f32x4*>(yq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yp[r] = acc[r][i];
+      }
     }
   }
   if (part == nullptr) return;
@@ -132,11 +148,16 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const bool ok = qpix[i] < TP;
-      const uint2 p = pk[r][i];
-      v[i][0] = ok ? __uint_as_float(p.x << 16) : 0.f;
-      v[i][1] = ok ? __uint_as_float(p.x & 0xffff0000u) : 0.f;
-      v[i][2] = ok ? __uint_as_float(p.y << 16) : 0.f;
-      v[i][3] = ok ? __uint_as_float(p.y & 0xffff0000u) : 0.f;
+      if (BF) {
+        const uint2 p = pk[r][i];
+        v[i][0] = ok ? __uint_as_float(p.x << 16) : 0.f;
+        v[i][1] = ok ? __uint_as_float(p.x & 0xffff0000u) : 0.f;
+        v[i][2] = ok ? __uint_as_float(p.y << 16) : 0.f;
+        v[i][3] = ok ? __uint_as_float(p.y & 0xffff0000u) : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = ok ? acc[r][i][e] : 0.f;
+      }
     }
     float mean[4], m2[4];
 #pragma unroll
@@ -179,16 +200,18 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
   }
 }
 
-template <int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
+template <typename T, int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int EPC = CvT<T>::EPC;
   constexpr int THREADS = WAVES * 64;
   constexpr int CG = COUT / 64, PG = WAVES / CG;
   static_assert(PG >= 1, "a wave owns 64 output channels");
-  constexpr int CB = CIN * 2;                      // bytes per input pixel
-  constexpr int CPP = CIN / 8;                     // 16-byte chunks per input pixel
+  constexpr int CB = CIN * (int)sizeof(T);         // bytes per input pixel
+  constexpr int CPP = CIN / EPC;                   // 16-byte chunks per input pixel
   constexpr int SWZ = (CPP < 16 ? CPP : 16) - 1;
   constexpr int TAPS = KS * KS;
-  constexpr int KPT = CIN / 32;                    // k-steps per tap
+  constexpr int KPT = CIN / CvT<T>::KSTEP;         // k-steps per tap
   constexpr int RING = cv3_ring(KS), G = RING / 4; // k-steps per ring turn
   constexpr int UNR = KS == 3 ? 2 * G : G;         // k-steps per loop trip (even: the B buffers alternate)
   static_assert(UNR % 2 == 0 && UNR % G == 0 && (TAPS * KPT) % UNR == 0, "whole loop trips");
@@ -265,9 +288,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
     for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (HAS_SC) {
       const int qq = qpix[i] < TP ? qpix[i] : 0;
-      const f32x4* sp = reinterpret_cast<const f32x4*>(a.shortcut + (img + qq) * COUT + cg * 64 + 16 * g);
+      const f32x4* sp = reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.shortcut) +
+                                                       (img + qq) * COUT + cg * 64 + 16 * g);
       acc[0][i] = sp[0];
       acc[1][i] = sp[1];
+      if (!BF) { acc[2][i] = sp[2]; acc[3][i] = sp[3]; }   // f32: the 16 channels as they are
     }
   }
 
@@ -278,13 +303,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
     constexpr int PPS = THREADS / CPP;             // pixels per sweep
     constexpr int U = WAVES == 4 ? 18 : 16;        // loads in flight per thread (one trip covers the usual tile)
     const int chunk = tid % CPP, pl = tid / CPP;
-    f32x4 ssv[4];                                  // a[0..3], a[4..7], b[0..3], b[4..7] of this chunk
+    constexpr int NSS = 2 * EPC / 4;               // bf16: a[0..3], a[4..7], b[0..3], b[4..7]; f32: a[0..3], b[0..3]
+    f32x4 ssv[NSS];
     {
-      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * CIN + 8 * chunk) * 2);
+      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * CIN + EPC * chunk) * 2);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ssv[k] = sp[k];
+      for (int k = 0; k < NSS; ++k) ssv[k] = sp[k];
     }
-    const bf16_t* xin = a.x + (long)n * H * W * CIN + 8 * chunk;
+    const T* xin = reinterpret_cast<const T*>(a.x) + (long)n * H * W * CIN + EPC * chunk;
     // tile pixel P = hy * PW + hx walks in steps of PPS without a division per element
     const int dq = PPS / PW, dr = PPS - dq * PW;
     int hy = pl / PW, hx = pl - hy * PW;
@@ -309,18 +335,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
         unsigned r4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const f32x2 xv = f32x2{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xffff0000u)};
-          const f32x2 sa = f32x2{ssv[k >> 1][2 * (k & 1)], ssv[k >> 1][2 * (k & 1) + 1]};
-          const f32x2 sb = f32x2{ssv[2 + (k >> 1)][2 * (k & 1)], ssv[2 + (k >> 1)][2 * (k & 1) + 1]};
-          const f32x2 yv = __builtin_elementwise_fma(xv, sa, sb);
-          r4[k] = relu_bf16x2(pack_bf16x2(yv.x, yv.y)) & m;
+          if (BF) {
+            const f32x2 xv = f32x2{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xffff0000u)};
+            const f32x2 sa = f32x2{ssv[k >> 1][2 * (k & 1)], ssv[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 sb = f32x2{ssv[NSS / 2 + (k >> 1)][2 * (k & 1)], ssv[NSS / 2 + (k >> 1)][2 * (k & 1) + 1]};
+            const f32x2 yv = __builtin_elementwise_fma(xv, sa, sb);
+            r4[k] = relu_bf16x2(pack_bf16x2(yv.x, yv.y)) & m;
+          } else {
+            r4[k] = __float_as_uint(fmaxf(fmaf(__uint_as_float(w4[k]), ssv[0][k], ssv[1][k]), 0.f)) & m;
+          }
         }
         if (off[u] >= 0) *reinterpret_cast<uint4*>(tile + (off[u] & 0x3fffffff)) = make_uint4(r4[0], r4[1], r4[2], r4[3]);
       }
     }
   }
 
-  if (HAS_SC) {
+  if (HAS_SC && BF) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const uint4 s0 = __builtin_bit_cast(uint4, acc[0][i]), s1 = __builtin_bit_cast(uint4, acc[1][i]);
@@ -329,6 +359,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
       acc[0][i] = ok ? bf4(s0.x, s0.y) : zero; acc[1][i] = ok ? bf4(s0.z, s0.w) : zero;
       acc[2][i] = ok ? bf4(s1.x, s1.y) : zero; acc[3][i] = ok ? bf4(s1.z, s1.w) : zero;
     }
+  }
+  if (HAS_SC && !BF) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if (qpix[i] >= TP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
   }
   tick(0);
   lds_barrier();
@@ -362,7 +400,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
         for (int r = 0; r < 4; ++r) {
           const uint4 fa = ring[(kk % G) * 4 + r];
 #pragma unroll
-          for (int i = 0; i < NT; ++i) MfmaStep<bf16_t>::run(fa, cur[i], acc[r][i]);
+          for (int i = 0; i < NT; ++i) MfmaStep<T>::run(fa, cur[i], acc[r][i]);
           ring[(kk % G) * 4 + r] = *wp;
           wp += 64;
           sched_fence();
@@ -376,8 +414,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
   tick(3);
 
   // ---- epilogue: round, store, per-channel (mean, M2) of what was stored
-  cv3_epilogue<COUT, NT, WAVES>(acc, qpix, TP, a.y + img * COUT,
-                                a.part ? a.part + ((long)n * a.tiles + t) * COUT * 2 : nullptr, tile);
+  cv3_epilogue<T, COUT, NT, WAVES>(acc, qpix, TP, reinterpret_cast<T*>(a.y) + img * COUT,
+                                   a.part ? a.part + ((long)n * a.tiles + t) * COUT * 2 : nullptr, tile);
   tick(4);
   if (TRACE && a.dbg_times != nullptr && lane == 0) {
     tick(5);
@@ -387,6 +425,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
   }
 }
 
+template <typename T>
 inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int stride, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block((unsigned)(a.waves * 64));
 #ifdef TAPIR_EXPERIMENTS
@@ -396,15 +435,15 @@ inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int
   constexpr bool kTrace = false;
   const bool trace = false;
 #endif
-#define TAPIR_CV3_SC(CI_, CO_, K_, S_, W_, SC_)                                                                       \
-  do {                                                                                                               \
-    if (trace) hipLaunchKernelGGL((conv_fused_kernel<CI_, CO_, K_, S_, CV3_NT, W_, SC_, kTrace>), grid, block, 0, s, a); \
-    else TAPIR_LAUNCH((conv_fused_kernel<CI_, CO_, K_, S_, CV3_NT, W_, SC_>), grid, block, s, a);                      \
+#define TAPIR_CV3_SC(CI_, CO_, K_, S_, W_, SC_)                                                                          \
+  do {                                                                                                                  \
+    if (trace) hipLaunchKernelGGL((conv_fused_kernel<T, CI_, CO_, K_, S_, CV3_NT, W_, SC_, kTrace>), grid, block, 0, s, a); \
+    else TAPIR_LAUNCH((conv_fused_kernel<T, CI_, CO_, K_, S_, CV3_NT, W_, SC_>), grid, block, s, a);                      \
   } while (0)
   // the shortcut is only ever added by conv_1 (3x3, stride 1, C -> C)
 #define TAPIR_CV3(CI_, CO_, K_, S_)                                                    \
   do {                                                                                 \
-    if (CO_ <= 256 && a.waves == 4) {                                                  \
+    if (a.waves == 4) {                                                                \
       if ((K_) == 3 && (S_) == 1 && a.shortcut) TAPIR_CV3_SC(CI_, CO_, K_, S_, 4, (K_ == 3 && S_ == 1)); \
       else TAPIR_CV3_SC(CI_, CO_, K_, S_, 4, false);                                   \
     } else {                                                                           \
@@ -559,7 +598,7 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
   }
   lds_barrier();
   const long img = ((long)n * a.Ho + r0) * Wo;
-  cv3_epilogue<64, NT, WAVES>(acc, qpix, TP, a.y + img * 64,
+  cv3_epilogue<bf16_t, 64, NT, WAVES>(acc, qpix, TP, a.y + img * 64,
                               a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile);
 }
 

@@ -1192,34 +1192,37 @@ int tapir_l2_normalize(tapir_ctx* c, const void* x, float* out, long pixels, int
 // ---- backbone convolutions (conv_fused.hpp): resnet.py:185-257, conv_0 / conv_1 / proj_conv of BlockV2
 int tapir_conv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles) {
   if (!c || !rows || !tiles) return TAPIR_ERR_INVALID;
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
-  if (!conv3_plan(H, W, cin, cout, ks, stride, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
+  const int es = c->cfg.dtype == TAPIR_BF16 ? 2 : 4;
+  if (!conv3_plan(H, W, cin, cout, ks, stride, es, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
   return TAPIR_OK;
 }
 
 int tapir_conv_pack(tapir_ctx* c, const float* w, int cout, int cin, int ks, void** wstream) {
   if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
   if (!conv3_supported(cin, cout, ks, 1) && !conv3_supported(cin, cout, ks, 2))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: channel counts / kernel size");
   // stream of channel group cg: for tap, k-step, row tile r: fragment row m = l & 15 holds output channel
   // cg*64 + 16 (m >> 2) + 4 r + (m & 3) -- so that lane group g = m >> 2 of the accumulator layout
   // (rows 4 g + e of tile r) owns the 16 consecutive channels 16 g + 4 r + e of its pixel --
-  // input channels 32 ks + 8 (l >> 4) + j
-  const long fpc = conv3_frags_per_cg(cin, ks);
+  // input channels KSTEP kstep + EPC (l >> 4) + j (bf16: 32 per k-step, 8 per lane; f32: 16 / 4)
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  const int kstep_n = bf ? 32 : 16, epc = bf ? 8 : 4;
+  const long fpc = conv3_frags_per_cg(cin, ks, kstep_n);
   const int taps = ks * ks;
   std::vector<uint8_t> host((size_t)(cout / 64) * fpc * 1024, 0);
   for (int cg = 0; cg < cout / 64; ++cg) {
-    uint16_t* q = (uint16_t*)(host.data() + (size_t)cg * fpc * 1024);
+    uint8_t* q = host.data() + (size_t)cg * fpc * 1024;
     for (int tap = 0; tap < taps; ++tap)
-      for (int kstep = 0; kstep < cin / 32; ++kstep)
-        for (int r = 0; r < 4; ++r, q += 512)
+      for (int kstep = 0; kstep < cin / kstep_n; ++kstep)
+        for (int r = 0; r < 4; ++r, q += 1024)
           for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < epc; ++j) {
               const int m = l & 15;
-              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = 32 * kstep + 8 * (l >> 4) + j;
-              q[l * 8 + j] = host_f2bf(w[((size_t)co * cin + ci) * taps + tap]);
+              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = kstep_n * kstep + epc * (l >> 4) + j;
+              const float v = w[((size_t)co * cin + ci) * taps + tap];
+              if (bf) ((uint16_t*)q)[l * epc + j] = host_f2bf(v);
+              else ((float*)q)[l * epc + j] = v;
             }
   }
   void* d = nullptr;
@@ -1236,23 +1239,24 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
                      int cout, int ks, int stride, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: bf16 build only");
   if (!x || !part_in || !gamma || !beta || !ss || !wstream || !y || N < 1 || slabs_in < 1 || per_s_in < 0)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (shortcut && !(ks == 3 && stride == 1)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shortcut on a 3x3 stride-1 convolution only");
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0, waves = 0;
-  if (!conv3_plan(H, W, cin, cout, ks, stride, &rows, &tiles, &waves))
+  if (!conv3_plan(H, W, cin, cout, ks, stride, bf ? 2 : 4, &rows, &tiles, &waves))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
-  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, 1};
+  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, bf ? 8 : 4};
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   Conv3Args ca{};
-  ca.x = (const bf16_t*)x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(cin, ks);
-  ca.shortcut = (const bf16_t*)shortcut; ca.y = (bf16_t*)y; ca.part = part_out;
+  ca.x = x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(cin, ks, bf ? 32 : 16);
+  ca.shortcut = shortcut; ca.y = y; ca.part = part_out;
   ca.N = N; ca.H = H; ca.W = W; ca.Ho = (H + stride - 1) / stride; ca.Wo = (W + stride - 1) / stride;
   ca.pad_y = conv3_pad_lo(H, ks, stride); ca.pad_x = conv3_pad_lo(W, ks, stride);
   ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
   ca.dbg_times = (long long*)c->dbg_times;
-  launch_conv_fused(ca, cin, cout, ks, stride, (hipStream_t)stream);
+  if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+  else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }

@@ -205,12 +205,59 @@ def test_stem_conv(H, W):
   lib.tapir_destroy(ctx)
 
 
-def test_conv_rejects_f32_and_bad_shapes():
+@pytest.mark.parametrize('cin,cout,ks,stride,H,W,shortcut', [
+    (64, 64, 3, 1, 6, 16, True), (128, 128, 3, 1, 5, 12, False), (256, 256, 3, 1, 4, 8, True),
+    (64, 128, 3, 2, 7, 10, False), (128, 256, 1, 2, 6, 8, False), (64, 64, 1, 1, 4, 20, False),
+    (64, 64, 3, 1, 3, 130, True)])      # the 8-wave tile
+def test_conv_fused_f32(cin, cout, ks, stride, H, W, shortcut):
+  """The f32 instantiation (exact-f32 MFMA, the parity build): the same kernel structure against float64
+  numpy at 1e-4 -- no operand rounding anywhere."""
+  lib = emu_lib()
+  ctx = _ctx(lib, _ffi.TAPIR_F32)
+  rng = np.random.default_rng(cin + cout + ks + H)
+  N = 2
+  x = (rng.standard_normal((N, H, W, cin)) * 1.5 + 0.5).astype(np.float32)
+  w = (rng.standard_normal((cout, cin, ks, ks)) / np.sqrt(ks * ks * cin)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+  beta = (rng.standard_normal(cin) * 0.3).astype(np.float32)
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  sc = rng.standard_normal((N, Ho, Wo, cout)).astype(np.float32) if shortcut else None
+  part_in = np.zeros((N, 2, cin, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(x), None, None, _p(part_in), N, H * W, cin, 2, None) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, _p(np.ascontiguousarray(w)), cout, cin, ks, ctypes.byref(ws)) == 0
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, H, W, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  y = np.zeros((N, Ho, Wo, cout), np.float32)
+  part = np.zeros((N, tiles.value, cout, 2), np.float32)
+  ss = np.zeros((N, cin, 2), np.float32)
+  rc = lib.tapir_conv_fused(ctx, _p(x), _p(part_in), 2, 0, _p(gamma), _p(beta), _p(ss), ws, _p(sc), _p(y), _p(part),
+                            N, H, W, cin, cout, ks, stride, None)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  mean = x.mean((1, 2), keepdims=True, dtype=np.float64)
+  var = x.astype(np.float64).var((1, 2), keepdims=True)
+  xn = np.maximum((x - mean) / np.sqrt(var + 1e-5) * gamma + beta, 0)
+  ref = _conv_ref(xn, w, stride)
+  if shortcut:
+    ref = ref + sc
+  np.testing.assert_allclose(y, ref, atol=1e-4, rtol=1e-4)
+  cnt = np.array([min(rows.value, Ho - t * rows.value) * Wo for t in range(tiles.value)], np.float64)
+  pm, pM2 = part[..., 0].astype(np.float64), part[..., 1].astype(np.float64)
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  np.testing.assert_allclose(tot_mean, y.mean((1, 2), dtype=np.float64), atol=1e-5)
+  np.testing.assert_allclose(tot_M2 / (Ho * Wo), y.astype(np.float64).var((1, 2)), rtol=1e-4, atol=1e-6)
+  lib.tapir_destroy(ctx)
+
+
+def test_conv_rejects_bad_shapes():
   lib = emu_lib()
   ctx = _ctx(lib, _ffi.TAPIR_F32)
   rows, tiles = ctypes.c_int(), ctypes.c_int()
   plan = lambda c_, h, w, ci, co, k, s: lib.tapir_conv_plan(c_, h, w, ci, co, k, s, ctypes.byref(rows), ctypes.byref(tiles))
-  assert plan(ctx, 8, 8, 64, 64, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert plan(ctx, 8, 8, 64, 64, 3, 1) == 0                                   # f32 contexts: the same kernels, exact-f32 MFMA
+  assert plan(ctx, 128, 128, 64, 64, 3, 1) == 0 and rows.value >= 1
+  assert lib.tapir_stem_plan(ctx, 64, 64, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED   # stem: bf16 only
   lib.tapir_destroy(ctx)
   ctx = _ctx(lib)
   assert plan(ctx, 8, 8, 96, 96, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED

@@ -151,6 +151,60 @@ def test_stem_conv_vs_torch(model, n, h, w):
   assert torch.allclose(tot_M2 / (ho * wo), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,ks,stride,shortcut', [
+    (3, 64, 64, 64, 64, 3, 1, True), (2, 32, 32, 128, 128, 3, 1, False), (2, 32, 32, 256, 256, 3, 1, True),
+    (2, 64, 64, 64, 128, 3, 2, False), (2, 32, 32, 128, 256, 1, 2, False), (2, 25, 31, 64, 128, 3, 2, False),
+    (1, 128, 128, 64, 64, 3, 1, True)])
+def test_conv_fused_f32_vs_torch(n, h, w, cin, cout, ks, stride, shortcut):
+  """The f32 instantiation of the same kernel (exact-f32 MFMA; what the f32 parity build's backbone runs)
+  against torch f32: no operand rounding, so the tolerance is 2e-4 absolute on values of a few units."""
+  from tapnet_amd import tapir_model
+  from tapnet_amd.backbone import _same_pad
+  m32 = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=synthetic.make_weights(21, 1, False, backbone=False),
+                          device='cuda:0', dtype='float32')
+  lib, ctx = m32._lib, m32._ctx
+  dev = m32.device
+  g = torch.Generator(device='cpu').manual_seed(h + cin + ks)
+  x = (torch.randn(n, h, w, cin, generator=g) * 1.5 + 0.5).to(dev)
+  wt = (torch.randn(cout, cin, ks, ks, generator=g) / (ks * ks * cin) ** 0.5).contiguous()
+  gamma = (torch.rand(cin, generator=g) + 0.5).to(dev)
+  beta = (torch.randn(cin, generator=g) * 0.3).to(dev)
+  ho, wo = -(-h // stride), -(-w // stride)
+  sc = torch.randn(n, ho, wo, cout, generator=g).to(dev) if shortcut else None
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  part_in = torch.empty(n, 4, cin, 2, device=dev)
+  stream = m32._stream()
+  assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, cin, 4, stream) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), cout, cin, ks, ctypes.byref(ws)) == 0
+  y = torch.zeros(n, ho, wo, cout, device=dev)
+  part = torch.zeros(n, tiles.value, cout, 2, device=dev)
+  ss = torch.empty(n, cin, 2, device=dev)
+  rc = lib.tapir_conv_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(),
+                            ss.data_ptr(), ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(),
+                            n, h, w, cin, cout, ks, stride, stream)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  torch.cuda.synchronize()
+  xd = x.double()
+  mean = xd.mean((1, 2), keepdim=True)
+  var = xd.var((1, 2), keepdim=True, unbiased=False)
+  xn = torch.relu((xd - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double())
+  ref = F.conv2d(_same_pad(xn.permute(0, 3, 1, 2), ks, stride), wt.double().to(dev), stride=stride).permute(0, 2, 3, 1)
+  if shortcut:
+    ref = ref + sc.double()
+  d = (y.double() - ref).abs()
+  assert float(d.max()) < 2e-4, float(d.max())
+  gd = y.double()
+  cnt = torch.tensor([min(rows.value, ho - t * rows.value) * wo for t in range(tiles.value)], device=dev,
+                     dtype=torch.float64)
+  pm, pM2 = part[..., 0].double(), part[..., 1].double()
+  tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
+  tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
+  assert torch.allclose(tot_mean, gd.mean((1, 2)), atol=1e-5)
+  assert torch.allclose(tot_M2 / (ho * wo), gd.var((1, 2), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('size', [256, 200])
 def test_backbone_fused_convs_vs_miopen(model, size):
   """Backbone.features of the bf16 model with the HIP convolutions and with every convolution on MIOpen,
@@ -165,7 +219,12 @@ def test_backbone_fused_convs_vs_miopen(model, size):
   frames = torch.as_tensor(synthetic.make_video(3, 6, size, size), device=model.device)
   frames = frames.reshape(-1, size, size, 3).float()
   assert bb._wstream, 'the 3x3 kernels were not packed for the HIP convolution'
+  m32._backbone.conv_mode = 'miopen'
   ref = [t.clone() for t in m32._backbone.features(frames)]
+  m32._backbone.conv_mode = 'auto'       # the f32 build's own HIP convolutions against the library's
+  assert m32._backbone._wstream
+  for r, a in zip(ref, m32._backbone.features(frames)):
+    assert float((r - a).abs().max()) < 2e-5, float((r - a).abs().max())
   bb.conv_mode = 'miopen'
   mio = [t.clone() for t in bb.features(frames)]
   bb.conv_mode = 'auto'
