@@ -249,9 +249,9 @@ int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int sl
                      const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                      int cout, int ks, int stride, void* stream);
 
-/* The stem of the ResNet (resnet.py:356-364: initial_conv, 7x7 / stride 2 / SAME, 3 -> 64 channels), bf16
- * contexts: x = the f32 frames [N,H,W,3] as the model receives them (rounded to bf16 on load, as the
- * library path's cast does), y [N, ceil(H/2), ceil(W/2), 64] bf16, part_out [N, tiles, 64, 2] the
+/* The stem of the ResNet (resnet.py:356-364: initial_conv, 7x7 / stride 2 / SAME, 3 -> 64 channels):
+ * x = the f32 frames [N,H,W,3] as the model receives them (bf16 contexts: rounded to bf16 on load, as the
+ * library path's cast does), y [N, ceil(H/2), ceil(W/2), 64] in the context's element type, part_out [N, tiles, 64, 2] the
  * (mean, M2) summaries of y per tile of rows * W_out pixels (input of the first InstanceNorm).
  * tapir_stem_pack takes the reference's [64, 3, 7, 7] f32 kernel (host memory). */
 int tapir_stem_plan(tapir_ctx* ctx, int H, int W, int* rows, int* tiles);

@@ -16,9 +16,10 @@ Runs channels-last (NHWC) so that the feature grids leave in the
 GPU only.  The convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2) are the fused HIP kernel
 of tapnet_amd/csrc/conv_fused.hpp -- InstanceNorm + ReLU in its operand load, residual add and the next
 norm's statistics in its epilogue (tapir_conv_fused; bf16 MFMA in bf16 contexts, exact-f32 MFMA in f32
-contexts); the 7x7 stem is a HIP kernel in bf16 contexts and PyTorch (MIOpen) in f32 contexts, the
-ExtraConvs of BootsTAPIR run in PyTorch (MIOpen / CK implicit-GEMM, NHWC); statistics of a MIOpen
-stem's output and the final L2 normalisation are the HIP kernels of csrc/backbone.hpp
+contexts) and so is the 7x7 stem (tapir_stem_conv); only the ExtraConvs of BootsTAPIR run in PyTorch
+(MIOpen / CK implicit-GEMM, NHWC); what is left between the kernels (the merge of the tile summaries,
+the final L2 normalisation; the statistics / normalise kernels behind a convolution whose shape does
+not fit the HIP kernel and goes to MIOpen) are the HIP kernels of csrc/backbone.hpp
 (tapir_inorm_stats / tapir_inorm_relu / tapir_l2_normalize).  From the third call with one shape on, a clip's launches are replayed
 from a hipGraph.  There is no CPU path here; the plain PyTorch restatement used by the CPU tests and
 by bench.py's cpu_baseline lives in oracle/backbone_torch.py.
@@ -122,7 +123,7 @@ class Backbone:
         if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
           self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
       k = 'resnet_torch.initial_conv.weight'
-      a = weights.get(k) if dtype == torch.bfloat16 else None      # (the stem kernel: bf16 contexts only)
+      a = weights.get(k)
       if a is not None:
         a = np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
         if a.shape == (64, 3, 7, 7):

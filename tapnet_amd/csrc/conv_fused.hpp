@@ -482,32 +482,42 @@ inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int
 // B fragment of (pixel x, kernel row ky, lane group g) is the 8 values at row 2 y + ky, element
 // 6 x + 8 g -- a 4-byte aligned address, read as four ds_read_b32; the values past the 21st multiply
 // zero weights.  Frames are f32 (the model's input), rounded to bf16 on the way into LDS like the
-// library path's cast; 4 waves x (64 output channels x 64 pixels), two workgroups per CU.
+// library path's cast (f32 contexts: an f32 image, two k-steps of 16 per kernel row); 4 waves x
+// (64 output channels x 64 pixels), two workgroups per CU.
 constexpr int STEM_WAVES = 4;
-constexpr int STEM_LDS_BYTES = 32 * 1024;
+constexpr int STEM_LDS_BYTES = 64 * 1024;
 
 struct StemArgs {
   const float* x;         // [N, H, W, 3] f32
-  const uint4* wstream;   // [7 + ring][4][64 lanes] packed A fragments (tapir_stem_pack)
-  bf16_t* y;              // [N, Ho, Wo, 64]
+  const uint4* wstream;   // [7 * ksub + ring][4][64 lanes] packed A fragments (tapir_stem_pack)
+  void* y;                // [N, Ho, Wo, 64] (the context's element type)
   float* part;            // null, or [N, tiles, 64, 2]
   int N, H, W, Ho, Wo, pad_y, pad_x, TH, tiles;
 };
 
-inline bool stem_plan(int H, int W, int* rows, int* tiles) {
+// bytes per LDS row of the input image: (2 Wo + 5) pixels x 3 channels + 64 bytes of slack for the padded k
+inline long stem_row_bytes(int Wo, int esize) { return ((long)(2 * (Wo - 1) + 7) * 3 * esize + 64 + 15) / 16 * 16; }
+
+inline bool stem_plan(int H, int W, int esize, int* rows, int* tiles) {
   if (H < 1 || W < 2 || (W & 1)) return false;     // (pairs of f32 are loaded: even rows of 3 W values)
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int th = (STEM_WAVES * CV3_NT * 16) / Wo;
   if (th > Ho) th = Ho;
-  auto bytes = [&](int t) { return (long)(2 * (t - 1) + 7) * ((((2 * (Wo - 1) + 7) * 6 + 64) + 15) / 16 * 16); };
-  while (th >= 1 && bytes(th) > STEM_LDS_BYTES) --th;
+  while (th >= 1 && (2 * (th - 1) + 7) * stem_row_bytes(Wo, esize) > STEM_LDS_BYTES) --th;
   if (th < 1) return false;
   *rows = th;
   *tiles = (Ho + th - 1) / th;
   return true;
 }
 
+// T = bf16: the frames are rounded to bf16 into the LDS image, one k-step of 32 per kernel row;
+// T = float (parity build): f32 image, two k-steps of 16 per kernel row, exact-f32 MFMA.
+template <typename T>
 __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs a) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int ES = (int)sizeof(T), EPC = CvT<T>::EPC, KSTEP = CvT<T>::KSTEP;
+  constexpr int KSUB = 32 / KSTEP;                 // k-steps per kernel row
+  constexpr int NK = 7 * KSUB;
   constexpr int NT = CV3_NT, WAVES = STEM_WAVES, THREADS = WAVES * 64, RING = 8;
   __shared__ uint4 s_tile[STEM_LDS_BYTES / 16];
   const int tid = threadIdx.x;
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
   const int n = bid / a.tiles, t = bid - n * a.tiles;
   const int H = a.H, W = a.W, Wo = a.Wo;
   const int PW = 2 * (Wo - 1) + 7;                 // input columns of the tile
-  const int RS = ((PW * 6 + 64) + 15) / 16 * 16;   // bytes per LDS row (64 bytes of slack for the padded k)
+  const int RS = (PW * 3 * ES + 64 + 15) / 16 * 16;   // bytes per LDS row (stem_row_bytes)
   const int r0 = t * a.TH;
   const int rows = min(a.TH, a.Ho - r0);
   const int in_rows = 2 * (rows - 1) + 7;
@@ -541,12 +551,12 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
     qpix[i] = q;
     const int qq = q < TP ? q : 0;
     const int yy = qq / Wo, xx = qq - yy * Wo;
-    Pb[i] = 2 * yy * RS + 12 * xx + 16 * g;
+    Pb[i] = 2 * yy * RS + 6 * ES * xx + 16 * g;
   }
 
-  // ---- stage the input rows: pairs of f32 -> packed bf16 (zero outside the image and in the slack)
+  // ---- stage the input rows, a pair of f32 per thread and trip (zero outside the image and in the slack)
   {
-    const int pairs = RS / 4;
+    const int pairs = RS / (2 * ES);
     const float* xin = a.x + (long)n * H * W * 3;
     for (int hy = 0; hy < in_rows; ++hy) {
       const int y = y0 + hy;
@@ -557,7 +567,8 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
         const bool ok = yok && ge >= 0 && ge + 1 < 3 * W && 2 * p < PW * 3 + 1;
         float2 v = make_float2(0.f, 0.f);
         if (ok) v = *reinterpret_cast<const float2*>(rowp + ge);
-        *reinterpret_cast<unsigned*>(tile + hy * RS + 4 * p) = pack_bf16x2(v.x, v.y);
+        if (BF) *reinterpret_cast<unsigned*>(tile + hy * RS + 4 * p) = pack_bf16x2(v.x, v.y);
+        else *reinterpret_cast<float2*>(tile + hy * RS + 8 * p) = v;
       }
     }
   }
@@ -568,11 +579,13 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
     for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   lds_barrier();
 
-  // ---- 7 k-steps (kernel rows); B fragments one step ahead
-  auto read_b = [&](int ky, uint4 (&fb)[NT]) {
+  // ---- 7 kernel rows x KSUB k-steps; B fragments one step ahead (the address 6 ES x + 16 g is only
+  // 4-byte aligned for bf16: four ds_read_b32)
+  auto read_b = [&](int ks, uint4 (&fb)[NT]) {
+    const int off = (ks / KSUB) * RS + (ks % KSUB) * KSTEP * ES;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const unsigned* p = reinterpret_cast<const unsigned*>(tile + Pb[i] + ky * RS);
+      const unsigned* p = reinterpret_cast<const unsigned*>(tile + Pb[i] + off);
       fb[i] = make_uint4(p[0], p[1], p[2], p[3]);
     }
   };
@@ -580,17 +593,17 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
     uint4 fb0[NT], fb1[NT];
     read_b(0, fb0);
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-      uint4 (&nxt)[NT] = (ky & 1) ? fb0 : fb1;
-      uint4 (&cur)[NT] = (ky & 1) ? fb1 : fb0;
-      read_b(ky < 6 ? ky + 1 : 0, nxt);
+    for (int ks = 0; ks < NK; ++ks) {
+      uint4 (&nxt)[NT] = (ks & 1) ? fb0 : fb1;
+      uint4 (&cur)[NT] = (ks & 1) ? fb1 : fb0;
+      read_b(ks + 1 < NK ? ks + 1 : 0, nxt);
       sched_fence();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint4 fa = ring[(ky & 1) * 4 + r];
+        const uint4 fa = ring[(ks & 1) * 4 + r];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) MfmaStep<bf16_t>::run(fa, cur[i], acc[r][i]);
-        ring[(ky & 1) * 4 + r] = *wp;
+        for (int i = 0; i < NT; ++i) MfmaStep<T>::run(fa, cur[i], acc[r][i]);
+        ring[(ks & 1) * 4 + r] = *wp;
         wp += 64;
         sched_fence();
       }
@@ -598,13 +611,14 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
   }
   lds_barrier();
   const long img = ((long)n * a.Ho + r0) * Wo;
-  cv3_epilogue<bf16_t, 64, NT, WAVES>(acc, qpix, TP, a.y + img * 64,
-                              a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile);
+  cv3_epilogue<T, 64, NT, WAVES>(acc, qpix, TP, reinterpret_cast<T*>(a.y) + img * 64,
+                                 a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile);
 }
 
+template <typename T>
 inline void launch_stem_conv(const StemArgs& a, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((a.N * a.tiles + 7) / 8))), block(STEM_WAVES * 64);
-  TAPIR_LAUNCH(stem_conv_kernel, grid, block, s, a);
+  TAPIR_LAUNCH((stem_conv_kernel<T>), grid, block, s, a);
 }
 
 }  // namespace tapir

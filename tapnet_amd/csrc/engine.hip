@@ -1264,27 +1264,32 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
 // ---- the 7x7 / stride-2 stem (resnet.py:356-364)
 int tapir_stem_plan(tapir_ctx* c, int H, int W, int* rows, int* tiles) {
   if (!c || !rows || !tiles) return TAPIR_ERR_INVALID;
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: bf16 build only");
-  if (!stem_plan(H, W, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: shape");
+  if (!stem_plan(H, W, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: shape");
   return TAPIR_OK;
 }
 
 int tapir_stem_pack(tapir_ctx* c, const float* w, void** wstream) {
   if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: bf16 build only");
-  // w [64, 3, 7, 7] (OIHW).  k-step ky, row tile r: fragment row m holds output channel 16 (m >> 2) + 4 r + (m & 3)
-  // (the permutation of the epilogue); k = 8 (l >> 4) + j = 3 kx + ci for k < 21, zero beyond
-  const long nfr = 7 * 4 + 8;
+  // w [64, 3, 7, 7] (OIHW).  Kernel row ky, k-step sub, row tile r: fragment row m holds output channel
+  // 16 (m >> 2) + 4 r + (m & 3) (the permutation of the epilogue); k = KSTEP sub + EPC (l >> 4) + j = 3 kx + ci
+  // for k < 21, zero beyond
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  const int kstep_n = bf ? 32 : 16, epc = bf ? 8 : 4, ksub = 32 / kstep_n;
+  const long nfr = 7 * ksub * 4 + 8;
   std::vector<uint8_t> host((size_t)nfr * 1024, 0);
-  uint16_t* q = (uint16_t*)host.data();
+  uint8_t* q = host.data();
   for (int ky = 0; ky < 7; ++ky)
-    for (int r = 0; r < 4; ++r, q += 512)
-      for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 8; ++j) {
-          const int m = l & 15, co = 16 * (m >> 2) + 4 * r + (m & 3), k = 8 * (l >> 4) + j;
-          if (k < 21) q[l * 8 + j] = host_f2bf(w[(((size_t)co * 3 + k % 3) * 7 + ky) * 7 + k / 3]);
-        }
+    for (int sub = 0; sub < ksub; ++sub)
+      for (int r = 0; r < 4; ++r, q += 1024)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < epc; ++j) {
+            const int m = l & 15, co = 16 * (m >> 2) + 4 * r + (m & 3), k = kstep_n * sub + epc * (l >> 4) + j;
+            if (k >= 21) continue;
+            const float v = w[(((size_t)co * 3 + k % 3) * 7 + ky) * 7 + k / 3];
+            if (bf) ((uint16_t*)q)[l * epc + j] = host_f2bf(v);
+            else ((float*)q)[l * epc + j] = v;
+          }
   void* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, host.size()));
   c->owned.push_back(d);
@@ -1297,16 +1302,17 @@ int tapir_stem_conv(tapir_ctx* c, const float* x, const void* wstream, void* y, 
                     int W, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: bf16 build only");
   if (!x || !wstream || !y || N < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0;
-  if (!stem_plan(H, W, &rows, &tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: shape");
+  if (!stem_plan(H, W, bf ? 2 : 4, &rows, &tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: shape");
   StemArgs sa{};
-  sa.x = x; sa.wstream = (const uint4*)wstream; sa.y = (bf16_t*)y; sa.part = part_out;
+  sa.x = x; sa.wstream = (const uint4*)wstream; sa.y = y; sa.part = part_out;
   sa.N = N; sa.H = H; sa.W = W; sa.Ho = (H + 1) / 2; sa.Wo = (W + 1) / 2;
   sa.pad_y = conv3_pad_lo(H, 7, 2); sa.pad_x = conv3_pad_lo(W, 7, 2);
   sa.TH = rows; sa.tiles = tiles;
-  launch_stem_conv(sa, (hipStream_t)stream);
+  if (bf) launch_stem_conv<bf16_t>(sa, (hipStream_t)stream);
+  else launch_stem_conv<float>(sa, (hipStream_t)stream);
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }

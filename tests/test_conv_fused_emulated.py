@@ -173,12 +173,14 @@ def test_strided_and_projection_convs(cin, cout, ks, stride, H, W):
   lib.tapir_destroy(ctx)
 
 
+@pytest.mark.parametrize('dtype', [_ffi.TAPIR_BF16, _ffi.TAPIR_F32])
 @pytest.mark.parametrize('H,W', [(16, 32), (9, 12), (6, 300)])
-def test_stem_conv(H, W):
-  """7x7 / stride 2 / SAME stem (resnet.py:356-364) on f32 frames, against numpy on the bf16-rounded
-  operands; summaries of the stored output."""
+def test_stem_conv(H, W, dtype):
+  """7x7 / stride 2 / SAME stem (resnet.py:356-364) on f32 frames, against numpy (on the bf16-rounded
+  operands for the bf16 build; the f32 build at 1e-4); summaries of the stored output."""
   lib = emu_lib()
-  ctx = _ctx(lib)
+  ctx = _ctx(lib, dtype)
+  bf = dtype == _ffi.TAPIR_BF16
   rng = np.random.default_rng(H + W)
   N = 2
   x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
@@ -188,14 +190,19 @@ def test_stem_conv(H, W):
   ws = ctypes.c_void_p()
   assert lib.tapir_stem_pack(ctx, _p(w), ctypes.byref(ws)) == 0
   Ho, Wo = -(-H // 2), -(-W // 2)
-  y = np.zeros((N, Ho, Wo, 64), np.uint16)
+  y = np.zeros((N, Ho, Wo, 64), np.uint16 if bf else np.float32)
   part = np.zeros((N, tiles.value, 64, 2), np.float32)
   rc = lib.tapir_stem_conv(ctx, _p(x), ws, _p(y), _p(part), N, H, W, None)
   assert rc == 0, lib.tapir_last_error(ctx)
-  ref = _conv_ref(_r(x), _r(w), 2)
-  got = from_bf16_bits(y)
-  np.testing.assert_allclose(got, ref, atol=1e-2, rtol=1e-2)
-  assert np.abs(got - ref).mean() < 1e-3
+  if bf:
+    ref = _conv_ref(_r(x), _r(w), 2)
+    got = from_bf16_bits(y)
+    np.testing.assert_allclose(got, ref, atol=1e-2, rtol=1e-2)
+    assert np.abs(got - ref).mean() < 1e-3
+  else:
+    ref = _conv_ref(x, w, 2)
+    got = y
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
   cnt = np.array([min(rows.value, Ho - t * rows.value) * Wo for t in range(tiles.value)], np.float64)
   pm, pM2 = part[..., 0].astype(np.float64), part[..., 1].astype(np.float64)
   tot_mean = (pm * cnt[None, :, None]).sum(1) / cnt.sum()
@@ -257,7 +264,8 @@ def test_conv_rejects_bad_shapes():
   plan = lambda c_, h, w, ci, co, k, s: lib.tapir_conv_plan(c_, h, w, ci, co, k, s, ctypes.byref(rows), ctypes.byref(tiles))
   assert plan(ctx, 8, 8, 64, 64, 3, 1) == 0                                   # f32 contexts: the same kernels, exact-f32 MFMA
   assert plan(ctx, 128, 128, 64, 64, 3, 1) == 0 and rows.value >= 1
-  assert lib.tapir_stem_plan(ctx, 64, 64, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED   # stem: bf16 only
+  assert lib.tapir_stem_plan(ctx, 64, 64, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  assert lib.tapir_stem_plan(ctx, 64, 63, ctypes.byref(rows), ctypes.byref(tiles)) == _ffi.TAPIR_ERR_UNSUPPORTED   # odd width
   lib.tapir_destroy(ctx)
   ctx = _ctx(lib)
   assert plan(ctx, 8, 8, 96, 96, 3, 1) == _ffi.TAPIR_ERR_UNSUPPORTED
