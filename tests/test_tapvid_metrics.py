@@ -78,3 +78,28 @@ def test_evaluate_driver_with_a_perfect_tracker():
     assert abs(good['average_jaccard'] - 1.0) < 1e-9 and abs(good['occlusion_accuracy'] - 1.0) < 1e-9
     bad = tapvid.evaluate(Oracle(ex, blind=True), [('clip', ex)], query_mode=mode)
     assert bad['average_jaccard'] == 0.0
+
+
+def test_davis_examples_resize_is_uint8_lanczos(tmp_path):
+  """tapvid/evaluation_datasets.py:41-45: frames are resized as uint8 with PIL's Lanczos filter (what
+  mediapy.resize_video does for uint8 videos) BEFORE the / 255 * 2 - 1 scaling: the scaled frames sit on the
+  uint8 grid and equal a direct PIL resize."""
+  import pickle
+  from PIL import Image
+  rng = np.random.default_rng(0)
+  video = rng.integers(0, 256, (3, 40, 56, 3), dtype=np.uint8)
+  pts = rng.uniform(0, 1, (5, 3, 2))
+  occ = rng.random((5, 3)) < 0.3
+  occ[:, 0] = False
+  path = tmp_path / 'davis.pkl'
+  with open(path, 'wb') as f:
+    pickle.dump({'clip': dict(video=video, points=pts, occluded=occ)}, f)
+  (name, ex), = list(tapvid.davis_examples(str(path), 'first', (32, 48)))
+  frames = ex['video'][0]
+  assert frames.shape == (3, 32, 48, 3) and frames.dtype == np.float32
+  u8 = np.round((frames + 1.0) * 127.5)
+  np.testing.assert_allclose((frames + 1.0) * 127.5, u8, atol=1e-3)          # on the uint8 grid
+  ref = np.stack([np.asarray(Image.fromarray(f).resize((48, 32), resample=Image.Resampling.LANCZOS)) for f in video])
+  np.testing.assert_array_equal(u8.astype(np.uint8), ref)
+  # same size: untouched
+  np.testing.assert_array_equal(tapvid.resize_video(video, (40, 56)), video)
