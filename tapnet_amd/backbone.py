@@ -359,14 +359,22 @@ class Backbone:
           self._graphs.pop(next(iter(self._graphs)))
         ent = self._graphs[key] = {'seen': 0}
       ent['seen'] += 1
-      if 'graph' not in ent and ent['seen'] >= 3:
+      if 'graph' not in ent and not ent.get('failed') and ent['seen'] >= 3:
         ent['in'] = frames_nhwc.contiguous().clone()
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):   # (the side streams fork from and join the capturing stream)
-          self._run_groups(ent['in'], ent['low'], ent['hi'], bounds, streams)
-        ent['graph'] = g
+        try:
+          g = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g):   # (the side streams fork from and join the capturing stream)
+            self._run_groups(ent['in'], ent['low'], ent['hi'], bounds, streams)
+          ent['graph'] = g
+        except RuntimeError as e:     # e.g. another thread touched the device during the capture
+          import warnings
+          warnings.warn(f'tapnet_amd.backbone: hipGraph capture failed ({e}); launching eagerly')
+          ent['failed'] = True
+          for k in ('in', 'low', 'hi'):
+            ent.pop(k, None)
+          torch.cuda.synchronize(self.device)
       if 'graph' in ent:
         ent['in'].copy_(frames_nhwc)
         ent['graph'].replay()
