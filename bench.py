@@ -8,6 +8,7 @@ query features -> cost volume -> 4 PIPs iterations in HIP) with the clip
 already resident in HBM.  points/s = clips * queries / seconds.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 ...        # spawns the 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU (weak scaling, default): every rank tracks its own clip x 256 queries;
@@ -28,6 +29,8 @@ together (frame-sharded backbone, all-gather of the grids, query-sharded hot pat
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -65,6 +68,50 @@ def parse():
   return ap.parse_args()
 
 
+def self_launch(args):
+  """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one
+  process per GPU, exactly as the driver's command line does (torch.distributed.run, rendezvous on
+  127.0.0.1).  Returns the launcher's exit code; rank 0 of the child job prints the JSON line."""
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def reference_torch_cpu(args, kw, weights, video_np, qpts_np):
+  """The reference's own CPU path (tapnet/torch/tapir_model.py TAPIR.forward; JAX is not installable
+  offline) at the FULL workload on this host's cores: 1 warm-up + 1 timed call (~12 s each on 8 cores).
+  Only where the reference tree exists ($TAPNET_REFERENCE or /root/reference: the build container)."""
+  root = os.environ.get('TAPNET_REFERENCE', '/root/reference')
+  if not os.path.isdir(os.path.join(root, 'tapnet', 'torch')):
+    return None
+  try:
+    from oracle.ref_import import import_reference
+    tm, _, _ = import_reference()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = tm.TAPIR(pyramid_level=kw['pyramid_level'], extra_convs=kw['extra_convs'],
+                     softmax_temperature=kw['softmax_temperature'],
+                     initial_resolution=(args.size, args.size)).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    v, q = torch.from_numpy(video_np), torch.from_numpy(qpts_np)
+    times = []
+    with torch.no_grad():
+      for _ in range(2):
+        t0 = time.perf_counter()
+        model(v, q)
+        times.append(time.perf_counter() - t0)
+    return dict(value=round(qpts_np.shape[1] / times[-1], 3), unit='points/s', cores=cores, kind='reference',
+                seconds=round(times[-1], 2), measured='live on this host (1 warm-up + 1 timed call, full workload)')
+  except Exception as e:   # the reference is not part of the product: never fail the bench over it
+    return dict(error=f'{type(e).__name__}: {e}')
+
+
 def cpu_baseline(args, kw, weights, video, qpts):
   """The oracle (numpy port of the reference hot path) + the backbone restatement on torch-CPU,
   timed on this host's cores on a bounded sample and extrapolated linearly to the workload:
@@ -100,18 +147,26 @@ def cpu_baseline(args, kw, weights, video, qpts):
              sample=f'backbone (torch-CPU restatement) on {sf}/{T} frames + numpy oracle hot path '
                     f'on {sq}/{Q} queries x {T} frames, extrapolated per-frame / per-query',
              backbone_s=round(t_bb, 2), hot_path_s=round(t_hot, 2))
-  # the reference's own CPU path (tapnet/torch/tapir_model.py; JAX is not installable offline) cannot
-  # travel to the GPU box: its timing at this workload was taken in the build container
-  # (oracle/time_reference_cpu.py) and is quoted with the host it ran on
-  ref = os.path.join(ROOT, 'profiles', f'r02_reference_torch_cpu_{args.model}.json')
-  if os.path.exists(ref) and (T, Q, args.size) == (48, 256, 256):
-    try:
-      r = json.load(open(ref))
-      out['reference_torch'] = dict(value=r['points_per_s'], unit='points/s', cores=r['cores'],
-                                    cpu=r['cpu'], median_s=r['median_s'], host=r['host'],
-                                    artefact=os.path.relpath(ref, ROOT))
-    except Exception:
-      pass
+  # the reference's own CPU path (tapnet/torch/tapir_model.py; JAX is not installable offline): timed
+  # live where the reference tree exists; it cannot travel to the GPU box, where the number measured in
+  # the build container (oracle/time_reference_cpu.py) is quoted instead and LABELLED as static
+  live = reference_torch_cpu(args, kw, weights, video, qpts)
+  if live is not None:
+    out['reference_torch'] = live
+  else:
+    ref = os.path.join(ROOT, 'profiles', f'r02_reference_torch_cpu_{args.model}.json')
+    if os.path.exists(ref) and (T, Q, args.size) == (48, 256, 256):
+      try:
+        r = json.load(open(ref))
+        out['reference_torch'] = dict(value=r['points_per_s'], unit='points/s', cores=r['cores'],
+                                      cpu=r['cpu'], median_s=r['median_s'], host=r['host'],
+                                      measured='STATIC: not timed in this run (no reference tree on this host); '
+                                               'quoted from ' + os.path.relpath(ref, ROOT),
+                                      artefact=os.path.relpath(ref, ROOT))
+      except Exception:
+        pass
+  out['note'] = ('kind=port is the numpy oracle, ~3x slower than the reference\'s torch CPU path: no GPU/CPU '
+                 'speed-up should be quoted against it; reference_torch is the comparable CPU number')
   return out
 
 
@@ -137,14 +192,33 @@ def accuracy_vs_f32(kw, weights, dev, video, qpts, out16):
 
 def main():
   args = parse()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  ndev = torch.cuda.device_count()
+  # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  With fewer devices than ranks (the 1-GPU test
+  # box: correctness only) the ranks share devices and the collectives go through gloo with host staging
+  # -- RCCL refuses two ranks on one device -- and the line says so.
+  oversubscribed = world > 1 and ndev < world
+  backend = 'gloo' if oversubscribed else 'nccl'
+  dev = torch.device('cuda', local_rank % max(ndev, 1))
+  torch.cuda.set_device(dev)
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+    if oversubscribed:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=dev)
+
+  def max_over_ranks(v):
+    if world == 1:
+      return v
+    import torch.distributed as dist
+    tt = torch.tensor([v], dtype=torch.float64, device='cpu' if oversubscribed else dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
   from tapnet_amd import distributed as tdist
   from tapnet_amd import synthetic, tapir_model
@@ -159,8 +233,11 @@ def main():
   video = torch.as_tensor(video_np, device=dev)
   qpts = torch.as_tensor(qpts_np, device=dev)
 
+  # wire format of the feature-grid all-gather: the operand type of the hot path (bf16 build: bf16,
+  # 75 MB per 48-frame clip instead of 151 MB; SURVEY.md 8e sizes the exchange in bf16)
+  grid_dtype = torch.bfloat16 if dtype == 'bfloat16' else None
   if args.shard == 'queries' and world > 1:
-    step = lambda: tdist.sharded_call(model, video, qpts)
+    step = lambda: tdist.sharded_call(model, video, qpts, grid_dtype=grid_dtype)
   else:
     step = lambda: model(video, False, qpts)
 
@@ -203,12 +280,8 @@ def main():
     if k != dom:
       prof[k] = v
   model.profile_enable(False)
-  if world > 1:
-    import torch.distributed as dist
-    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-  assert torch.isfinite(out['tracks']).all()
+  elapsed = max_over_ranks(elapsed)
+  assert torch.isfinite(torch.as_tensor(out['tracks'])).all()
 
   # N > 1: additionally ONE clip over all ranks (frame-sharded backbone -> all-gather of the grids
   # over xGMI -> query-sharded hot path), the strong-scaling view of the same workload
@@ -218,17 +291,19 @@ def main():
     v1 = torch.as_tensor(synthetic.make_video(1, T, S, S), device=dev)
     q1 = torch.as_tensor(synthetic.make_queries(101, Q, T, S, S), device=dev)
     for _ in range(max(1, args.warmup)):
-      tdist.sharded_call(model, v1, q1)
+      tdist.sharded_call(model, v1, q1, grid_dtype=grid_dtype)
     barrier()
     ts = time.perf_counter()
     for _ in range(args.steps):
-      tdist.sharded_call(model, v1, q1)
+      tdist.sharded_call(model, v1, q1, grid_dtype=grid_dtype)
     barrier()
-    tt = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    sharded = dict(ms_per_step=round(float(tt.item()) / args.steps * 1e3, 3),
-                   value=round(Q / (float(tt.item()) / args.steps), 2), unit='points/s', scaling='strong',
-                   exchange='all_gather_into_tensor of lowres+hires grids along T (f32), outputs gathered')
+    tsh = max_over_ranks(time.perf_counter() - ts)
+    wire = 2 if grid_dtype is not None else 4
+    sharded = dict(ms_per_step=round(tsh / args.steps * 1e3, 3),
+                   value=round(Q / (tsh / args.steps), 2), unit='points/s', scaling='strong',
+                   exchange=f'all_gather_into_tensor of lowres+hires grids along T ({"bf16" if wire == 2 else "f32"} '
+                            f'on the wire), outputs gathered',
+                   exchange_bytes=int(T * ((S // 8) ** 2 * 256 + (S // 4) ** 2 * 128) * wire))
 
   # hot path only (feature grids precomputed): R8 + R1
   fg = model.get_feature_grids(video)
@@ -259,26 +334,55 @@ def main():
     d_ms, d_n = prof[dom]
     in_dim = 388 + 49 * (2 + kw['pyramid_level'])
     peak = PEAK_TFLOPS[dtype]
+    es = 2 if dtype == 'bfloat16' else 4
+    k0_pad = -(-in_dim // (256 // es)) * (256 // es)     # mixer input rows padded to 256 bytes (engine.hip)
+    alg_bytes = None
     if dom == 'mixer_fused':
       # algorithmic flops of one launch = the whole PIPs mixer of R token rows:
       # input Linear + 12 x (512 -> 2048 -> 512) + output Linear; the temporal convolutions, GELUs and
       # LayerNorms the launch also executes are not counted
       flops = 2.0 * R * (in_dim * 512 + 12 * 2 * 512 * 2048 + 512 * 388)
-      kname = ('mixer_fused_kernel<one workgroup per track: input Linear + 12 x (LN, temporal convs, LN, '
-               'MLP 512-2048-512) + output Linear; residual stream in registers>')
+      # algorithmic HBM bytes: every weight once + the mixer input rows in + the 388 outputs per row out
+      alg_bytes = (es * (k0_pad * 512 + 12 * 2 * 512 * 2048 + 512 * 388) + 12 * 4 * (512 * 32 + 512 + 2048 + 512)
+                   + R * k0_pad * es + R * 388 * 4)
+      wide = R // T > 256 or T > 48
+      kname = ('mixer_fused_wide_kernel' if wide else 'mixer_fused_kernel') + \
+              ('<track-resident: input Linear + 12 x (LN, temporal convs, LN, MLP 512-2048-512) + output Linear; '
+               'residual stream in registers>')
+      pmc_key = 'mixer_fused_wide' if wide else 'mixer_fused'
     elif dom == 'gemm_up':
       flops = 2.0 * R * 2048 * 512
       kname = 'gemm_nt_kernel<mlp2_up: [R,512]x[512,2048]+bias+GELU>'
+      pmc_key = 'gemm_up'
     elif dom == 'gemm_down':
       flops = 2.0 * R * 2048 * 512
       kname = 'gemm_nt_kernel<mlp2_down: [R,2048]x[2048,512]+bias+skip>'
+      pmc_key = 'gemm_down'
     else:
-      flops, kname = None, dom
+      flops, kname, pmc_key = None, dom, dom
     ach = (flops / (d_ms / d_n * 1e-3) / 1e12) if (d_n and flops) else None
+    # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE need their own passes (the guide's
+    # HBM section; they cannot be collected from inside this process), so the line carries the value of
+    # the committed counter passes of THIS workload and names the artefact
+    traffic, traffic_src = None, None
+    if (args.model, T, Q, S, args.dtype, world) == ('tapir', 48, 256, 256, 'bf16', 1):
+      for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+        f = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(f):
+          try:
+            ent = json.load(open(f))['kernels'].get(pmc_key)
+          except Exception:
+            ent = None
+          if ent:
+            traffic = int(ent['hbm_bytes'])
+            traffic_src = (f'profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this '
+                           f'workload (FETCH_SIZE x 2, the guide\'s gfx950 correction), mean of {ent["launches"]} '
+                           'launches; not collected in this run')
+            break
     roof = dict(bound='mfma', kernel=kname,
                 achieved=round(ach, 2) if ach else None, peak=peak, unit='TFLOP/s',
-                frac=round(ach / peak, 4) if ach else None, traffic=None,
-                traffic_artefact='profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not collected in this run)',
+                frac=round(ach / peak, 4) if ach else None, traffic=traffic, traffic_source=traffic_src,
+                algorithmic_bytes=alg_bytes,
                 launches=d_n, avg_us=round(d_ms / d_n * 1e3, 2) if d_n else None,
                 flops_per_launch=flops, share_of_step=round(d_ms / args.steps / ms_per_step, 3))
     kernels = {k: dict(total_ms=round(v[0], 3), launches=v[1],
@@ -292,10 +396,9 @@ def main():
         dtype='bf16' if dtype == 'bfloat16' else 'f32', data='synthetic',
         config=dict(workload=f'TAPIR.__call__ ({args.model} kwargs), {S}x{S}x{T} clip, Q={Q}, '
                              f'4 refinement iters, random-init weights', clips=clips,
-                    shard=args.shard, backbone=('HIP fused 3x3 convolutions (norm+ReLU in, add+statistics out) + MIOpen stem / strided / 1x1 '
-                              '+ HIP norm / L2 kernels, hipGraph replay' if dtype == 'bfloat16' else
-                              'MIOpen convolutions + HIP norm/add/L2 kernels'),
-                    hot_path='HIP gfx950'),
+                    shard=args.shard, backbone=model._backbone.describe(T),
+                    hot_path='HIP gfx950', backend=(backend if world > 1 else None)),
+        rccl_ranks=(world if (world > 1 and backend == 'nccl') else 0),
         hot_path_ms=round(hot_s * 1e3, 3), backbone_ms=round(bb_s * 1e3, 3),
         hot_path_points_per_s=round(Q / hot_s, 2),
         point_frames_per_s=round(value * T, 1),

@@ -196,9 +196,10 @@ int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
 
 /* Feature backbone, the memory-bound half (TAPIR.get_feature_grids, tapir_model.py:626-729; ResNet
- * blocks, tapnet/models/resnet.py:152-257).  The stem, the strided and the 1x1 convolutions stay on
- * PyTorch-ROCm / MIOpen in f32 contexts (north_star); these three entry points are everything between
- * them (bf16 contexts: the block convolutions have their own fused entry point below).  Tensors are NHWC in the
+ * blocks, tapnet/models/resnet.py:152-257).  Every convolution of the ResNet (stem, 3x3, strided, 1x1)
+ * has a HIP kernel in both element types (tapir_conv_fused / tapir_stem_conv below); these three entry
+ * points are what is left between them -- the final L2 normalisation, and the statistics / normalise
+ * passes around a convolution whose shape does not fit the HIP kernels and goes to MIOpen.  Tensors are NHWC in the
  * context's element type (f32, or bf16 bits for TAPIR_BF16); channel counts: C / (8 bf16 | 4 f32)
  * must be a power of two <= 256 (<= 64 for tapir_l2_normalize).
  *
@@ -234,7 +235,10 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  * tapir_conv_plan : output rows per workgroup tile and tiles per image for an [H, W, cin] INPUT map
  *   (TAPIR_ERR_UNSUPPORTED when the shape does not fit: keep that convolution on MIOpen).
  * tapir_conv_pack : w = the reference's [cout, cin, ks, ks] f32 kernel (torch OIHW, host memory)
- *   -> device-resident packed fragment streams (owned by the context).
+ *   -> device-resident packed fragment streams.  A pack (and a tapir_stem_pack) belongs to the caller's
+ *   backbone object, NOT to the hot-path weights: it survives tapir_set_weight / tapir_finalize_weights
+ *   (a second load of hot-path weights does not invalidate a backbone or the hipGraphs that captured
+ *   its pointers) and lives until tapir_conv_free(ctx, wstream) or tapir_destroy.
  * tapir_conv_fused: y [N, ceil(H/stride), ceil(W/stride), cout] =
  *   conv(relu(instance_norm(x; part_in, gamma, beta))) (+ shortcut, 3x3 stride 1 only), rounded to the
  *   context's element type.
@@ -244,6 +248,7 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  *   NULL, [N, tiles, cout, 2] receives the summaries of y per tile (rows * W_out pixels each). */
 int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles);
 int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);
+int tapir_conv_free(tapir_ctx* ctx, void* wstream);
 int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
                      const float* gamma, const float* beta, float* ss, const void* wstream,
                      const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,

@@ -35,6 +35,27 @@ LOWRES_DIM = 256  # tapir_model.py:321
 
 
 # ---------------------------------------------------------------------------
+# operand rounding of the bf16 build (test infrastructure for the bf16 HIP kernels)
+# ---------------------------------------------------------------------------
+def bf16_round(x):
+  """float32 -> nearest-even bfloat16 -> float32 (the rounding of the HIP kernels' pack_bf16x2 /
+  host_f2bf).  The functions below take `rnd=None | bf16_round`: with rnd they round exactly the
+  tensors the bf16 build of the engine rounds -- the operands of its MFMA products (GEMM weights,
+  mixer input rows, LayerNorm / GELU outputs that feed a GEMM, feature grids and query vectors of the
+  cost-volume einsum, the 16-channel map and kernel of the occlusion convolution) -- and keep everything
+  else (residual stream, LayerNorm, temporal convolutions, softmax / soft arg max, biases) in f32, so a
+  bf16 kernel can be held to this restatement at accumulation-order noise instead of to a loose
+  drift bound.  rnd=None is the reference's f32 arithmetic, bit for bit what the fixtures pin."""
+  u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+  u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+  return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def _id(x):
+  return x
+
+
+# ---------------------------------------------------------------------------
 # plumbing (R9)
 # ---------------------------------------------------------------------------
 def convert_grid_coordinates(coords, input_grid_size, output_grid_size):
@@ -222,7 +243,7 @@ def heatmaps_to_points(all_pairs_softmax, image_hw, query_points=None,
 
 def tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
                             feature_grid, query_points, im_hw=(256, 256),
-                            softmax_temperature=20.0, return_stages=False):
+                            softmax_temperature=20.0, return_stages=False, rnd=None):
   """TAPIR.tracks_from_cost_volume (tapir_model.py:399-471).
 
   interp_feature [B,N,C]; feature_grid [B,T,h,w,C]; query_points [B,N,3] in
@@ -230,8 +251,9 @@ def tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
   expd [B,N,T] (+ dict of stage tensors).
   """
   p = 'torch_cost_volume_track_mods.'
+  rnd = rnd or _id
   dt = feature_grid.dtype
-  cv = build_cost_volume(interp_feature, feature_grid)  # [T,B,N,h,w]
+  cv = build_cost_volume(rnd(interp_feature), rnd(feature_grid))  # [T,B,N,h,w]
   t, b, n, h, w = cv.shape
   x = cv.reshape(t * b * n, h, w, 1)
   hid1 = np.maximum(conv2d_same(x, weights[p + 'hid1.weight'],
@@ -244,7 +266,7 @@ def tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
   sm = (e / e.sum(axis=(-2, -1), keepdims=True)).astype(dt)
   points = heatmaps_to_points(sm, im_hw, query_points)
 
-  occ = np.maximum(conv2d_same(hid1, weights[p + 'hid3.weight'],
+  occ = np.maximum(conv2d_same(rnd(hid1), rnd(weights[p + 'hid3.weight']),
                                weights[p + 'hid3.bias'], stride=2), 0)
   occ = occ.mean(axis=(1, 2), dtype=dt)
   occ = np.maximum(occ @ weights[p + 'hid4.weight'].T.astype(dt)
@@ -398,8 +420,9 @@ def _depthwise_conv1d(x, w, b, mult, causal):
 
 def pips_conv_block(weights, prefix, x, use_causal_conv=False,
                     causal_context=None, get_causal_context=False,
-                    block_name=None):
+                    block_name=None, rnd=None):
   """PIPsConvBlock (tapir_model.py:101-124) with depthwise_conv_residual (:39-89)."""
+  rnd = rnd or _id
   dt = x.dtype
   to_skip = x
   x = layernorm(x, weights[prefix + 'layer_norm.weight'])
@@ -426,40 +449,41 @@ def pips_conv_block(weights, prefix, x, use_causal_conv=False,
   x = x[..., 0::4] + x[..., 1::4] + x[..., 2::4] + x[..., 3::4]
   x = x + to_skip
   to_skip = x
-  x = layernorm(x, weights[prefix + 'layer_norm_1.weight'])
-  x = x @ weights[prefix + 'conv_channels_mixer.mlp2_up.weight'].T.astype(dt) \
+  x = rnd(layernorm(x, weights[prefix + 'layer_norm_1.weight']))
+  x = x @ rnd(weights[prefix + 'conv_channels_mixer.mlp2_up.weight']).T.astype(dt) \
       + weights[prefix + 'conv_channels_mixer.mlp2_up.bias'].astype(dt)
-  x = gelu_tanh(x)
-  x = x @ weights[prefix + 'conv_channels_mixer.mlp2_down.weight'].T.astype(dt) \
+  x = rnd(gelu_tanh(x))
+  x = x @ rnd(weights[prefix + 'conv_channels_mixer.mlp2_down.weight']).T.astype(dt) \
       + weights[prefix + 'conv_channels_mixer.mlp2_down.bias'].astype(dt)
   return (x + to_skip).astype(dt), new_ctx
 
 
 def pips_mlp_mixer(weights, x, num_blocks=12, use_causal_conv=False,
-                   causal_context=None, get_causal_context=False):
+                   causal_context=None, get_causal_context=False, rnd=None):
   """PIPSMLPMixer (tapir_model.py:127-156).  x [N,T,Cin] -> [N,T,388].
 
   Causal context keys follow the torch twin: ``block_{i}_causal_{1,2}``
   (tapnet/torch/tapir_model.py:766-768).
   """
   p = 'torch_pips_mixer.'
+  rn = rnd or _id
   dt = x.dtype
-  x = x @ weights[p + 'linear.weight'].T.astype(dt) + weights[p + 'linear.bias'].astype(dt)
+  x = rn(x) @ rn(weights[p + 'linear.weight']).T.astype(dt) + weights[p + 'linear.bias'].astype(dt)
   all_ctx = {}
   for i in range(num_blocks):
     x, ctx = pips_conv_block(weights, f'{p}blocks.{i}.', x, use_causal_conv,
                              causal_context, get_causal_context,
-                             block_name=f'block_{i}')
+                             block_name=f'block_{i}', rnd=rnd)
     all_ctx.update(ctx)
-  x = layernorm(x, weights[p + 'layer_norm.weight'])
-  x = x @ weights[p + 'linear_1.weight'].T.astype(dt) + weights[p + 'linear_1.bias'].astype(dt)
+  x = rn(layernorm(x, weights[p + 'layer_norm.weight']))
+  x = x @ rn(weights[p + 'linear_1.weight']).T.astype(dt) + weights[p + 'linear_1.bias'].astype(dt)
   return x.astype(dt), all_ctx
 
 
 def refine_pips(weights, target_feature, pyramid, pos_guess, occ_guess, expd_guess,
                 orig_hw, last_iter=None, resize_hw=None, num_blocks=12,
                 use_causal_conv=False, causal_context=None,
-                get_causal_context=False, return_stages=False):
+                get_causal_context=False, return_stages=False, rnd=None):
   """TAPIR.refine_pips (tapir_model.py:473-624).
 
   target_feature: list of [B,N,C_l]; pyramid: list of [B,T,h_l,w_l,C_l];
@@ -475,7 +499,7 @@ def refine_pips(weights, target_feature, pyramid, pos_guess, occ_guess, expd_gue
     liq = None
     if last_iter is not None:
       liq = last_iter[..., :HIRES_DIM] if pyridx == 0 else last_iter[..., HIRES_DIM:]
-    corrs.append(patch_correlation(query, grid, pos_guess, orig_hw, liq))
+    corrs.append(patch_correlation(query, (rnd or _id)(grid), pos_guess, orig_hw, liq))
   corrs = np.concatenate(corrs, axis=-1)
   b, n, t = pos_guess.shape[:3]
   if last_iter is None:
@@ -491,7 +515,7 @@ def refine_pips(weights, target_feature, pyramid, pos_guess, occ_guess, expd_gue
   if causal_context is not None:
     cc = {k: v.reshape((b * n,) + v.shape[2:]) for k, v in causal_context.items()}
   res, new_cc = pips_mlp_mixer(weights, x, num_blocks, use_causal_conv, cc,
-                               get_causal_context)
+                               get_causal_context, rnd=rnd)
   res = res.reshape(b, n, t, -1)
   new_cc = {k: v.reshape((b, n) + v.shape[1:]) for k, v in new_cc.items()}
   pos_update = convert_grid_coordinates(res[..., :2], (resized_w, resized_h),
@@ -512,7 +536,7 @@ def estimate_trajectories(weights, video_size, lowres, hires, resolutions,
                           softmax_temperature=20.0, initial_resolution=(256, 256),
                           num_blocks=12, use_causal_conv=False,
                           query_chunk_size=None, causal_context=None,
-                          get_causal_context=False):
+                          get_causal_context=False, rnd=None):
   """TAPIR.estimate_trajectories (tapir_model.py:858-1066).
 
   The random query permutation (:938-946) only randomises which chunk a query
@@ -543,7 +567,7 @@ def estimate_trajectories(weights, video_size, lowres, hires, resolutions,
           (num_frames,) + tuple(initial_resolution))
     points, occ, expd = tracks_from_cost_volume(
         weights, q_lowres[0][:, sl], lowres[0], qp, initial_resolution,
-        softmax_temperature)
+        softmax_temperature, rnd=rnd)
     pts_it[0].append(train2orig(points))
     occ_it[0].append(occ)
     exp_it[0].append(expd)
@@ -562,7 +586,7 @@ def estimate_trajectories(weights, video_size, lowres, hires, resolutions,
           weights, queries, pyramid, points, occ, expd, initial_resolution,
           last_iter=mixer_feats, resize_hw=resolutions[lvl], num_blocks=num_blocks,
           use_causal_conv=use_causal_conv, causal_context=cc,
-          get_causal_context=get_causal_context)
+          get_causal_context=get_causal_context, rnd=rnd)
       pts_it[i + 1].append(train2orig(points))
       occ_it[i + 1].append(occ)
       exp_it[i + 1].append(expd)

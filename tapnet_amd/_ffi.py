@@ -91,6 +91,7 @@ PROTOTYPES = {
                                  c_int, c_int, c_void_p]),
     'tapir_stem_plan': (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'tapir_stem_pack': (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    'tapir_conv_free': (c_int, [c_void_p, c_void_p]),
     'tapir_stem_conv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,

@@ -137,6 +137,41 @@ class Backbone:
       if n not in self.w:
         raise KeyError(f'backbone weight missing: {n}')
 
+  def describe(self, frames: int) -> str:
+    """What runs for a clip of `frames` frames (bench.py prints it in its JSON line)."""
+    hip = self._use_hip_convs(frames)
+    missing = sorted(k for k in ('stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2')
+                     if k not in self.hip_convs)
+    if hip and self._stem_ws is not None and self._wstream and not missing:
+      s = ('HIP: 7x7 stem + every ResNet block convolution (3x3 / 1x1, stride 1 / 2) as fused implicit-GEMM MFMA '
+           'kernels (InstanceNorm+ReLU in the operand load, residual add + next-norm statistics in the epilogue), '
+           'HIP finalize / L2-normalise kernels')
+    elif hip:
+      s = 'HIP fused convolutions except ' + ', '.join(missing or ['(unpacked shapes)']) + ' (MIOpen) + HIP norm kernels'
+    else:
+      s = 'MIOpen convolutions + HIP InstanceNorm / add / L2 kernels'
+    if self.extra_convs:
+      s += '; ExtraConvs: ' + self._extra_convs_impl()
+    if self.graph_min_frames and frames >= self.graph_min_frames:
+      s += f'; {max(1, min(int(self.streams), frames // 8))} streams, hipGraph replay'
+    return s
+
+  def _extra_convs_impl(self) -> str:
+    return 'PyTorch-ROCm / MIOpen convolutions + torch LayerNorm / GELU'
+
+  def close(self):
+    """Releases the packed weight streams this backbone owns in the engine context (tapir_conv_free)
+    and drops its captured graphs, which hold their addresses."""
+    self._graphs = {}
+    eng = getattr(self, 'engine', None)
+    if eng is None:
+      return
+    lib, ctx = eng
+    for h in [v[0] for v in getattr(self, '_wstream', {}).values()] + [getattr(self, '_stem_ws', None)]:
+      if h:
+        lib.tapir_conv_free(ctx, h)
+    self._wstream, self._stem_ws = {}, None
+
   # -- ExtraConvs (BootsTAPIR): small 32x32 maps, PyTorch ops on the GPU -----
   def _conv(self, x, name, stride=1, bias=False):
     w = self.w[name + '.weight']
@@ -219,8 +254,11 @@ class Backbone:
     return self._plans[key]
 
   def _use_hip_convs(self, n):
-    """'auto': the HIP convolutions from `hip_min_frames` frames per launch on -- a single frame (the
-    online model) gives them too few workgroups per launch, the library's kernels win there."""
+    """'auto': the HIP convolutions from `hip_min_frames` frames per CALL on -- a single frame (the
+    online model) gives them too few workgroups per launch, the library's kernels win there.  Decided
+    once per features() call from the whole clip (`global_frames` when the clip is sharded over ranks,
+    tapnet_amd.distributed), never per group of frames: a short last chunk or a small frame shard must
+    run the same kernels as the rest of the clip, or sharded and unsharded results differ by rounding."""
     return self.conv_mode == 'hip' or (self.conv_mode == 'auto' and n >= self.hip_min_frames)
 
   def _fusable(self, conv_name, h, w, stride):
@@ -289,7 +327,6 @@ class Backbone:
 
   def _features_hip(self, frames_nhwc, out_low=None, out_hi=None):
     st = None
-    self._hip_now = self._use_hip_convs(frames_nhwc.shape[0])
     if self._hip_now and 'stem' in self.hip_convs and self._stem_ws is not None:
       import ctypes
       lib, ctx = self.engine
@@ -323,12 +360,16 @@ class Backbone:
 
   # -- public ---------------------------------------------------------------
   @torch.no_grad()
-  def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None, borrow: bool = False
-               ) -> Tuple[torch.Tensor, torch.Tensor]:
+  def features(self, frames_nhwc: torch.Tensor, chunk: Optional[int] = None, borrow: bool = False,
+               global_frames: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """frames [N,H,W,3] f32 in [-1,1] -> (lowres [N,H/8,W/8,256], hires [N,H/4,W/4,128]) f32,
     L2-normalised, contiguous channels-last.  borrow=True: the caller consumes the grids before the
-    next call with this shape and may get the graph's own output buffers (no 150-MB copy per clip)."""
+    next call with this shape and may get the graph's own output buffers (no 150-MB copy per clip).
+    chunk (feature_extractor_chunk_size, tapir_model.py:689-703): frames per backbone pass -- bounds the
+    scratch memory, so such calls are launched eagerly (a captured graph keeps full-clip static buffers).
+    global_frames: frame count of the whole clip when this call sees one rank's shard of it."""
     n, H, W = frames_nhwc.shape[:3]
+    self._hip_now = self._use_hip_convs(max(n, int(global_frames or 0)))
     half = lambda v: -(-v // 2)
     last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
     c_low = self.w[last(3)].shape[0]
@@ -348,17 +389,24 @@ class Backbone:
     else:
       per = -(-n // streams)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
-    key = (n, H, W, self.conv_mode, tuple(sorted(self.hip_convs)), streams, len(bounds))
-    if os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (profilers that need every dispatch on its own)
-      key = None
+    key = (n, H, W, self._hip_now, tuple(sorted(self.hip_convs)), streams, tuple(bounds))
+    if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need
+      key = None                                                       #  every dispatch on its own)
     if (key is not None and self.graph_min_frames and n >= self.graph_min_frames
         and not torch.cuda.is_current_stream_capturing()):
-      ent = self._graphs.get(key)
+      ent = self._graphs.pop(key, None)            # (re-inserted below: the dict is kept in LRU order)
       if ent is None:
-        if len(self._graphs) >= 4:                 # a few shapes at most: the static buffers are large
-          self._graphs.pop(next(iter(self._graphs)))
-        ent = self._graphs[key] = {'seen': 0}
+        ent = {'seen': 0}
+      self._graphs[key] = ent
       ent['seen'] += 1
+      # a few captured shapes at most (their static buffers are large): evict the least recently used
+      # CAPTURED entry; entries that were only counted cost nothing and are trimmed separately
+      captured = [k for k, e in self._graphs.items() if 'graph' in e]
+      if len(captured) > 4:
+        self._graphs.pop(captured[0])
+      if len(self._graphs) > 64:
+        for k in [k for k, e in self._graphs.items() if 'graph' not in e][:32]:
+          self._graphs.pop(k)
       if 'graph' not in ent and not ent.get('failed') and ent['seen'] >= 3:
         ent['in'] = frames_nhwc.contiguous().clone()
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)

@@ -48,7 +48,9 @@ struct tapir_ctx {
   std::string err;
   std::map<std::string, HostTensor> host_w;
   bool finalized = false;
-  std::vector<void*> owned;         // device weight allocations
+  std::vector<void*> owned;         // device weight allocations (hot path: rebuilt by tapir_finalize_weights)
+  std::vector<void*> conv_owned;    // backbone weight packs (tapir_conv_pack / tapir_stem_pack): they belong to the
+                                    // caller's Backbone object and outlive tapir_finalize_weights (tapir_conv_free)
 
   // cost-volume head weights (f32)
   CvHeadWeights cvw;
@@ -905,6 +907,7 @@ void tapir_destroy(tapir_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (void* p : c->owned) (void)hipFree(p);
+  for (void* p : c->conv_owned) (void)hipFree(p);
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
                     &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk};
@@ -1227,9 +1230,20 @@ int tapir_conv_pack(tapir_ctx* c, const float* w, int cout, int cin, int ks, voi
   }
   void* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, host.size()));
-  c->owned.push_back(d);
+  c->conv_owned.push_back(d);
   HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
   *wstream = d;
+  return TAPIR_OK;
+}
+
+int tapir_conv_free(tapir_ctx* c, void* wstream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  if (!wstream) return TAPIR_OK;
+  auto it = std::find(c->conv_owned.begin(), c->conv_owned.end(), wstream);
+  if (it == c->conv_owned.end()) return fail(c, TAPIR_ERR_INVALID, "tapir_conv_free: not a pack of this context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipFree(wstream));
+  c->conv_owned.erase(it);
   return TAPIR_OK;
 }
 
@@ -1292,7 +1306,7 @@ int tapir_stem_pack(tapir_ctx* c, const float* w, void** wstream) {
           }
   void* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, host.size()));
-  c->owned.push_back(d);
+  c->conv_owned.push_back(d);
   HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
   *wstream = d;
   return TAPIR_OK;

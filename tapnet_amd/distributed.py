@@ -116,7 +116,9 @@ def gather_feature_grids(model, video_local, num_frames: int, group=None,
   B, t_local = video_local.shape[:2]
   lows, his = [], []
   if t_local > 0:
-    fg = model.get_feature_grids(video_local)
+    # (the convolution implementation is chosen from the WHOLE clip's frame count, so a small shard runs
+    # the kernels the unsharded call runs: bit-identical sharding, tapnet_amd/backbone.py)
+    fg = model.get_feature_grids(video_local, _global_frames=num_frames)
     res = tuple(fg.resolutions)
     levels = list(zip(fg.lowres, fg.hires))
   else:   # empty frame shard: contribute zero-length tensors of the right trailing shape

@@ -65,7 +65,7 @@ class OnlineTracker:
     """Drops the captured graphs and releases this session's pin on the model's workspaces."""
     self._graphs = [None, None]
     self._warm = False
-    if self._pinned:
+    if getattr(self, '_pinned', False):   # (__del__ also runs when __init__ raised half-way)
       self._pinned = False
       try:
         self.model._lib.tapir_pin_workspaces(self.model._ctx, 0)
@@ -162,11 +162,17 @@ class OnlineTracker:
       # model gets an error instead of reallocating them under the graphs (include/tapir_hip.h)
       m._check(m._lib.tapir_pin_workspaces(m._ctx, 1), 'tapir_pin_workspaces')
       self._pinned = True
-      for src in (0, 1):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-          self._run(src)
-        self._graphs[src] = g
+      try:
+        for src in (0, 1):
+          g = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g):
+            self._run(src)
+          self._graphs[src] = g
+      except Exception:
+        # a failed capture must not leave the model pinned: every later, larger call on the shared model
+        # would fail with 'workspace growth while pinned'
+        self.close()
+        raise
       torch.cuda.synchronize(m.device)
       for (a, b), (sa, sb) in zip(self._state, saved):   # the capture itself does not execute,
         a.copy_(sa); b.copy_(sb)                        # but keep the state exactly as it was

@@ -102,6 +102,19 @@ def make_weights(seed: int = 0, pyramid_level: int = 1, extra_convs: bool = True
   return w
 
 
+def proxy_checkpoint(seed: int = 0, pyramid_level: int = 0, extra_convs: bool = False) -> Dict[str, np.ndarray]:
+  """Random-init weights for the offline AJ proxy (tapnet_amd.tapvid.evaluate on make_tracked_dataset):
+  make_weights with the occlusion head biased towards "visible" (an untrained head predicts arbitrary
+  visibility, and Average Jaccard only scores points predicted visible), so that the proxy's AJ follows
+  the POSITION accuracy of the tracks -- the quantity reduced precision can move.  Not a trained model:
+  the numbers it gives are for comparing builds (bf16 vs f32) on the same data, nothing else."""
+  w = make_weights(seed, pyramid_level, extra_convs)
+  c = 'torch_cost_volume_track_mods.'
+  w[c + 'occ_out.weight'] = (w[c + 'occ_out.weight'] * np.float32(0.1)).astype(np.float32)
+  w[c + 'occ_out.bias'] = np.full((2,), -4.0, np.float32)
+  return w
+
+
 def make_tapnet_head_weights(seed: int = 0, peaky: bool = True) -> Dict[str, np.ndarray]:
   """Seeded weights of the TAP-Net cost-volume head (tapnet/models/tapnet_model.py:64-107) under the
   names tapnet_amd.tapnet_model loads, torch layout of the TAPIR head (occ_out has ONE output)."""
@@ -124,6 +137,28 @@ def make_tapnet_head_weights(seed: int = 0, peaky: bool = True) -> Dict[str, np.
   return w
 
 
+def _texture_clip(rng, num_frames: int, height: int, width: int, pad: int = 32, step: int = 1):
+  """One moving-texture clip [T,H,W,3] in [-1,1] and the integer (dy, dx) offset of every frame: a
+  low-pass random texture seen through a window that moves along a smooth path (offsets rounded to
+  multiples of `step` pixels)."""
+  big = rng.standard_normal((height + 2 * pad, width + 2 * pad, 3)).astype(np.float32)
+  # separable box blur x3 ~ gaussian, keeps structure at the stride-8 feature scale
+  for _ in range(3):
+    for ax in (0, 1):
+      big = (np.roll(big, 1, ax) + big + np.roll(big, -1, ax)
+             + np.roll(big, 2, ax) + np.roll(big, -2, ax)) / 5.0
+  big = big / (np.abs(big).max() + 1e-6)
+  ph = rng.uniform(0, 2 * np.pi, 2)
+  out = np.zeros((num_frames, height, width, 3), np.float32)
+  dys, dxs = [], []
+  for t in range(num_frames):
+    dy = int(round(pad * 0.6 * np.sin(ph[0] + 0.35 * t) / step)) * step
+    dx = int(round(pad * 0.6 * np.cos(ph[1] + 0.27 * t) / step)) * step
+    out[t] = big[pad + dy: pad + dy + height, pad + dx: pad + dx + width]
+    dys.append(dy); dxs.append(dx)
+  return out, np.array(dys), np.array(dxs)
+
+
 def make_video(seed: int, num_frames: int, height: int, width: int,
                batch: int = 1, texture: bool = True) -> np.ndarray:
   """Synthetic clip [B,T,H,W,3] float32 in [-1,1].
@@ -135,21 +170,37 @@ def make_video(seed: int, num_frames: int, height: int, width: int,
   if not texture:
     return rng.uniform(-1, 1, (batch, num_frames, height, width, 3)).astype(np.float32)
   out = np.zeros((batch, num_frames, height, width, 3), np.float32)
-  pad = 32
   for b in range(batch):
-    big = rng.standard_normal((height + 2 * pad, width + 2 * pad, 3)).astype(np.float32)
-    # separable box blur x3 ~ gaussian, keeps structure at the stride-8 feature scale
-    for _ in range(3):
-      for ax in (0, 1):
-        big = (np.roll(big, 1, ax) + big + np.roll(big, -1, ax)
-               + np.roll(big, 2, ax) + np.roll(big, -2, ax)) / 5.0
-    big = big / (np.abs(big).max() + 1e-6)
-    ph = rng.uniform(0, 2 * np.pi, 2)
-    for t in range(num_frames):
-      dy = int(round(pad * 0.6 * np.sin(ph[0] + 0.35 * t)))
-      dx = int(round(pad * 0.6 * np.cos(ph[1] + 0.27 * t)))
-      out[b, t] = big[pad + dy: pad + dy + height, pad + dx: pad + dx + width]
+    out[b], _, _ = _texture_clip(rng, num_frames, height, width)
   return out
+
+
+def make_tracked_dataset(seed: int, num_videos: int, num_frames: int, height: int, width: int,
+                         num_tracks: int, step: int = 8) -> Dict[str, Dict[str, np.ndarray]]:
+  """Moving-texture clips WITH ground truth, in the layout of the TAP-Vid-DAVIS pickle
+  (tapnet/tapvid/evaluation_datasets.py:490-532): {name: dict(video uint8 [T,H,W,3], points [N,T,2] (x, y)
+  in [0,1], occluded [N,T] bool)}.  Every track is a point of the texture: it moves with the window's
+  (integer) offsets and is occluded while it is outside the frame (structured clip with known
+  tracks and occlusions -- the offline stand-in for TAP-Vid, which cannot be fetched here).
+  step = 8: the window moves in multiples of the backbone's stride, so that an UNTRAINED (random-init)
+  translation-equivariant backbone produces the same feature vector for a texture point in every frame
+  and the cost volume has a clear, correct peak -- the regime a trained checkpoint works in."""
+  rng = np.random.default_rng(seed)
+  data = {}
+  for v in range(num_videos):
+    frames, dys, dxs = _texture_clip(rng, num_frames, height, width, step=step)
+    t0 = rng.integers(0, num_frames, num_tracks)
+    x0 = rng.uniform(0, width, num_tracks)
+    y0 = rng.uniform(0, height, num_tracks)
+    # a point at (x0, y0) of frame t0 shows texture cell (y0 + dy[t0], x0 + dx[t0]); in frame t that
+    # cell sits at (y0 + dy[t0] - dy[t], x0 + dx[t0] - dx[t])
+    xs = x0[:, None] + dxs[t0][:, None] - dxs[None, :]
+    ys = y0[:, None] + dys[t0][:, None] - dys[None, :]
+    occluded = (xs < 0) | (xs >= width) | (ys < 0) | (ys >= height)
+    points = np.stack([xs / width, ys / height], axis=-1)
+    video = np.clip(np.round((frames + 1.0) * 127.5), 0, 255).astype(np.uint8)
+    data[f'texture_{v:02d}'] = dict(video=video, points=points.astype(np.float64), occluded=occluded)
+  return data
 
 
 def make_queries(seed: int, num_queries: int, num_frames: int, height: int,

@@ -171,6 +171,8 @@ class TAPIR:
   # ------------------------------------------------------------------ plumbing
   def __del__(self):
     try:
+      if getattr(self, '_backbone', None) is not None:
+        self._backbone._graphs = {}
       if getattr(self, '_ctx', None):
         self._lib.tapir_destroy(self._ctx)
         self._ctx = None
@@ -205,7 +207,12 @@ class TAPIR:
       self._check(self._lib.tapir_set_weight(self._ctx, k.encode(), a.ctypes.data_as(ctypes.c_void_p),
                                              shape, a.ndim), f'tapir_set_weight({k})')
     self._check(self._lib.tapir_finalize_weights(self._ctx), 'tapir_finalize_weights')
+    # (a dict with hot-path weights only keeps the current backbone: its packed weight streams belong to
+    # the Backbone object, not to the hot-path weights tapir_finalize_weights rebuilds)
     if any(k.startswith('resnet_torch.') for k in host):
+      if self._backbone is not None:
+        torch.cuda.synchronize(self.device)
+        self._backbone.close()
       self._backbone = backbone_lib.Backbone(
           host, self.extra_convs, self.device,
           torch.bfloat16 if self.dtype == 'bfloat16' else torch.float32, self.blocks_per_group,
@@ -271,9 +278,10 @@ class TAPIR:
   # ------------------------------------------------------------------ R7
   def get_feature_grids(self, video, is_training: bool = False,
                         refinement_resolutions: Optional[List[Tuple[int, int]]] = None,
-                        _borrow: bool = False) -> FeatureGrids:
+                        _borrow: bool = False, _global_frames: Optional[int] = None) -> FeatureGrids:
     """tapir_model.py:626-729.  (_borrow: internal -- __call__ consumes the grids before it returns
-    and lets the backbone hand out its graph's own output buffers.)"""
+    and lets the backbone hand out its graph's own output buffers.  _global_frames: internal --
+    frames of the whole clip when `video` is one rank's shard, tapnet_amd.distributed.)"""
     del is_training
     if self._backbone is None:
       raise RuntimeError('backbone weights (resnet_torch.*) were not loaded')
@@ -297,7 +305,8 @@ class TAPIR:
         curr = resolution
         b, t, h, w, c = video_resize.shape
         low, hi = self._backbone.features(video_resize.reshape(b * t, h, w, c),
-                                          self.feature_extractor_chunk_size, borrow=_borrow)
+                                          self.feature_extractor_chunk_size, borrow=_borrow,
+                                          global_frames=None if _global_frames is None else b * _global_frames)
         latent = low.reshape(b, t, *low.shape[1:])
         hires = hi.reshape(b, t, *hi.shape[1:])
       feature_grid.append(latent)

@@ -1,0 +1,60 @@
+"""`-m gpu`: the offline stand-in for "TAP-Vid-DAVIS AJ within 0.1 of the reference" (north_star; the real
+number needs a trained checkpoint and tapvid_davis.pkl, neither fetchable here).
+
+tapnet_amd.synthetic.make_tracked_dataset writes moving-texture clips with exact ground-truth tracks and
+occlusions in the TAP-Vid-DAVIS pickle layout (tapnet/tapvid/evaluation_datasets.py:490-532);
+tapnet_amd.tapvid.evaluate (compute_tapvid_metrics :48-192, strided / first query sampling :230-337) scores
+the f32 build (held to the oracle at 1e-3) and the bf16 build (what bench.py times) of the engine on it,
+video -> tracks on the GPU.  What is asserted is AGREEMENT of the two builds' scores -- the quantity
+reduced precision can move -- not the level of AJ (the weights are random-init)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from tapnet_amd import synthetic, tapvid  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('average_jaccard', 'average_pts_within_thresh', 'occlusion_accuracy', 'pts_within_1', 'pts_within_4',
+        'pts_within_16')
+
+
+@pytest.mark.parametrize('mode', ['strided', 'first'])
+def test_aj_proxy_bf16_vs_f32(tmp_path, mode):
+  from tapnet_amd import tapir_model
+  data = synthetic.make_tracked_dataset(seed=5, num_videos=3, num_frames=24, height=256, width=256, num_tracks=48)
+  path = str(tmp_path / 'moving_texture_davis.pkl')
+  tapvid.write_davis_pickle(path, data)
+  w = synthetic.proxy_checkpoint(0)
+  kw = dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0)
+  res = {}
+  for dtype in ('float32', 'bfloat16'):
+    m = tapir_model.TAPIR(**kw, weights=w, dtype=dtype, device='cuda:0')
+    res[dtype] = dict(final=tapvid.evaluate(m, tapvid.davis_examples(path, mode), query_mode=mode),
+                      cost_volume_init=tapvid.evaluate(m, tapvid.davis_examples(path, mode), query_mode=mode,
+                                                       iteration=0))
+    del m
+  rec = {dt: {st: {k: round(100 * v[k], 3) for k in KEYS} for st, v in r.items()} for dt, r in res.items()}
+  rec['delta_points'] = {st: {k: round(rec['bfloat16'][st][k] - rec['float32'][st][k], 3) for k in KEYS}
+                         for st in ('final', 'cost_volume_init')}
+  rec['what'] = (f'moving-texture proxy, 3 clips x 24 frames x 48 tracks, {mode} queries, random-init proxy '
+                 'checkpoint; numbers x100 as in the TAP-Vid tables')
+  os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+  with open(os.path.join(ROOT, 'gpurun_out', f'aj_proxy_{mode}.json'), 'w') as f:
+    json.dump(rec, f, indent=1)
+  print(json.dumps(rec))
+  f32 = rec['float32']
+  # the data is trackable: the cost-volume initialisation of the f32 build finds the texture point
+  assert f32['cost_volume_init']['pts_within_16'] > 90.0, rec
+  assert f32['final']['occlusion_accuracy'] > 80.0, rec
+  d = rec['delta_points']
+  # north_star: AJ within 0.1 (points of the x100 scale are what the tables quote; the bound asserted here
+  # is on the proxy) -- see DESIGN.md 4 for the measured values
+  for st in ('final', 'cost_volume_init'):
+    assert abs(d[st]['average_jaccard']) <= 1.0, rec
+    assert abs(d[st]['average_pts_within_thresh']) <= 1.0, rec
+    assert abs(d[st]['occlusion_accuracy']) <= 0.5, rec

@@ -1,0 +1,239 @@
+"""`-m gpu`: the bf16 PRODUCTION kernels, stage by stage, against the oracle run with the bf16 build's
+operand roundings (oracle.tapir_oracle.bf16_round: GEMM weights, mixer input rows, the LayerNorm /
+GELU outputs that feed a GEMM, feature grids and query vectors of the einsum, the operands of the
+occlusion convolution rounded to bf16; residual stream, LayerNorms, temporal convolutions, softmax /
+soft arg max in f32 -- tapnet_amd/csrc/{mixer_fused,mixer_fused_wide,costvol_fused,pips}.hpp).
+
+With the roundings restated, a bf16 kernel differs from the oracle only by f32 accumulation order and
+by the occasional operand that lands on the other side of a bf16 rounding boundary, so it is held to
+the ORACLE (not to a drift bound against the f32 build):
+
+  * mixer_fused_wide_kernel (auto-selected for > 256 tracks and for 49..96-frame clips; it had no
+    GPU parity test in round 2): N = 512 / 1024 at T = 48, N = 64 at T = 96, ragged T = 40 / 90, odd N;
+  * mixer_fused_kernel<bf16> at the benchmarked shape (256 tracks x 48 frames) and a ragged one;
+  * cv_fused_kernel<bf16> at 256 queries x 48 frames x 32x32 cells;
+  * patch_corr_kernel<bf16> + mixer + update through tapir_refine_pips at that shape, first and later
+    iteration;
+  * TAPIR.__call__ in bf16 with 512 queries (the wide kernel inside the whole hot path).
+
+Reference arithmetic: tapnet/models/tapir_model.py:33-156 (mixer), :399-471 (cost volume), :473-624
+(refine_pips).  The measured deviations are written to gpurun_out/bf16_stage_parity.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import tapir_oracle as O  # noqa: E402
+from tapnet_amd import synthetic  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REC = {}
+
+
+def _record(key, **vals):
+  REC[key] = {k: (float(v) if np.ndim(v) == 0 else v) for k, v in vals.items()}
+  os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+  path = os.path.join(ROOT, 'gpurun_out', 'bf16_stage_parity.json')
+  old = {}
+  if os.path.exists(path):
+    try:
+      old = json.load(open(path))
+    except Exception:
+      old = {}
+  old.update(REC)
+  with open(path, 'w') as f:
+    json.dump(old, f, indent=1, sort_keys=True)
+
+
+def _model(pyr, dtype='bfloat16', weights=None, **kw):
+  from tapnet_amd import tapir_model
+  return tapir_model.TAPIR(pyramid_level=pyr, extra_convs=False, weights=weights, dtype=dtype,
+                           device='cuda:0', **kw)
+
+
+def _mixer(m, x, mode):
+  """tapir_pips_mixer through the C ABI with the mixer implementation pinned (include/tapir_hip.h)."""
+  assert m._lib.tapir_debug_set_mixer_mode(m._ctx, mode) == 0
+  try:
+    xt = torch.as_tensor(x, device='cuda').contiguous()
+    N, T, _ = x.shape
+    out = torch.empty((N, T, 388), device='cuda', dtype=torch.float32)
+    m._check(m._lib.tapir_pips_mixer(m._ctx, xt.data_ptr(), N, T, out.data_ptr(), None, None, None,
+                                     None, m._stream()), 'tapir_pips_mixer')
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+  finally:
+    m._lib.tapir_debug_set_mixer_mode(m._ctx, 0)
+
+
+def _dev_stats(a, b):
+  d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).ravel()
+  return dict(max=float(d.max()), p999=float(np.percentile(d, 99.9)), median=float(np.median(d)))
+
+
+def _mixer_case(mode, N, T, pyr, seed, tag):
+  w = synthetic.make_weights(seed, pyr, False, backbone=False)
+  m = _model(pyr, weights=w)
+  rng = np.random.default_rng(1000 * N + T)
+  x = rng.standard_normal((N, T, 388 + 49 * (2 + pyr))).astype(np.float32)
+  got = _mixer(m, x, mode)
+  assert np.isfinite(got).all()
+  # oracle on a subset of the tracks (tracks are independent units): first, last (an odd N leaves the
+  # last workgroup of the wide kernel half empty) and a few in between
+  idx = sorted(set([0, N - 1] + list(np.random.default_rng(N).choice(N, min(N, 4), replace=False))))
+  ref16, _ = O.pips_mlp_mixer(w, x[idx], rnd=O.bf16_round)
+  ref32, _ = O.pips_mlp_mixer(w, x[idx])
+  s16, s32 = _dev_stats(got[idx], ref16), _dev_stats(got[idx], ref32)
+  scale = float(np.abs(ref32).mean())
+  # the separate-launch path (token-mixing kernel + tiled GEMMs) on ALL tracks: same roundings
+  sep = _mixer(m, x, 1)
+  ssep = _dev_stats(got, sep)
+  _record(f'{tag}[N={N},T={T},pyr={pyr}]', vs_rounding_oracle=s16, vs_f32_oracle=s32,
+          vs_separate_launches=ssep, mean_abs_output=scale)
+  # outputs are O(1) (mean |y| ~ 0.3-0.6).  Against the rounding oracle: accumulation order + rare
+  # rounding-boundary flips of single operands; against the f32 oracle: the bf16 operand rounding itself
+  # (host emulator, 2 blocks: max 1.4e-3 / median <= 1.3e-5 against the rounding oracle, 5e-3 / 7e-4 against
+  # the f32 one -- tests/test_bf16_rounding_oracle_emulated.py; here 12 blocks and the GPU's v_exp / v_rcp)
+  assert s16['max'] < 1.5e-2 and s16['median'] < 3e-4, (tag, N, T, s16)
+  assert ssep['max'] < 1.5e-2 and ssep['median'] < 3e-4, (tag, N, T, ssep)
+  assert s32['max'] < 0.2 and s32['median'] < 1.5e-2, (tag, N, T, s32)
+  # and the rounding oracle must explain most of the distance to the f32 oracle
+  assert s16['median'] < 0.25 * s32['median'], (s16, s32)
+  return got, m, x
+
+
+@pytest.mark.parametrize('N,T,pyr', [(512, 48, 0), (1024, 48, 1), (64, 96, 1), (6, 40, 1), (3, 90, 0),
+                                     (5, 48, 1), (33, 70, 0)])
+def test_wide_fused_mixer_vs_oracle(N, T, pyr):
+  """mixer_fused_wide_kernel (mode 3) through tapir_pips_mixer: two tracks of <= 48 frames per
+  workgroup (N = 512, 1024: BASELINE configs[2] sizes; 5: odd; T = 40: ragged two-and-a-half tiles)
+  and one 49..96-frame track per workgroup (T = 96: configs[4]; 90 / 70: ragged, 6 / 5 token tiles)."""
+  got, m, x = _mixer_case(3, N, T, pyr, 40 + T, 'wide_mixer')
+  if T <= 48:   # the 3-tile kernel on the same input
+    s = _dev_stats(got, _mixer(m, x, 2))
+    assert s['max'] < 1.5e-2 and s['median'] < 3e-4, s
+
+
+@pytest.mark.parametrize('N,T,pyr', [(256, 48, 0), (256, 48, 1), (130, 33, 1), (7, 16, 0)])
+def test_fused_mixer_bf16_vs_oracle(N, T, pyr):
+  """mixer_fused_kernel<bf16> (mode 2) at the benchmarked shape (256 tracks x 48 frames, both input
+  widths), a ragged three-tile clip and a one-tile one."""
+  _mixer_case(2, N, T, pyr, 60 + T, 'fused_mixer')
+
+
+def test_cv_fused_bf16_vs_oracle():
+  """cv_fused_kernel<bf16> at BASELINE configs[1]: 256 queries x 48 frames x 32x32 cells.  The einsum
+  operands and the occlusion convolution's operands are bf16, everything that feeds the soft arg max is
+  exact f32 (costvol_fused.hpp)."""
+  w = synthetic.make_weights(3, 0, False, backbone=False)
+  m = _model(0, weights=w)
+  rng = np.random.default_rng(5)
+  Q, T = 256, 48
+  grid = O.l2_normalize(rng.standard_normal((1, T, 32, 32, 256)).astype(np.float32))
+  qp = synthetic.make_queries(6, Q, T, 256, 256)
+  qf, _ = O.get_query_features([grid], [grid[..., :128]], [(256, 256)], qp, (1, T, 256, 256, 3))
+  pts, occ, expd = m.tracks_from_cost_volume(qf[0], grid, qp)
+  idx = np.random.default_rng(7).choice(Q, 12, replace=False)
+  rp, ro, re, st = O.tracks_from_cost_volume(w, qf[0][:, idx], grid, qp[:, idx], (256, 256), 20.0,
+                                             return_stages=True, rnd=O.bf16_round)
+  ok = st['top2_rel_gap'] > 1e-3
+  so, se = _dev_stats(occ[:, idx], ro), _dev_stats(expd[:, idx], re)
+  sp = _dev_stats(pts[:, idx][ok], rp[ok])
+  _record('cv_fused_bf16[Q=256,T=48]', occlusion=so, expected_dist=se, points_clear_argmax=sp,
+          clear_fraction=float(ok.mean()))
+  assert ok.mean() > 0.9
+  # points: f32 arithmetic on a bf16-operand cost map -> 1e-3 px like the f32 build, given the rounded
+  # operands; occlusion logits: bf16 MFMA over K = 144 with rounding-boundary flips of hid1
+  assert sp['max'] < 2e-3, sp
+  assert so['max'] < 5e-3 and so['median'] < 2e-4, so
+  assert se['max'] < 5e-3 and se['median'] < 2e-4, se
+
+
+@pytest.mark.parametrize('pyr', [0, 1])
+def test_refine_pips_bf16_vs_oracle(pyr):
+  """patch_corr_kernel<bf16> + the fused mixer + update_kernel through tapir_refine_pips at 256 queries x
+  48 frames: the first iteration of a level (tiled query features) and a later one (per-token refined
+  features as the correlation query), against O.refine_pips with the rounded pyramid and mixer operands."""
+  w = synthetic.make_weights(8 + pyr, pyr, False, backbone=False)
+  m = _model(pyr, weights=w)
+  rng = np.random.default_rng(11 + pyr)
+  Q, T, S = 256, 48, 256
+  low = O.l2_normalize(rng.standard_normal((1, T, 32, 32, 256)).astype(np.float32))
+  hi = O.l2_normalize(rng.standard_normal((1, T, 64, 64, 128)).astype(np.float32))
+  qp = synthetic.make_queries(12, Q, T, S, S)
+  ql, qh = O.get_query_features([low], [hi], [(S, S)], qp, (1, T, S, S, 3))
+  queries, pyramid = [qh[0], ql[0]], [hi, low]
+  for _ in range(pyr):
+    queries.append(queries[-1]); pyramid.append(O.avg_pool_2x2(pyramid[-1]))
+  pos = (rng.uniform(8, S - 8, (1, Q, T, 2))).astype(np.float32)
+  pos[:, :8] = rng.uniform(-6, S + 6, (1, 8, T, 2))            # some windows hang over the border
+  occ = rng.standard_normal((1, Q, T)).astype(np.float32)
+  expd = rng.standard_normal((1, Q, T)).astype(np.float32)
+  idx = np.concatenate([np.arange(4), np.random.default_rng(3).choice(np.arange(8, Q), 6, replace=False)])
+  sub = lambda a: a[:, idx]
+  last = None
+  for it in range(2):
+    out = m.refine_pips(queries, None, pyramid, pos, occ, expd, (S, S), last_iter=last, resize_hw=(S, S))
+    ref = O.refine_pips(w, [sub(q) for q in queries], pyramid, sub(pos), sub(occ), sub(expd), (S, S),
+                        last_iter=None if last is None else sub(last), resize_hw=(S, S), rnd=O.bf16_round)
+    names = ('pos', 'occ', 'expd', 'feats')
+    stats = {n: _dev_stats(out[k][:, idx], ref[k]) for k, n in enumerate(names)}
+    _record(f'refine_pips_bf16[pyr={pyr},iter={it}]', **stats)
+    # position updates are in pixels of a 256-px frame; logits and features O(1)
+    assert stats['pos']['max'] < 1.5e-2 and stats['pos']['median'] < 3e-4, stats
+    for n in ('occ', 'expd', 'feats'):
+      assert stats[n]['max'] < 1.5e-2 and stats[n]['median'] < 3e-4, (n, stats)
+    pos, occ, expd, last = out[0], out[1], out[2], out[3]
+
+
+def test_wide_mixer_inside_the_call_bf16():
+  """TAPIR.__call__ in bf16 with 512 queries on a 48-frame clip: the engine picks the wide kernel
+  (N > 256).  (a) its result equals the same call with the 3-tile kernel / the separate launches pinned,
+  up to the refinement's amplification of accumulation-order noise; (b) a 16-query subset against
+  O.tapir_from_grids with the bf16 roundings (per-query independence makes the subset exact)."""
+  from tapnet_amd import tapir_model
+  kw = dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0)
+  w = synthetic.make_weights(3, 0, False)
+  T, S, Q = 48, 256, 512
+  video = synthetic.make_video(7, T, S, S)
+  qp = synthetic.make_queries(8 + Q, Q, T, S, S)
+  m32 = tapir_model.TAPIR(**kw, weights=w, device='cuda:0')
+  fg = m32.get_feature_grids(torch.as_tensor(video).cuda())
+  del m32
+  m = tapir_model.TAPIR(**kw, weights=w, device='cuda:0', dtype='bfloat16')
+  auto = m(video, False, qp, feature_grids=fg)
+  outs = {}
+  for mode in (3, 2, 1):
+    assert m._lib.tapir_debug_set_mixer_mode(m._ctx, mode) == 0
+    outs[mode] = m(video, False, qp, feature_grids=fg)
+  assert m._lib.tapir_debug_set_mixer_mode(m._ctx, 0) == 0
+  np.testing.assert_array_equal(auto['tracks'], outs[3]['tracks'])    # auto IS the wide kernel here
+  rec = {}
+  for mode, name in ((2, 'vs_3tile_kernel'), (1, 'vs_separate_launches')):
+    d = np.linalg.norm(outs[3]['tracks'] - outs[mode]['tracks'], axis=-1)
+    rec[name] = dict(median=float(np.median(d)), p99=float(np.percentile(d, 99)), max=float(d.max()))
+  idx = np.random.default_rng(2).choice(Q, 16, replace=False)
+  lows = [x.cpu().numpy() for x in fg.lowres]; his = [x.cpu().numpy() for x in fg.hires]
+  ref = O.tapir_from_grids(w, video.shape, lows, his, [tuple(r) for r in fg.resolutions], qp[:, idx],
+                           pyramid_level=0, softmax_temperature=20.0, rnd=O.bf16_round)
+  d0 = np.linalg.norm(auto['unrefined_tracks'][0][:, idx] - ref['unrefined_tracks'][0], axis=-1)
+  keep = d0 < 4.0      # (a different cell won a near-tie of the heat map: an 8-px jump, not a mixer matter)
+  d = np.linalg.norm(auto['tracks'][:, idx] - ref['tracks'], axis=-1)[keep]
+  do = np.abs(auto['occlusion'][:, idx] - ref['occlusion'])[keep]
+  rec['vs_rounding_oracle'] = dict(tracks_px=dict(median=float(np.median(d)), p99=float(np.percentile(d, 99)),
+                                                  max=float(d.max())),
+                                   occlusion_logit=dict(median=float(np.median(do)), p99=float(np.percentile(do, 99))),
+                                   argmax_flip_rate=float((~keep).mean()))
+  _record('call_bf16_wide[Q=512,T=48]', **rec)
+  # same roundings in all three implementations: what separates them is accumulation order, amplified by
+  # four refinement iterations of a random-init (non-contractive) mixer
+  for name in ('vs_3tile_kernel', 'vs_separate_launches'):
+    assert rec[name]['median'] < 0.02 and rec[name]['p99'] < 0.3, rec
+  v = rec['vs_rounding_oracle']
+  assert v['argmax_flip_rate'] < 0.01, rec
+  assert v['tracks_px']['median'] < 0.02 and v['tracks_px']['p99'] < 0.3, rec
+  assert v['occlusion_logit']['median'] < 0.01 and v['occlusion_logit']['p99'] < 0.15, rec

@@ -116,3 +116,27 @@ def test_tapnet_haiku_param_conversion():
   w = params['tap_net/cost_volume_occlusion_1']['w']
   assert flat['tapnet_cost_volume_track_mods.hid3.weight'][5, 7, 2, 1] == w[0, 2, 1, 7, 5]
   assert flat['tapnet_cost_volume_track_mods.hid4.weight'][3, 9] == params['tap_net/cost_volume_occlusion_2']['w'][9, 3]
+
+
+def test_bench_self_launch_command(monkeypatch):
+  """`python bench.py --gpus N` (N > 1, no launcher around it) re-executes itself through
+  torch.distributed.run with one process per GPU and a 127.0.0.1 rendezvous, passing its flags on."""
+  import importlib
+  import subprocess
+  import sys
+  bench = importlib.import_module('bench')
+  seen = {}
+
+  def fake_call(cmd, env=None):
+    seen['cmd'], seen['env'] = cmd, env
+    return 0
+
+  monkeypatch.setattr(subprocess, 'call', fake_call)
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3'])
+  args = bench.parse()
+  assert bench.self_launch(args) == 0
+  cmd = seen['cmd']
+  assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd
+  assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+  assert cmd[-4:] == ['--gpus', '4', '--steps', '3'] and cmd[-5].endswith('bench.py')
+  assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

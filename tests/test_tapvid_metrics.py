@@ -103,3 +103,50 @@ def test_davis_examples_resize_is_uint8_lanczos(tmp_path):
   np.testing.assert_array_equal(u8.astype(np.uint8), ref)
   # same size: untouched
   np.testing.assert_array_equal(tapvid.resize_video(video, (40, 56)), video)
+
+
+def test_tracked_dataset_ground_truth_and_davis_layout(tmp_path):
+  """synthetic.make_tracked_dataset (the offline AJ proxy's data): every track is a point of
+  the moving texture -- the pixel under a visible track never changes -- occluded exactly while outside the
+  frame, offsets in multiples of the backbone stride; written / read back in the TAP-Vid-DAVIS layout and
+  scored by tapvid.evaluate with a tracker that returns the ground truth (AJ = 1)."""
+  from tapnet_amd import synthetic
+  T, S, N = 9, 64, 12
+  data = synthetic.make_tracked_dataset(3, 2, T, S, S, N)
+  assert sorted(data) == ['texture_00', 'texture_01']
+  for d in data.values():
+    assert d['video'].shape == (T, S, S, 3) and d['video'].dtype == np.uint8
+    assert d['points'].shape == (N, T, 2) and d['occluded'].shape == (N, T)
+    px = d['points'] * S
+    inside = (px >= 0).all(-1) & (px < S).all(-1)
+    np.testing.assert_array_equal(d['occluded'], ~inside)
+    step = np.diff(px, axis=1)
+    np.testing.assert_allclose(step, np.round(step / 8) * 8, atol=1e-9)     # multiples of the stride
+    for n in range(N):
+      vis = np.nonzero(~d['occluded'][n])[0]
+      vals = np.stack([d['video'][t, int(px[n, t, 1]), int(px[n, t, 0])] for t in vis])
+      assert (vals == vals[0]).all()
+  path = str(tmp_path / 'tex.pkl')
+  tapvid.write_davis_pickle(path, data)
+
+  class Perfect:
+    def __init__(self): self.ex = None
+    def get_feature_grids(self, video): return None
+    def __call__(self, video, is_training, qp, feature_grids=None):
+      ex = self.ex
+      idx = [int(np.argmin(np.abs(ex['query_points'][0] - q).sum(-1))) for q in qp[0]]
+      occl = np.where(ex['occluded'][0][idx], 20.0, -20.0)
+      out = dict(tracks=ex['target_points'][:, idx], occlusion=occl[None], expected_dist=np.full_like(occl, -20.0)[None])
+      out.update({'unrefined_' + k: [v] for k, v in list(out.items())})
+      return out
+
+  for mode in ('strided', 'first'):
+    exs = list(tapvid.davis_examples(path, mode, (S, S)))
+    assert len(exs) == 2
+    for it in (None, 0):
+      m = Perfect()
+      tot = []
+      for name, ex in exs:
+        m.ex = ex
+        tot.append(tapvid.evaluate(m, [(name, ex)], query_mode=mode, iteration=it)['average_jaccard'])
+      assert abs(np.mean(tot) - 1.0) < 1e-9
