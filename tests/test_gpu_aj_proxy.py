@@ -52,9 +52,12 @@ def test_aj_proxy_bf16_vs_f32(tmp_path, mode):
   assert f32['cost_volume_init']['pts_within_16'] > 90.0, rec
   assert f32['final']['occlusion_accuracy'] > 80.0, rec
   d = rec['delta_points']
-  # north_star: AJ within 0.1 (points of the x100 scale are what the tables quote; the bound asserted here
-  # is on the proxy) -- see DESIGN.md 4 for the measured values
+  # north_star: "AJ within 0.1" (points of the x100 scale the TAP-Vid tables quote).  Measured on MI355X
+  # (profiles/r03_aj_proxy_*.json): strided AJ 44.99 (f32) vs 45.04 (bf16), +0.05; first 42.45 vs 42.56,
+  # +0.11 -- differences of a handful of the ~5-11 k scored points (a near-tie of the heat map resolved
+  # the other way by the bf16 backbone), bf16 scoring HIGHER; occlusion accuracy identical.  The gate is
+  # 0.25 points on this 144-track proxy (its own sampling noise), not a claim about TAP-Vid-DAVIS.
   for st in ('final', 'cost_volume_init'):
-    assert abs(d[st]['average_jaccard']) <= 1.0, rec
-    assert abs(d[st]['average_pts_within_thresh']) <= 1.0, rec
-    assert abs(d[st]['occlusion_accuracy']) <= 0.5, rec
+    assert abs(d[st]['average_jaccard']) <= 0.25, rec
+    assert abs(d[st]['average_pts_within_thresh']) <= 0.25, rec
+    assert abs(d[st]['occlusion_accuracy']) <= 0.1, rec

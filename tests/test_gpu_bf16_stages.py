@@ -35,7 +35,7 @@ REC = {}
 
 
 def _record(key, **vals):
-  REC[key] = {k: (float(v) if np.ndim(v) == 0 else v) for k, v in vals.items()}
+  REC[key] = {k: (v if isinstance(v, (dict, list, str)) else float(v)) for k, v in vals.items()}
   os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
   path = os.path.join(ROOT, 'gpurun_out', 'bf16_stage_parity.json')
   old = {}
@@ -96,13 +96,16 @@ def _mixer_case(mode, N, T, pyr, seed, tag):
           vs_separate_launches=ssep, mean_abs_output=scale)
   # outputs are O(1) (mean |y| ~ 0.3-0.6).  Against the rounding oracle: accumulation order + rare
   # rounding-boundary flips of single operands; against the f32 oracle: the bf16 operand rounding itself
-  # (host emulator, 2 blocks: max 1.4e-3 / median <= 1.3e-5 against the rounding oracle, 5e-3 / 7e-4 against
-  # the f32 one -- tests/test_bf16_rounding_oracle_emulated.py; here 12 blocks and the GPU's v_exp / v_rcp)
-  assert s16['max'] < 1.5e-2 and s16['median'] < 3e-4, (tag, N, T, s16)
-  assert ssep['max'] < 1.5e-2 and ssep['median'] < 3e-4, (tag, N, T, ssep)
-  assert s32['max'] < 0.2 and s32['median'] < 1.5e-2, (tag, N, T, s32)
-  # and the rounding oracle must explain most of the distance to the f32 oracle
-  assert s16['median'] < 0.25 * s32['median'], (s16, s32)
+  # Measured on MI355X (profiles/r03_bf16_stage_parity.json), 12 blocks, every kernel and shape alike:
+  # against the rounding oracle max 2.8-4.1e-3, median 3.7-4.0e-4 -- the same as between two HIP
+  # implementations (fused vs separate launches: 3.0-4.7e-3 / 3.5-3.9e-4), i.e. the floor set by
+  # accumulation order and rounding-boundary flips over 12 blocks (host emulator, 2 blocks: 1.4e-3 / 1e-5);
+  # against the f32 oracle max 5.4-6.2e-3, median 7.9-8.3e-4.  Gates = 2x.
+  assert s16['max'] < 8e-3 and s16['median'] < 8e-4, (tag, N, T, s16)
+  assert ssep['max'] < 9e-3 and ssep['median'] < 8e-4, (tag, N, T, ssep)
+  assert s32['max'] < 1.3e-2 and s32['median'] < 1.7e-3, (tag, N, T, s32)
+  # and the rounding oracle must explain the larger part of the distance to the f32 oracle
+  assert s16['median'] < 0.6 * s32['median'], (s16, s32)
   return got, m, x
 
 
@@ -115,7 +118,7 @@ def test_wide_fused_mixer_vs_oracle(N, T, pyr):
   got, m, x = _mixer_case(3, N, T, pyr, 40 + T, 'wide_mixer')
   if T <= 48:   # the 3-tile kernel on the same input
     s = _dev_stats(got, _mixer(m, x, 2))
-    assert s['max'] < 1.5e-2 and s['median'] < 3e-4, s
+    assert s['max'] < 9e-3 and s['median'] < 8e-4, s      # (measured: the two kernels agree bit for bit)
 
 
 @pytest.mark.parametrize('N,T,pyr', [(256, 48, 0), (256, 48, 1), (130, 33, 1), (7, 16, 0)])
@@ -148,9 +151,10 @@ def test_cv_fused_bf16_vs_oracle():
   assert ok.mean() > 0.9
   # points: f32 arithmetic on a bf16-operand cost map -> 1e-3 px like the f32 build, given the rounded
   # operands; occlusion logits: bf16 MFMA over K = 144 with rounding-boundary flips of hid1
-  assert sp['max'] < 2e-3, sp
-  assert so['max'] < 5e-3 and so['median'] < 2e-4, so
-  assert se['max'] < 5e-3 and se['median'] < 2e-4, se
+  # measured: points max 1.2e-4 px, logits max 3.5e-7 (the bf16 products of this head are exact in f32)
+  assert sp['max'] < 1e-3, sp
+  assert so['max'] < 1e-4 and so['median'] < 1e-5, so
+  assert se['max'] < 1e-4 and se['median'] < 1e-5, se
 
 
 @pytest.mark.parametrize('pyr', [0, 1])
@@ -184,9 +188,10 @@ def test_refine_pips_bf16_vs_oracle(pyr):
     stats = {n: _dev_stats(out[k][:, idx], ref[k]) for k, n in enumerate(names)}
     _record(f'refine_pips_bf16[pyr={pyr},iter={it}]', **stats)
     # position updates are in pixels of a 256-px frame; logits and features O(1)
-    assert stats['pos']['max'] < 1.5e-2 and stats['pos']['median'] < 3e-4, stats
+    # measured: max 2.0-4.8e-3, median 3.7-5.1e-4 (the mixer's floor above); gates = 2x
+    assert stats['pos']['max'] < 8e-3 and stats['pos']['median'] < 1e-3, stats
     for n in ('occ', 'expd', 'feats'):
-      assert stats[n]['max'] < 1.5e-2 and stats[n]['median'] < 3e-4, (n, stats)
+      assert stats[n]['max'] < 1e-2 and stats[n]['median'] < 1e-3, (n, stats)
     pos, occ, expd, last = out[0], out[1], out[2], out[3]
 
 
@@ -231,9 +236,12 @@ def test_wide_mixer_inside_the_call_bf16():
   _record('call_bf16_wide[Q=512,T=48]', **rec)
   # same roundings in all three implementations: what separates them is accumulation order, amplified by
   # four refinement iterations of a random-init (non-contractive) mixer
-  for name in ('vs_3tile_kernel', 'vs_separate_launches'):
-    assert rec[name]['median'] < 0.02 and rec[name]['p99'] < 0.3, rec
+  # measured: the wide and the 3-tile kernel agree bit for bit; vs separate launches median 0.0027 px,
+  # p99 0.0082, max 0.0195; vs the rounding oracle median 0.0028 px, p99 0.0084, max 0.0154, logits
+  # median 0.0016 / p99 0.0075, no argmax flips.  Gates = 2x.
+  assert rec['vs_3tile_kernel']['max'] < 0.04, rec
+  assert rec['vs_separate_launches']['median'] < 0.006 and rec['vs_separate_launches']['p99'] < 0.017, rec
   v = rec['vs_rounding_oracle']
-  assert v['argmax_flip_rate'] < 0.01, rec
-  assert v['tracks_px']['median'] < 0.02 and v['tracks_px']['p99'] < 0.3, rec
-  assert v['occlusion_logit']['median'] < 0.01 and v['occlusion_logit']['p99'] < 0.15, rec
+  assert v['argmax_flip_rate'] < 0.005, rec
+  assert v['tracks_px']['median'] < 0.006 and v['tracks_px']['p99'] < 0.017 and v['tracks_px']['max'] < 0.04, rec
+  assert v['occlusion_logit']['median'] < 0.004 and v['occlusion_logit']['p99'] < 0.015, rec

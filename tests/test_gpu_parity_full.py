@@ -43,11 +43,11 @@ def _np_grids(fg):
           [tuple(r) for r in fg.resolutions])
 
 
-def _oracle_subset(w, kw, video_shape, grids, qp, idx):
+def _oracle_subset(w, kw, video_shape, grids, qp, idx, rnd=None):
   lows, his, res = grids
   sub = qp[:, idx]
   ref = O.tapir_from_grids(w, video_shape, lows, his, res, sub, pyramid_level=kw['pyramid_level'],
-                           softmax_temperature=kw['softmax_temperature'])
+                           softmax_temperature=kw['softmax_temperature'], rnd=rnd)
   ql, _ = O.get_query_features(lows, his, res, sub, video_shape)
   _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], sub,
                                           softmax_temperature=kw['softmax_temperature'],
@@ -121,9 +121,11 @@ def test_bf16_end_to_end_vs_oracle():
   What bounds it: with these random-init weights the refinement is not contractive -- the f32 HIP
   build differs from the f32 oracle by ~1e-4 px for ~1e-6 relative re-association noise (a x100
   amplification), so 2^-9 operand rounding gives tenths of a pixel; the SURVEY.md 7 estimate
-  (median 8e-3 px) does not hold for them.  The gates are 1.5x the values measured on MI355X
-  (profiles/r02_accuracy_bf16.json), i.e. regression gates, not an accuracy claim; AJ on TAP-Vid
-  needs a trained checkpoint."""
+  (median 8e-3 px) does not hold for them.  The hot-path gates are 2x the values measured on
+  MI355X (profiles/r02_accuracy_bf16.json), the end-to-end ones 1.4-1.6x: regression gates, not an
+  accuracy claim -- the stage-level claim is tests/test_gpu_bf16_stages.py (every bf16 kernel against the
+  oracle with the bf16 build's roundings); AJ on TAP-Vid needs a trained checkpoint
+  (tests/test_gpu_aj_proxy.py is the offline stand-in)."""
   from tapnet_amd import tapir_model
   kw = KW['tapir']
   w = synthetic.make_weights(3, kw['pyramid_level'], kw['extra_convs'])
@@ -138,7 +140,12 @@ def test_bf16_end_to_end_vs_oracle():
   d32 = np.linalg.norm(out32['tracks'][:, idx] - ref['tracks'], axis=-1)[clear]
   del m32
   m16 = tapir_model.TAPIR(**kw, weights=w, device='cuda:0', dtype='bfloat16')
-  hot = _drift(m16(video, False, qp, feature_grids=fg32), ref, idx, clear)
+  out_hot = m16(video, False, qp, feature_grids=fg32)
+  hot = _drift(out_hot, ref, idx, clear)
+  # the same run against the oracle WITH the bf16 build's operand roundings (oracle.tapir_oracle.bf16_round):
+  # what is left is accumulation order and rounding-boundary flips, amplified by the refinement
+  ref16, _ = _oracle_subset(w, kw, video.shape, _np_grids(fg32), qp, idx, rnd=O.bf16_round)
+  hot16 = _drift(out_hot, ref16, idx, clear)
   e2e = _drift(m16(video, False, qp), ref, idx, clear)     # bf16 backbone inside
   fg16 = m16.get_feature_grids(torch.as_tensor(video).cuda())
   cos = {}
@@ -146,14 +153,22 @@ def test_bf16_end_to_end_vs_oracle():
     c = (a * b).sum(-1).flatten().float().cpu().numpy()
     cos[name] = dict(min=float(c.min()), p01=float(np.percentile(c, 1)), median=float(np.median(c)))
   rec = dict(config='TAPIR kwargs, 256x256x48, Q=256 (32-query subset vs the f32 numpy oracle)',
-             f32_build_tracks_px=_stats(d32), hot_path=hot, backbone_cosine=cos, end_to_end=e2e)
+             f32_build_tracks_px=_stats(d32), hot_path=hot, hot_path_vs_rounding_oracle=hot16,
+             backbone_cosine=cos, end_to_end=e2e)
   os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
   with open(os.path.join(ROOT, 'gpurun_out', 'accuracy_bf16.json'), 'w') as f:
     json.dump(rec, f, indent=1)
   print(json.dumps(rec))
   assert rec['f32_build_tracks_px']['max'] <= 1e-3
-  assert hot['tracks_px']['median'] <= 0.3 and hot['tracks_px']['p99'] <= 2.5, rec
-  assert hot['argmax_flip_rate'] <= 0.04, rec
+  # gates = 2x the values measured on MI355X (profiles/r02_accuracy_bf16.json: hot path median 0.0155 px,
+  # p99 0.137 px, flips 0.46 %; end to end 0.256 / 1.58 px, flips 9 %)
+  assert hot['tracks_px']['median'] <= 0.031 and hot['tracks_px']['p99'] <= 0.28, rec
+  assert hot['occlusion_logit']['p99'] <= 0.17 and hot['expected_dist_logit']['p99'] <= 0.15, rec
+  assert hot['argmax_flip_rate'] <= 0.01, rec
+  # against the rounding oracle the bf16 hot path must sit well inside its distance to the f32 oracle
+  # (measured: median 0.0030 px, p99 0.0099, max 0.0155, no flips -- 5x / 14x closer than to the f32 oracle)
+  assert hot16['tracks_px']['median'] <= 0.006 and hot16['tracks_px']['p99'] <= 0.02, rec
+  assert hot16['tracks_px']['max'] <= 0.04 and hot16['argmax_flip_rate'] <= 0.005, rec
   assert e2e['tracks_px']['median'] <= 0.36 and e2e['tracks_px']['p99'] <= 2.6, rec
   assert e2e['occlusion_logit']['p99'] <= 0.5 and e2e['expected_dist_logit']['p99'] <= 0.5, rec
   assert e2e['argmax_flip_rate'] <= 0.12, rec
