@@ -264,6 +264,26 @@ int tapir_stem_pack(tapir_ctx* ctx, const float* w, void** wstream);
 int tapir_stem_conv(tapir_ctx* ctx, const float* x, const void* wstream, void* y, float* part_out, int N,
                     int H, int W, void* stream);
 
+/* BootsTAPIR's ExtraConvs (tapnet/models/tapir_model.py:159-186, class ExtraConvs; torch twin
+ * tapnet/torch/nets.py:25-89): five blocks  y = LayerNorm(x) * scale + offset;  r = gelu(conv3x3(y) + b);
+ * x = y + conv3x3(r) + b'  on the low-resolution map.  NHWC tensors in the context's element type.
+ * tapir_layernorm_affine: hk.LayerNorm(axis=-1, create_scale=True, create_offset=True) per pixel (:176),
+ *   eps 1e-5; C / (8 bf16 | 4 f32) a power of two <= 64.
+ * tapir_xconv_plan : output rows per workgroup tile, tiles per image and input channels per LDS chunk for
+ *   an [H, W, cin] map (W <= 64; cin, cout multiples of 256), TAPIR_ERR_UNSUPPORTED otherwise.
+ * tapir_xconv_pack : w = the reference's [cout, cin, 3, 3] f32 kernel (torch OIHW, host memory) -> packed
+ *   fragment streams for chunks of `cch` input channels (the value tapir_xconv_plan returned); owned like
+ *   a tapir_conv_pack (tapir_conv_free).
+ * tapir_xconv      : y [N, H, W, cout] = conv3x3_SAME(x [N, H, W, cin]) + bias, then gelu (tanh form,
+ *   jax.nn.gelu :184) if `gelu`, or + skip [N, H, W, cout] if skip != NULL (:185), rounded to the element
+ *   type.  (hk.Conv2D(1024, 3) / hk.Conv2D(256, 3): stride 1, SAME padding, with bias.) */
+int tapir_layernorm_affine(tapir_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y,
+                           long pixels, int C, void* stream);
+int tapir_xconv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch);
+int tapir_xconv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int cch, void** wstream);
+int tapir_xconv(tapir_ctx* ctx, const void* x, const void* wstream, const float* bias, const void* skip,
+                void* y, int N, int H, int W, int cin, int cout, int gelu, void* stream);
+
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):
  * A [M,lda], W [N,ldw] in the context's operand type (f32 or bf16 bits), bias [N] f32 or NULL;

@@ -92,6 +92,9 @@ class Backbone:
     self._plans: Dict[tuple, Optional[tuple]] = {}
     self._stem_ws = None
     self._wstream: Dict[str, int] = {}
+    self._xstream: Dict[tuple, int] = {}     # ExtraConvs weight packs, by (conv name, input channels per chunk)
+    self._xhost: Dict[str, 'np.ndarray'] = {}
+    self.extra_convs_mode = os.environ.get('TAPIR_EXTRA_CONVS', 'hip')   # 'hip' | 'torch' (MIOpen convolutions + torch glue: the A/B switch)
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
     self.extra_convs = extra_convs
@@ -122,6 +125,10 @@ class Backbone:
                                  ctypes.byref(h))
         if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
           self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
+      for k, v in weights.items():          # ExtraConvs kernels: packed on first use (the chunking depends on the map)
+        if k.startswith('extra_convs.') and k.endswith(('conv.weight', 'conv_1.weight')):
+          self._xhost[k[:-len('.weight')]] = np.ascontiguousarray(
+              v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
       k = 'resnet_torch.initial_conv.weight'
       a = weights.get(k)
       if a is not None:
@@ -157,6 +164,9 @@ class Backbone:
     return s
 
   def _extra_convs_impl(self) -> str:
+    if self.extra_convs_mode == 'hip' and self._xhost:
+      return ('HIP: LayerNorm kernel + 3x3 implicit-GEMM MFMA kernels (256 -> 1024 with bias + GELU, 1024 -> 256 '
+              'with bias + skip in the epilogue)')
     return 'PyTorch-ROCm / MIOpen convolutions + torch LayerNorm / GELU'
 
   def close(self):
@@ -167,10 +177,11 @@ class Backbone:
     if eng is None:
       return
     lib, ctx = eng
-    for h in [v[0] for v in getattr(self, '_wstream', {}).values()] + [getattr(self, '_stem_ws', None)]:
+    for h in ([v[0] for v in getattr(self, '_wstream', {}).values()] + [getattr(self, '_stem_ws', None)] +
+              list(getattr(self, '_xstream', {}).values())):
       if h:
         lib.tapir_conv_free(ctx, h)
-    self._wstream, self._stem_ws = {}, None
+    self._wstream, self._stem_ws, self._xstream = {}, None, {}
 
   # -- ExtraConvs (BootsTAPIR): small 32x32 maps, PyTorch ops on the GPU -----
   def _conv(self, x, name, stride=1, bias=False):
@@ -188,6 +199,53 @@ class Backbone:
       x = xl.permute(0, 3, 1, 2)
       r = F.gelu(self._conv(x, p + 'conv', 1, bias=True), approximate='tanh')
       x = x + self._conv(r, p + 'conv_1', 1, bias=True)
+    return x
+
+  # -- ExtraConvs as HIP kernels (csrc/extra_convs.hpp) ----------------------
+  def _xplan(self, h, w, cin, cout):
+    key = ('x', h, w, cin, cout)
+    if key not in self._plans:
+      import ctypes
+      lib, ctx = self.engine
+      rows, tiles, cch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+      ok = lib.tapir_xconv_plan(ctx, h, w, cin, cout, ctypes.byref(rows), ctypes.byref(tiles), ctypes.byref(cch)) == 0
+      self._plans[key] = cch.value if ok else None
+    return self._plans[key]
+
+  def _xpack(self, name, cch):
+    key = (name, cch)
+    if key not in self._xstream:
+      import ctypes
+      lib, ctx = self.engine
+      a = self._xhost[name]
+      h = ctypes.c_void_p()
+      self._check(lib.tapir_xconv_pack(ctx, a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], cch,
+                                       ctypes.byref(h)), 'tapir_xconv_pack')
+      self._xstream[key] = h.value
+    return self._xstream[key]
+
+  def _extra_convs_hip(self, x):
+    """tapir_model.py:159-186 on an NHWC map [n,h,w,256] of the element type: per block one LayerNorm kernel
+    and two convolution kernels (bias + GELU / bias + skip in their epilogues).  None: shape not covered."""
+    lib, ctx = self.engine
+    n, h, w, c = x.shape
+    c1, c2 = self._xplan(h, w, c, 4 * c), self._xplan(h, w, 4 * c, c)
+    if c1 is None or c2 is None or not self._xhost:
+      return None
+    st = self._stream()
+    for blk in range(5):
+      p = f'extra_convs.blocks.{blk}.'
+      y = self._buf(('xln', n, h, w, c), (n, h, w, c), self.dtype)
+      self._check(lib.tapir_layernorm_affine(ctx, x.data_ptr(), self.w[p + 'layer_norm.weight'].data_ptr(),
+                                             self.w[p + 'layer_norm.bias'].data_ptr(), y.data_ptr(), n * h * w, c, st),
+                  'tapir_layernorm_affine')
+      r = self._buf(('xhid', n, h, w, 4 * c), (n, h, w, 4 * c), self.dtype)
+      self._check(lib.tapir_xconv(ctx, y.data_ptr(), self._xpack(p + 'conv', c1), self.w[p + 'conv.bias'].data_ptr(),
+                                  None, r.data_ptr(), n, h, w, c, 4 * c, 1, st), 'tapir_xconv')
+      out = self._buf(('xout', blk & 1, n, h, w, c), (n, h, w, c), self.dtype)
+      self._check(lib.tapir_xconv(ctx, r.data_ptr(), self._xpack(p + 'conv_1', c2), self.w[p + 'conv_1.bias'].data_ptr(),
+                                  y.data_ptr(), out.data_ptr(), n, h, w, 4 * c, c, 0, st), 'tapir_xconv')
+      x = out
     return x
 
   # -- GPU path: MIOpen convolutions + HIP glue kernels ---------------------
@@ -355,7 +413,8 @@ class Backbone:
       if g == 1:
         unit1 = x
     if self.extra_convs:
-      x = self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+      xe = self._extra_convs_hip(x) if self.extra_convs_mode == 'hip' else None
+      x = xe if xe is not None else self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
     return self._hip_l2norm(x, out_low), self._hip_l2norm(unit1, out_hi)
 
   # -- public ---------------------------------------------------------------
@@ -389,7 +448,7 @@ class Backbone:
     else:
       per = -(-n // streams)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
-    key = (n, H, W, self._hip_now, tuple(sorted(self.hip_convs)), streams, tuple(bounds))
+    key = (n, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds))
     if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need
       key = None                                                       #  every dispatch on its own)
     if (key is not None and self.graph_min_frames and n >= self.graph_min_frames

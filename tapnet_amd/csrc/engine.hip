@@ -15,6 +15,7 @@
 #include "conv_fused.hpp"
 #include "costvol.hpp"
 #include "costvol_fused.hpp"
+#include "extra_convs.hpp"
 #include "gemm.hpp"
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
@@ -1271,6 +1272,89 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
   ca.dbg_times = (long long*)c->dbg_times;
   if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+  HIP_TRY(c, hipGetLastError());
+  return TAPIR_OK;
+}
+
+// ---- BootsTAPIR's ExtraConvs (tapir_model.py:159-186; extra_convs.hpp)
+int tapir_layernorm_affine(tapir_ctx* c, const void* x, const float* gamma, const float* beta, void* y,
+                           long pixels, int C, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!x || !gamma || !beta || !y || pixels < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!norm_channels_ok(c, C, 64)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  const int ept = c->cfg.dtype == TAPIR_BF16 ? 8 : 4;
+  const int PP = NORM_THREADS / (C / ept);
+  LnAffineArgs la{x, gamma, beta, y, pixels, C};
+  const unsigned grid = (unsigned)std::min<long>((pixels + PP - 1) / PP, 8192);
+  if (c->cfg.dtype == TAPIR_BF16)
+    hipLaunchKernelGGL((ln_affine_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+  else
+    hipLaunchKernelGGL((ln_affine_kernel<float>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+  return TAPIR_OK;
+}
+
+int tapir_xconv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch) {
+  if (!c || !rows || !tiles || !cch) return TAPIR_ERR_INVALID;
+  if (!xconv_plan(H, W, cin, cout, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles, cch))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  return TAPIR_OK;
+}
+
+int tapir_xconv_pack(tapir_ctx* c, const float* w, int cout, int cin, int cch, void** wstream) {
+  if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  const int kstep_n = bf ? 32 : 16, epc = bf ? 8 : 4;
+  if (cout % 256 || cin % 256 || cch < 64 || cch > 256 || (cch & (cch - 1)) || cin % cch)
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: channel counts");
+  // stream of output-channel group cg (64 channels), in the order a wave multiplies: for input-channel
+  // chunk, tap, k-step of the chunk, row tile r -- fragment row m = l & 15 holds output channel
+  // cg*64 + 16 (m >> 2) + 4 r + (m & 3) (the row permutation of the epilogue, as tapir_conv_pack),
+  // input channels chunk*cch + KSTEP kstep + EPC (l >> 4) + j.  w = torch OIHW [cout, cin, 3, 3].
+  const long fpc = xconv_frags_per_cg(cin, kstep_n);
+  std::vector<uint8_t> host((size_t)(cout / 64) * fpc * 1024, 0);
+  for (int cg = 0; cg < cout / 64; ++cg) {
+    uint8_t* q = host.data() + (size_t)cg * fpc * 1024;
+    for (int chn = 0; chn < cin / cch; ++chn)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int kstep = 0; kstep < cch / kstep_n; ++kstep)
+          for (int r = 0; r < 4; ++r, q += 1024)
+            for (int l = 0; l < 64; ++l)
+              for (int j = 0; j < epc; ++j) {
+                const int m = l & 15;
+                const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3);
+                const int ci = chn * cch + kstep_n * kstep + epc * (l >> 4) + j;
+                const float v = w[((size_t)co * cin + ci) * 9 + tap];
+                if (bf) ((uint16_t*)q)[l * epc + j] = host_f2bf(v);
+                else ((float*)q)[l * epc + j] = v;
+              }
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->conv_owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  *wstream = d;
+  return TAPIR_OK;
+}
+
+int tapir_xconv(tapir_ctx* c, const void* x, const void* wstream, const float* bias, const void* skip, void* y,
+                int N, int H, int W, int cin, int cout, int gelu, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!x || !wstream || !bias || !y || N < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (gelu && skip) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: gelu and skip together");
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  int rows = 0, tiles = 0, cch = 0;
+  if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  XConvArgs xa{};
+  xa.x = x; xa.wstream = (const uint4*)wstream; xa.frags_per_cg = xconv_frags_per_cg(cin, bf ? 32 : 16);
+  xa.bias = bias; xa.skip = skip; xa.y = y;
+  xa.N = N; xa.H = H; xa.W = W; xa.cin = cin; xa.cout = cout;
+  xa.TH = rows; xa.tiles = tiles; xa.passes = cout / 256;
+  const bool ok = bf ? launch_xconv<bf16_t>(xa, cch, gelu != 0, (hipStream_t)stream)
+                     : launch_xconv<float>(xa, cch, gelu != 0, (hipStream_t)stream);
+  if (!ok) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: no kernel for this chunking");
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }

@@ -1,0 +1,112 @@
+"""BootsTAPIR's ExtraConvs kernels (csrc/extra_convs.hpp: per-pixel LayerNorm, 3x3 implicit-GEMM convolution
+with bias + GELU / bias + skip in the epilogue, output-channel passes, input-channel chunks) on the fiber
+emulator, against numpy restatements of tapnet/models/tapir_model.py:159-186 on the same rounded operands
+(bf16 build) and in float64 (f32 build)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tapnet_amd import _ffi
+from tests.emu_engine import emu_lib
+from tests.test_conv_fused_emulated import _conv_ref, _ctx, _p, _r
+from tests.test_gemm_tiles_emulated import from_bf16_bits, to_bf16_bits
+
+
+def _gelu(x):
+  return 0.5 * x * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * x ** 3)))
+
+
+def _ln(x, g, b):
+  x = x.astype(np.float64)
+  m = x.mean(-1, keepdims=True)
+  v = x.var(-1, keepdims=True)
+  return (x - m) / np.sqrt(v + 1e-5) * g + b
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+def test_layernorm_affine(dtype):
+  lib = emu_lib()
+  bf = dtype == 'bf16'
+  ctx = _ctx(lib, _ffi.TAPIR_BF16 if bf else _ffi.TAPIR_F32)
+  rng = np.random.default_rng(0)
+  P, C = 37, 256
+  x = (rng.standard_normal((P, C)) * 2 + 0.7).astype(np.float32)
+  g = rng.uniform(0.5, 1.5, C).astype(np.float32)
+  b = (rng.standard_normal(C) * 0.2).astype(np.float32)
+  if bf:
+    x = _r(x)
+    xin, y = to_bf16_bits(x), np.zeros((P, C), np.uint16)
+  else:
+    xin, y = x, np.zeros((P, C), np.float32)
+  assert lib.tapir_layernorm_affine(ctx, _p(xin), _p(g), _p(b), _p(y), P, C, None) == 0
+  got = from_bf16_bits(y) if bf else y
+  np.testing.assert_allclose(got, _ln(x, g, b), atol=2e-2 if bf else 2e-5, rtol=1e-2 if bf else 0)
+  lib.tapir_destroy(ctx)
+
+
+def _xconv(lib, ctx, bf, x, w, bias, skip, gelu):
+  N, H, W, cin = x.shape
+  cout = w.shape[0]
+  rows, tiles, cch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_xconv_plan(ctx, H, W, cin, cout, ctypes.byref(rows), ctypes.byref(tiles), ctypes.byref(cch)) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_xconv_pack(ctx, _p(np.ascontiguousarray(w, np.float32)), cout, cin, cch.value, ctypes.byref(ws)) == 0
+  if bf:
+    xin, sk, y = to_bf16_bits(x), (to_bf16_bits(skip) if skip is not None else None), np.zeros((N, H, W, cout), np.uint16)
+  else:
+    xin, sk, y = x, skip, np.zeros((N, H, W, cout), np.float32)
+  rc = lib.tapir_xconv(ctx, _p(xin), ws, _p(bias), _p(sk), _p(y), N, H, W, cin, cout, 1 if gelu else 0, None)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  assert lib.tapir_conv_free(ctx, ws) == 0
+  return (from_bf16_bits(y) if bf else y), rows.value, tiles.value, cch.value
+
+
+# (H, W): 2 rows x 32 (the 256x256 model), ragged last tile, one row of 64 (512x512 inputs), 8x8 (one tile),
+# a narrow map with unused pixel columns
+@pytest.mark.parametrize('dtype,H,W', [('bf16', 4, 32), ('bf16', 5, 32), ('bf16', 2, 64), ('bf16', 8, 8),
+                                       ('bf16', 3, 24), ('f32', 3, 32), ('f32', 2, 64), ('f32', 4, 8)])
+def test_xconv_up_gelu_and_down_skip(dtype, H, W):
+  """conv 256 -> 1024 (+ bias, GELU: 4 output-channel passes) and conv 1024 -> 256 (+ bias + skip: input
+  channels in 4-16 LDS chunks), asymmetric random operands."""
+  lib = emu_lib()
+  bf = dtype == 'bf16'
+  ctx = _ctx(lib, _ffi.TAPIR_BF16 if bf else _ffi.TAPIR_F32)
+  rng = np.random.default_rng(H * 100 + W)
+  N, C = 2, 256
+  rd = _r if bf else (lambda a: np.asarray(a, np.float32))
+  x = rd(rng.standard_normal((N, H, W, C)))
+  w1 = (rng.standard_normal((4 * C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  b1 = (rng.standard_normal(4 * C) * 0.1).astype(np.float32)
+  got, rows, tiles, cch = _xconv(lib, ctx, bf, x, w1, b1, None, True)
+  assert rows == min(H, 64 // W) and tiles == -(-H // rows)
+  ref = _gelu(_conv_ref(x, rd(w1)) + b1)
+  if bf:
+    np.testing.assert_allclose(got, ref, atol=1.5e-2, rtol=1e-2)
+    assert np.abs(got - ref).mean() < 2e-3
+  else:
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+  # second convolution of the block on the (rounded) hidden tensor, skip = the block's normalised input
+  hdn = rd(ref)
+  w2 = (rng.standard_normal((C, 4 * C, 3, 3)) / np.sqrt(9 * 4 * C)).astype(np.float32)
+  b2 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+  got2, _, _, cch2 = _xconv(lib, ctx, bf, hdn, w2, b2, x, False)
+  assert 1024 % cch2 == 0 and cch2 <= cch
+  ref2 = _conv_ref(hdn, rd(w2)) + b2 + x
+  if bf:
+    np.testing.assert_allclose(got2, ref2, atol=2e-2, rtol=1e-2)
+    assert np.abs(got2 - ref2).mean() < 3e-3
+  else:
+    np.testing.assert_allclose(got2, ref2, atol=5e-5)
+  lib.tapir_destroy(ctx)
+
+
+def test_xconv_rejects_unsupported_shapes():
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  r, t, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_xconv_plan(ctx, 8, 80, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_xconv_plan(ctx, 8, 32, 128, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_xconv_plan(ctx, 32, 32, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == 0
+  assert (r.value, t.value, c.value) == (2, 16, 256)
+  lib.tapir_destroy(ctx)

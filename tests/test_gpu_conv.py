@@ -266,3 +266,79 @@ def test_backbone_graph_replay_and_streams_match_eager(model):
     assert all(torch.equal(a, b) for a, b in zip(out, ref))
   finally:
     bb.graph_min_frames, bb.streams = saved
+
+
+@pytest.mark.parametrize('dtype,n,h,w', [('float32', 2, 32, 32), ('bfloat16', 3, 32, 32), ('float32', 1, 64, 64),
+                                         ('bfloat16', 2, 64, 64), ('bfloat16', 2, 24, 32)])
+def test_extra_convs_block_vs_torch(dtype, n, h, w):
+  """One ExtraConvs block (tapir_model.py:159-186) through the C ABI -- tapir_layernorm_affine, tapir_xconv
+  256 -> 1024 (+ bias + GELU), tapir_xconv 1024 -> 256 (+ bias + skip) -- against torch float64 on the same
+  operands (bf16 build: operands and stored intermediates rounded to bf16 as the kernels round them)."""
+  from tapnet_amd import tapir_model
+  bf = dtype == 'bfloat16'
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=synthetic.make_weights(21, 1, False, backbone=False),
+                        device='cuda:0', dtype=dtype)
+  lib, ctx, dev, st = m._lib, m._ctx, m.device, m._stream()
+  tt = torch.bfloat16 if bf else torch.float32
+  g = torch.Generator(device='cpu').manual_seed(h + w + n)
+  C = 256
+  x = (torch.randn(n, h, w, C, generator=g) * 1.3 + 0.4).to(dev).to(tt)
+  gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+  beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+  w1 = (torch.randn(4 * C, C, 3, 3, generator=g) / (9 * C) ** 0.5).contiguous()
+  b1 = (torch.randn(4 * C, generator=g) * 0.1).to(dev)
+  w2 = (torch.randn(C, 4 * C, 3, 3, generator=g) / (9 * 4 * C) ** 0.5).contiguous()
+  b2 = (torch.randn(C, generator=g) * 0.1).to(dev)
+  rows, tiles, c1, c2 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_xconv_plan(ctx, h, w, C, 4 * C, ctypes.byref(rows), ctypes.byref(tiles), ctypes.byref(c1)) == 0
+  assert lib.tapir_xconv_plan(ctx, h, w, 4 * C, C, ctypes.byref(rows), ctypes.byref(tiles), ctypes.byref(c2)) == 0
+  ws1, ws2 = ctypes.c_void_p(), ctypes.c_void_p()
+  assert lib.tapir_xconv_pack(ctx, ctypes.c_void_p(w1.data_ptr()), 4 * C, C, c1.value, ctypes.byref(ws1)) == 0
+  assert lib.tapir_xconv_pack(ctx, ctypes.c_void_p(w2.data_ptr()), C, 4 * C, c2.value, ctypes.byref(ws2)) == 0
+  y = torch.zeros(n, h, w, C, device=dev, dtype=tt)
+  r = torch.zeros(n, h, w, 4 * C, device=dev, dtype=tt)
+  out = torch.zeros(n, h, w, C, device=dev, dtype=tt)
+  assert lib.tapir_layernorm_affine(ctx, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), n * h * w, C, st) == 0
+  assert lib.tapir_xconv(ctx, y.data_ptr(), ws1, b1.data_ptr(), None, r.data_ptr(), n, h, w, C, 4 * C, 1, st) == 0, lib.tapir_last_error(ctx)
+  assert lib.tapir_xconv(ctx, r.data_ptr(), ws2, b2.data_ptr(), y.data_ptr(), out.data_ptr(), n, h, w, 4 * C, C, 0, st) == 0
+  torch.cuda.synchronize()
+  rd = (lambda t: t.to(torch.bfloat16).double()) if bf else (lambda t: t.double())
+  yr = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), eps=1e-5)
+  tol = dict(atol=2e-2, rtol=1e-2) if bf else dict(atol=2e-4, rtol=0)
+  torch.testing.assert_close(y.double(), yr, **tol)
+  # each stage against the reference applied to the kernel's own (stored) input of that stage
+  conv = lambda a, wt: F.conv2d(a.permute(0, 3, 1, 2), wt.to(dev), padding=1).permute(0, 2, 3, 1)
+  rr = F.gelu(conv(y.double(), rd(w1)) + b1.double(), approximate='tanh')
+  torch.testing.assert_close(r.double(), rr, **tol)
+  orr = conv(r.double(), rd(w2)) + b2.double() + y.double()
+  torch.testing.assert_close(out.double(), orr, **tol)
+  if bf:
+    assert float((r.double() - rr).abs().mean()) < 1.5e-3 and float((out.double() - orr).abs().mean()) < 3e-3
+  for hnd in (ws1, ws2):
+    assert lib.tapir_conv_free(ctx, hnd) == 0
+
+
+def test_extra_convs_hip_vs_torch_path():
+  """Backbone.features of the BootsTAPIR model with the ExtraConvs as HIP kernels and as MIOpen convolutions +
+  torch glue (the round-2 path, kept as the A/B switch): f32 grids agree to 2e-5, bf16 grids are as close to
+  the f32 ones either way."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(21, 1, True)
+  frames = torch.as_tensor(synthetic.make_video(3, 6, 256, 256), device='cuda:0').reshape(-1, 256, 256, 3).float()
+  m32 = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='float32')
+  bb = m32._backbone
+  bb.extra_convs_mode = 'torch'
+  ref = [t.clone() for t in bb.features(frames)]
+  bb.extra_convs_mode = 'hip'
+  got = bb.features(frames)
+  assert bb._xstream, 'the ExtraConvs kernels were not packed'
+  assert float((ref[0] - got[0]).abs().max()) < 2e-5, float((ref[0] - got[0]).abs().max())
+  m16 = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='bfloat16')
+  b16 = m16._backbone
+  b16.extra_convs_mode = 'torch'
+  t16 = [t.clone() for t in b16.features(frames)]
+  b16.extra_convs_mode = 'hip'
+  h16 = b16.features(frames)
+  cos_t, cos_h = (ref[0] * t16[0]).sum(-1).min(), (ref[0] * h16[0]).sum(-1).min()
+  print(f'min cosine to the f32 grids: torch path {float(cos_t):.5f}, HIP path {float(cos_h):.5f}')
+  assert float(cos_h) > 0.998 and float(cos_h) > float(cos_t) - 5e-4

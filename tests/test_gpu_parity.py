@@ -170,8 +170,15 @@ def test_full_call_golden_with_backbone():
   cfg, g, w = load_case('bootstapir')
   m = _model(cfg, w)
   out = m(g['video'], False, g['query_points'])
-  np.testing.assert_allclose(out['tracks'], g['tracks'], atol=5e-3)
-  np.testing.assert_allclose(out['occlusion'], g['occlusion'], atol=5e-3)
+  et = float(np.abs(out['tracks'] - g['tracks']).max())
+  eo = float(np.abs(out['occlusion'] - g['occlusion']).max())
+  print(f'full call (BootsTAPIR kwargs, HIP backbone incl. ExtraConvs) vs reference golden: tracks {et:.2e} px, occlusion {eo:.2e}')
+  # north_star: 1e-3 abs in f32 (measured on MI355X with the whole backbone -- ResNet and ExtraConvs -- in
+  # exact-f32 HIP kernels: 9.9e-5 px, 8.2e-6 on the logits; the round-2 gate of 5e-3 dated from MIOpen
+  # convolutions with atomically accumulated partial sums)
+  np.testing.assert_allclose(out['tracks'], g['tracks'], atol=1e-3)
+  np.testing.assert_allclose(out['occlusion'], g['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'], g['expected_dist'], atol=1e-3)
 
 
 # ---------------------------------------------------------------- full-size properties
