@@ -413,7 +413,9 @@ class Backbone:
       if g == 1:
         unit1 = x
     if self.extra_convs:
-      xe = self._extra_convs_hip(x) if self.extra_convs_mode == 'hip' else None
+      # (like the ResNet convolutions: a single frame -- the online model -- gives the HIP kernels 16-64
+      # workgroups per launch; the library's split-K kernels win there)
+      xe = self._extra_convs_hip(x) if (self.extra_convs_mode == 'hip' and self._hip_now) else None
       x = xe if xe is not None else self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
     return self._hip_l2norm(x, out_low), self._hip_l2norm(unit1, out_hi)
 

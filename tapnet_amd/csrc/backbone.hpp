@@ -188,42 +188,59 @@ struct NormFinalizeArgs {
   int planar;           // P = 8 | 4: ss is [N, C / P, 2, P] (the P scales of a channel chunk, then its P shifts); 0: [N, C, 2]
 };
 
-// grid (N, C / 64), 256 threads = 64 channels x 4 slab lanes: lane q of a channel merges the slabs
-// q, q + 4, ... (all of its loads issued before the first merge), the four partial summaries meet in
-// LDS.  (One thread per channel walking 64 slabs serially took 9 us per launch, 20 launches per clip.)
+// grid (N, C / 64), 256 threads = 64 channels x 4 slab lanes: lane q of a channel takes the slabs
+// q, q + 4, ...  Two passes over the summaries (all loads of a pass issued before the first use): the
+// weighted mean, then M2 about it -- Chan's formula for all slabs at once, no serial chain of pairwise
+// merges with a division each (that chain was 9 us per launch, 20 launches on every stream's dependency
+// chain per clip); the four partial sums of a channel meet in LDS.
 constexpr int NORM_FIN_LANES = 4;
 constexpr int NORM_FIN_MAXS = 16;    // slabs per lane held in registers per round
 __global__ __launch_bounds__(NORM_THREADS) void inorm_finalize_kernel(NormFinalizeArgs a) {
-  __shared__ float s_sum[NORM_FIN_LANES][64][3];
+  __shared__ float s_red[NORM_FIN_LANES][64];
   const int n = blockIdx.x;
   const int ch = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + ch;
+  const int c = min((int)blockIdx.y * 64 + ch, a.C - 1);
+  const bool live = (int)blockIdx.y * 64 + ch < a.C;
   const int per_s = a.per_s > 0 ? a.per_s : (a.HW + a.slabs - 1) / a.slabs;
-  float cn = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < a.C) {
-    for (int s0 = q; s0 < a.slabs; s0 += NORM_FIN_LANES * NORM_FIN_MAXS) {
-      float2 v[NORM_FIN_MAXS];
+  const float2* ps = reinterpret_cast<const float2*>(a.part) + (long)n * a.slabs * a.C + c;
+  auto slab_n = [&](int s) { return s < a.slabs ? (float)max(0, min(a.HW, (s + 1) * per_s) - s * per_s) : 0.f; };
+  const float inv_hw = 1.0f / (float)a.HW;
+  const bool one_round = a.slabs <= NORM_FIN_LANES * NORM_FIN_MAXS;
+  float2 v[NORM_FIN_MAXS];
+  float s1 = 0.f;
+  for (int s0 = q; s0 < a.slabs; s0 += NORM_FIN_LANES * NORM_FIN_MAXS) {
 #pragma unroll
-      for (int k = 0; k < NORM_FIN_MAXS; ++k) {
-        const int s = min(s0 + k * NORM_FIN_LANES, a.slabs - 1);
-        v[k] = *reinterpret_cast<const float2*>(a.part + (((long)n * a.slabs + s) * a.C + c) * 2);
-      }
+    for (int k = 0; k < NORM_FIN_MAXS; ++k) v[k] = ps[(long)min(s0 + k * NORM_FIN_LANES, a.slabs - 1) * a.C];
 #pragma unroll
-      for (int k = 0; k < NORM_FIN_MAXS; ++k) {
-        const int s = s0 + k * NORM_FIN_LANES;
-        if (s < a.slabs) {
-          const float nb = (float)max(0, min(a.HW, (s + 1) * per_s) - s * per_s);
-          merge_stats(cn, mean, m2, nb, v[k].x, v[k].y);
-        }
-      }
+    for (int k = 0; k < NORM_FIN_MAXS; ++k) s1 = fmaf(slab_n(s0 + k * NORM_FIN_LANES), v[k].x, s1);
+  }
+  s_red[q][ch] = s1;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_FIN_LANES; ++k) mean += s_red[k][ch];
+  mean *= inv_hw;
+  float m2 = 0.f;
+  for (int s0 = q; s0 < a.slabs; s0 += NORM_FIN_LANES * NORM_FIN_MAXS) {
+    if (!one_round) {   // (more than 64 slabs: the registers hold the last round only)
+#pragma unroll
+      for (int k = 0; k < NORM_FIN_MAXS; ++k) v[k] = ps[(long)min(s0 + k * NORM_FIN_LANES, a.slabs - 1) * a.C];
+    }
+#pragma unroll
+    for (int k = 0; k < NORM_FIN_MAXS; ++k) {
+      const float nk = slab_n(s0 + k * NORM_FIN_LANES);
+      const float d = v[k].x - mean;
+      m2 += nk > 0.f ? fmaf(nk * d, d, v[k].y) : 0.f;
     }
   }
-  s_sum[q][ch][0] = cn; s_sum[q][ch][1] = mean; s_sum[q][ch][2] = m2;
+  __syncthreads();        // every lane has read the first partial sums
+  s_red[q][ch] = m2;
   __syncthreads();
-  if (q == 0 && c < a.C) {
+  if (q == 0 && live) {
+    float tot = 0.f;
 #pragma unroll
-    for (int k = 1; k < NORM_FIN_LANES; ++k) merge_stats(cn, mean, m2, s_sum[k][ch][0], s_sum[k][ch][1], s_sum[k][ch][2]);
-    const float rstd = 1.0f / sqrtf(m2 / (float)a.HW + kInEps);
+    for (int k = 0; k < NORM_FIN_LANES; ++k) tot += s_red[k][ch];
+    const float rstd = 1.0f / sqrtf(tot * inv_hw + kInEps);
     const float sc = rstd * a.gamma[c];
     const int P = a.planar;
     const long i0 = P ? ((long)n * a.C + (c & ~(P - 1))) * 2 + (c & (P - 1)) : ((long)n * a.C + c) * 2;

@@ -85,8 +85,16 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   const int h = a.h, w = a.w, hw = h * w;
   const int pw = w + 2, pn = pw * (h + 2);
   const int qtiles = (a.Q + QPW - 1) / QPW;
-  const int qt = blockIdx.x % qtiles;
-  const long frame = blockIdx.x / qtiles;            // b * T + t
+  // Consecutive workgroup ids go round the 8 XCDs (each with its own L2): XCD x takes the x-th CONTIGUOUS
+  // eighth of the (frame, query tile) units, i.e. all query tiles of its frames -- a frame's grid (512 KiB)
+  // comes into ONE L2 once.  (In launch order the 16 tiles of a frame landed on all eight XCDs: 202 MB
+  // fetched per launch for a 25 MB grid, profiles/r02_pmc_traffic.json.)
+  const long units = (long)a.B * a.T * qtiles;
+  const long per_xcd = (units + 7) >> 3;
+  const long unit = (long)(blockIdx.x & 7u) * per_xcd + (long)(blockIdx.x >> 3);
+  if (unit >= units) return;
+  const int qt = (int)(unit % qtiles);
+  const long frame = unit / qtiles;                  // b * T + t
   const int t = (int)(frame % a.T);
   const long b = frame / a.T;
   const int q0 = qt * QPW;
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   }
   if (TRACE && a.dbg_times != nullptr && tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a.dbg_times[(long)blockIdx.x * 8 + k] = (long long)tph[k];
+    for (int k = 0; k < 8; ++k) a.dbg_times[unit * 8 + k] = (long long)tph[k];
   }
 }
 
@@ -408,11 +416,11 @@ inline void launch_cv_fused(const CvFusedArgs& a, hipStream_t s) {
   const int qtiles = (a.Q + CvFusedCfg<TA>::QPW - 1) / CvFusedCfg<TA>::QPW;
 #ifdef TAPIR_EXPERIMENTS
   if (a.dbg_times != nullptr) {
-    hipLaunchKernelGGL((cv_fused_kernel<TA, true>), dim3((unsigned)((long)a.B * a.T * qtiles)), dim3(CVF_THREADS), 0, s, a);
+    hipLaunchKernelGGL((cv_fused_kernel<TA, true>), dim3((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), dim3(CVF_THREADS), 0, s, a);
     return;
   }
 #endif
-  TAPIR_LAUNCH((cv_fused_kernel<TA>), dim3((unsigned)((long)a.B * a.T * qtiles)), dim3(CVF_THREADS), s, a);
+  TAPIR_LAUNCH((cv_fused_kernel<TA>), dim3((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), dim3(CVF_THREADS), s, a);
 }
 
 }  // namespace tapir

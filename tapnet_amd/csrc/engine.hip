@@ -563,7 +563,8 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 1) fused = wide = false;
     if (c->mixer_mode == 2) wide = false;
-    if (c->mixer_mode == 3) fused = false;
+    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
+    if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
       // share the weight stream (MFMA-bound instead of L2-fill-bound); below ~128 tracks the tiled /
@@ -583,6 +584,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       fa.dbg_times = (long long*)c->dbg_times;
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
+      fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
       if (wide) launch_mixer_fused_wide(fa, s);
       else launch_mixer_fused<TA>(fa, s);
@@ -1452,7 +1454,12 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 }
 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 3) return TAPIR_ERR_INVALID;
+#ifdef TAPIR_EXPERIMENTS
+  const int max_mode = 4;   // 4: timing-only pair simulation of the wide kernel (tools/kbench.py)
+#else
+  const int max_mode = 3;
+#endif
+  if (!c || mode < 0 || mode > max_mode) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
   return TAPIR_OK;
 }

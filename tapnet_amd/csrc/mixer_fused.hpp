@@ -82,6 +82,7 @@ struct FusedArgs {
   float* res;                    // [N*T, 388]
   int N, T;
   long long* dbg_times;          // TRACE build: [N][8 waves][8] shader-cycle totals per phase
+  int pair_sim;                  // TAPIR_EXPERIMENTS builds: timing-only stand-in of the wide kernel (mixer_fused_wide.hpp)
 };
 
 // Number of A fragments in one wave's stream (host packing and kernel must agree).

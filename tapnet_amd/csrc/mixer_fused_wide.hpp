@@ -30,7 +30,10 @@ inline long fused_wide_frags_per_wave(int k0_pad, int nblocks) {
 }
 
 // NTT token tiles per track, NTRK tracks per workgroup; NTT * NTRK in 4 .. 6.
-template <int NTT, int NTRK, bool RAGGED>
+// SIM (TAPIR_EXPERIMENTS builds only, tools/kbench.py): 1 = TIMING-ONLY stand-in for a paired design in which
+// two CUs share two tracks and each takes half of the hidden units of both -- one workgroup per track, token
+// mixing for one track, half of the hidden chunks for both; its outputs are meaningless.
+template <int NTT, int NTRK, bool RAGGED, int SIM = 0>
 __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs a) {
   typedef bf16_t TA;
   constexpr int NT = NTT * NTRK;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
   // LayerNorm summaries live in the hidden-chunk region (dead outside the chunk loop)
   float2 (*const s_stat)[ROWS][8] = reinterpret_cast<float2 (*)[ROWS][8]>(s_h);
   const int ch_lane = 64 * wave + 4 * g;
-  const int trk0 = blockIdx.x * NTRK;        // first track of this workgroup
+  const int trk0 = SIM ? (int)(blockIdx.x & ~1u) : (int)blockIdx.x * NTRK;   // first track of this workgroup
 
   const uint4* wp = a.stream + ((long)wave * a.frags_per_wave) * 64 + lane;
   uint4 ring[RING];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
         const f32x4* pw = reinterpret_cast<const f32x4*>(s_act) +
                           opaque((ch_lane + 16 * q + 2 * rp) >> 1) * (2 * FM_MIXW / 4);
 #pragma unroll
-        for (int tk = 0; tk < NTRK; ++tk) {
+        for (int tk = 0; tk < (SIM ? 1 : NTRK); ++tk) {
           f32x2 xc[NTT], xp[NTT], xq[NTT], s0[NTT], s1[NTT], s2[NTT];
           const f32x2 zero = f32x2{0.f, 0.f};
 #pragma unroll
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
     }
     *reinterpret_cast<f32x4*>(&s_bup[tid * 4]) = gload4(bp.bup + tid * 4);
     lds_barrier();
-    for (int hc = 0; hc < NC; ++hc) {
+    for (int hc = 0; hc < (SIM ? NC / 2 : NC); ++hc) {
       f32x4 ua[RAU][NT];
 #pragma unroll
       for (int r = 0; r < RAU; ++r) {
@@ -327,6 +330,12 @@ inline void launch_mixer_fused_wide(const FusedArgs& a, hipStream_t s) {
     if (ragged) TAPIR_LAUNCH((mixer_fused_wide_kernel<NTT_, NTRK_, true>), grid, block, s, a);            \
     else TAPIR_LAUNCH((mixer_fused_wide_kernel<NTT_, NTRK_, false>), grid, block, s, a);                  \
   } while (0)
+#ifdef TAPIR_EXPERIMENTS
+  if (a.pair_sim && ntt == 3 && !ragged) {
+    hipLaunchKernelGGL((mixer_fused_wide_kernel<3, 2, false, 1>), dim3((unsigned)a.N), block, 0, s, a);
+    return;
+  }
+#endif
   if (ntt == 2) TAPIR_WIDE(2, 2);
   else if (ntt == 3) TAPIR_WIDE(3, 2);
   else if (T <= 64) TAPIR_WIDE(4, 1);

@@ -323,6 +323,8 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (512, 48), 
       modes.append((2, 'fused'))
     if model.dtype == 'bfloat16' and T > 16:
       modes.append((3, 'fused_wide'))
+    if os.environ.get('KBENCH_PAIRSIM') and model.dtype == 'bfloat16' and T == 48 and N % 2 == 0:
+      modes.append((4, 'pair_sim_TIMING_ONLY'))   # (-DTAPIR_EXPERIMENTS builds; meaningless outputs)
     for mode, name in modes:
       assert lib.tapir_debug_set_mixer_mode(ctx, mode) == 0
       out = torch.empty(N, T, 388, device=dev)
@@ -594,7 +596,11 @@ def main():
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
-      bench_mixer(model, args.reps, results)
+      if os.environ.get('KBENCH_MIXER_SHAPES'):
+        shapes = tuple(tuple(int(v) for v in t.split('x')) for t in os.environ['KBENCH_MIXER_SHAPES'].split(','))
+        bench_mixer(model, args.reps, results, shapes)
+      else:
+        bench_mixer(model, args.reps, results)
     if need_bb:
       bench_backbone(model, args.reps, results)
   os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -23,13 +23,17 @@ KERNELS = {
     'mixer_fused_wide': ('mixer_fused_wide_kernel<3, 2, false', ''),
     'cv_fused': ('cv_fused_kernel<unsigned short', ''),
     'patch_corr': ('patch_corr_kernel<unsigned short', ''),
-    'conv3x3_c64_shortcut': ('conv_fused_kernel<64, 64, 3, 1, 4, 4, true', ''),
-    'conv3x3_c64': ('conv_fused_kernel<64, 64, 3, 1, 4, 4, false', ''),
-    'conv3x3_c128_shortcut': ('conv_fused_kernel<128, 128, 3, 1, 4, 4, true', ''),
-    'conv3x3_c256_shortcut': ('conv_fused_kernel<256, 256, 3, 1, 4, 4, true', ''),
-    'conv3x3_c256': ('conv_fused_kernel<256, 256, 3, 1, 4, 4, false', ''),
-    'conv3x3_s2_64_128': ('conv_fused_kernel<64, 128, 3, 2', ''),
+    'conv3x3_c64_shortcut': ('conv_fused_kernel<', '64, 64, 3, 1, 4, 4, true'),
+    'conv3x3_c64': ('conv_fused_kernel<', '64, 64, 3, 1, 4, 4, false'),
+    'conv3x3_c128_shortcut': ('conv_fused_kernel<', '128, 128, 3, 1, 4, 4, true'),
+    'conv3x3_c256_shortcut': ('conv_fused_kernel<', '256, 256, 3, 1, 4, 4, true'),
+    'conv3x3_c256': ('conv_fused_kernel<', '256, 256, 3, 1, 4, 4, false'),
+    'conv3x3_s2_64_128': ('conv_fused_kernel<', '64, 128, 3, 2'),
     'stem': ('stem_conv_kernel', ''),
+    # round 3
+    'xconv_256_1024_gelu': ('xconv_kernel<unsigned short, 256, true, false', ''),
+    'xconv_1024_256_skip': ('xconv_kernel<unsigned short, 256, false, true', ''),
+    'ln_affine': ('ln_affine_kernel<unsigned short', ''),
 }
 
 
