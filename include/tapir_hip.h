@@ -324,6 +324,9 @@ int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
  * heads, no volume in HBM -- for grids of up to 32 x 32 cells; larger grids take the path below),
  * 1 = einsum GEMM into a workspace followed by the heads kernel (round-1 path; tools A/B it). */
 int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
+/* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
+ * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
+int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

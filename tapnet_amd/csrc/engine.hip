@@ -70,6 +70,7 @@ struct tapir_ctx {
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
+  int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
@@ -531,6 +532,12 @@ int pick_time_chunk(int N, int T) {
 // mixer GEMM: split-K for few rows (online model), the tiled persistent kernel otherwise
 template <typename TA, typename TO, int EPI>
 int mixer_gemm(tapir_ctx* c, const GemmArgs& g, hipStream_t s) {
+  // few rows (the online model): the whole-K small-tile kernel, one launch (gemm.hpp); small_gemm 0 pins the
+  // round-2 split-K pair for A/B measurements (tapir_debug_set_gemm_mode)
+  if (c->small_gemm && gemm_small_supported<TA>(g.M, g.N, g.K)) {
+    launch_gemm_small<TA, TO, EPI>(g, s);
+    return TAPIR_OK;
+  }
   const int splits = gemm_splits<TA>(g.M, g.K);
   if (splits > 1 && g.N % 4 == 0) {
     TRY(ensure(c, c->splitk, (size_t)splits * g.M * g.N * sizeof(float)));
@@ -619,13 +626,13 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s, gemm_splits<TA>(g1.M, g1.K) <= 1);
+    { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s, (c->small_gemm && gemm_small_supported<TA>(g1.M, g1.N, g1.K)) || gemm_splits<TA>(g1.M, g1.K) <= 1);
       TRY((mixer_gemm<TA, TA, EPI_BIAS_GELU>(c, g1, s))); }
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
-    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s, gemm_splits<TA>(g2.M, g2.K) <= 1);
+    { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s, (c->small_gemm && gemm_small_supported<TA>(g2.M, g2.N, g2.K)) || gemm_splits<TA>(g2.M, g2.K) <= 1);
       TRY((mixer_gemm<TA, float, EPI_BIAS_RESID>(c, g2, s))); }
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
@@ -1461,6 +1468,12 @@ int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
 #endif
   if (!c || mode < 0 || mode > max_mode) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  c->small_gemm = mode;
   return TAPIR_OK;
 }
 

@@ -807,6 +807,114 @@ inline void launch_gemm_splitk(const GemmArgs& g, int splits, float* part, hipSt
                      dim3(256), 0, stream, r);
 }
 
+// ---- few-row GEMM in ONE launch (the online model: M = tracked points x 1 frame = 256 rows).  The
+// split-K pair above is two dependent launches (tiled kernel with LDS-DMA prologue + element-wise reduce:
+// 8.8 + 5 us for 0.5 GFLOP) 26 times per refinement iteration, 4 iterations per frame.  At this size
+// nothing is bandwidth- or MFMA-bound; what counts is the number of dependent launches and round trips.
+// gemm_small_kernel: a workgroup of 4 waves owns a tile of FM*16 rows x FN*16 columns over the WHOLE K; the
+// waves split K (wave w takes k-steps w, w + 4, ...), each keeps the whole tile's accumulators, operands go
+// global -> registers straight in MFMA fragment layout (16 bytes per lane, no LDS staging: a fragment is
+// read by exactly one wave), DEPTH k-steps of loads in flight; the four partial tiles meet in LDS and every
+// wave finishes a quarter of the fragments (bias, GELU / residual, store).  Tiles are small (32 x 64 /
+// 32 x 32) so that 100-256 workgroups are in flight for M = 256.  Measured on MI355X (rocprofv3, online
+// step): 8.4 us (K = 512) / 11.1 us (K = 2048) per launch against 8.8 + 5 us for the pair; 3.20 -> 2.89 ms
+// per frame.  (An 8-wave form with ALL operand loads of a wave issued up front -- one round trip instead
+// of four -- measured SLOWER: 14.5 / 10.4 us; every kernel of this launch-bound step, however small, takes
+// >= 4-5 us at the clocks the mostly idle chip runs at.)
+template <typename TA, typename TO, int EPI, int FM, int FN>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  constexpr int EPC = 16 / (int)sizeof(TA);          // elements per 16-byte chunk
+  constexpr int KS = 4 * EPC;                        // k per MFMA step (one chunk per lane group)
+  constexpr int NF = FM * FN;
+  constexpr int DEPTH = (FM + FN) <= 4 ? 4 : 2;      // k-steps of operand loads in flight per wave
+  __shared__ f32x4 s_part[4][NF][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  const int tiles_n = (g.N + FN * 16 - 1) / (FN * 16);
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * FM * 16, n0 = tn * FN * 16;
+  const TA* __restrict__ A = reinterpret_cast<const TA*>(g.A);
+  const TA* __restrict__ W = reinterpret_cast<const TA*>(g.W);
+  // this lane's operand rows (clamped: rows past M / N are computed and never stored)
+  const TA* pa[FM];
+  const TA* pw[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) pa[i] = A + (long)min(m0 + 16 * i + c, g.M - 1) * g.lda + EPC * gq;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) pw[j] = W + (long)min(n0 + 16 * j + c, g.N - 1) * g.ldw + EPC * gq;
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ksteps = g.K / KS;                       // (K is a multiple of 4 KS)
+  const int mine = (ksteps - wave + 3) / 4;          // k-steps of this wave: wave, wave + 4, ...
+  uint4 fa[DEPTH][FM], fw[DEPTH][FN];
+  auto load = [&](int slot, int it) {
+    const int k = (wave + 4 * min(it, mine - 1)) * KS;   // past the end: any valid address (not used)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa[slot][i] = *reinterpret_cast<const uint4*>(pa[i] + k);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fw[slot][j] = *reinterpret_cast<const uint4*>(pw[j] + k);
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(d, d);
+  for (int it0 = 0; it0 < mine; it0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (it0 + d < mine) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int i = 0; i < FM; ++i) MfmaStep<TA>::run(fw[d][j], fa[d][i], acc[j][i]);
+      }
+      load(d, it0 + d + DEPTH);
+    }
+  }
+  // ---- the four partial tiles meet in LDS; wave w finishes the fragments f = w, w + 4, ...
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) s_part[wave][j * FM + i][lane] = acc[j][i];
+  __syncthreads();
+#pragma unroll
+  for (int f0 = 0; f0 < NF; f0 += 4) {
+    const int f = f0 + wave;
+    if (f >= NF) break;
+    const int j = f / FM, i = f - j * FM;
+    f32x4 v = s_part[0][f][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += s_part[w][f][lane];
+    // lane (c, gq) holds output columns n .. n + 3 of row m (MFMA C/D layout: W rows on the A port)
+    const int m = m0 + 16 * i + c, n = n0 + 16 * j + 4 * gq;
+    if (m < g.M && n < g.N) {
+      if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+      if (EPI == EPI_BIAS_GELU) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
+      if (EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+      Store4<TO>::run(reinterpret_cast<TO*>(g.C) + (long)m * g.ldc + n, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// shapes gemm_small_kernel covers (K a multiple of four MFMA k-steps; N, ldc multiples of 4 like every GEMM here)
+template <typename TA>
+inline bool gemm_small_supported(int M, int N, int K) {
+  const int ks = 4 * (16 / (int)sizeof(TA));
+  return M >= 1 && M <= 512 && K >= 4 * ks && K % (4 * ks) == 0 && N % 4 == 0;
+}
+
+template <typename TA, typename TO, int EPI>
+inline void launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
+  const int tm = (g.M + 31) / 32;
+  if (g.N >= 1024) {   // 32 x 64 tiles: 256 workgroups for [256, 2048]
+    TAPIR_LAUNCH((gemm_small_kernel<TA, TO, EPI, 2, 4>), dim3((unsigned)(tm * ((g.N + 63) / 64))), dim3(256), stream, g);
+  } else {             // 32 x 32 tiles: 128 workgroups for [256, 512]
+    TAPIR_LAUNCH((gemm_small_kernel<TA, TO, EPI, 2, 2>), dim3((unsigned)(tm * ((g.N + 31) / 32))), dim3(256), stream, g);
+  }
+}
+
 #ifdef TAPIR_EXPERIMENTS
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, int max_grid) {

@@ -1,0 +1,37 @@
+"""The few-row GEMM of the online model (csrc/gemm.hpp gemm_small_kernel: whole K per workgroup, the four
+waves split K and meet in LDS, operands global -> registers in fragment layout) on the host emulator: the
+causal T = 1 mixer (M = points x 1 frame rows) against the oracle, and against the split-K + reduce pair it
+replaces (tapir_debug_set_gemm_mode), both element types, ragged row counts."""
+import numpy as np
+import pytest
+
+from oracle import tapir_oracle as O
+from tapnet_amd import _ffi, synthetic
+from tests.emu_engine import EmuEngine
+
+
+@pytest.mark.parametrize('dtype,N,pyr', [(_ffi.TAPIR_F32, 37, 1), (_ffi.TAPIR_F32, 256, 0), (_ffi.TAPIR_BF16, 70, 1),
+                                         (_ffi.TAPIR_BF16, 1, 0)])
+def test_online_mixer_small_gemm(dtype, N, pyr):
+  w = synthetic.make_weights(5, pyr, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=pyr, num_mixer_blocks=2, use_causal_conv=True, initial_resolution=(64, 64), dtype=dtype)
+  rng = np.random.default_rng(N)
+  x = rng.standard_normal((N, 1, 388 + 49 * (2 + pyr))).astype(np.float32)
+  c1 = rng.standard_normal((2, N, 2, 512)).astype(np.float32)
+  c2 = rng.standard_normal((2, N, 2, 2048)).astype(np.float32)
+  outs = {}
+  for mode in (1, 0):
+    assert e.lib.tapir_debug_set_gemm_mode(e.ctx, mode) == 0
+    outs[mode] = e.pips_mixer(x, c1, c2, get_ctx=True)
+  ctx = {}
+  for i in range(2):
+    ctx[f'block_{i}_causal_1'] = c1[i]
+    ctx[f'block_{i}_causal_2'] = c2[i]
+  bf = dtype == _ffi.TAPIR_BF16
+  ref, new_ctx = O.pips_mlp_mixer(w, x, num_blocks=2, use_causal_conv=True, causal_context=ctx, get_causal_context=True,
+                                  rnd=O.bf16_round if bf else None)
+  tol = 4e-3 if bf else 2e-4
+  np.testing.assert_allclose(outs[1][0], ref, atol=tol)                # one-launch kernel vs the oracle
+  np.testing.assert_allclose(outs[1][0], outs[0][0], atol=tol)         # vs the split-K pair
+  np.testing.assert_allclose(outs[1][1][1], new_ctx['block_1_causal_1'], atol=tol)
+  e.close()

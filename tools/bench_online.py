@@ -24,16 +24,20 @@ def main():
   ap.add_argument('--frames', type=int, default=60)
   ap.add_argument('--size', type=int, default=256)
   ap.add_argument('--dtype', default='bf16')
+  ap.add_argument('--eager-only', action='store_true', help='one configuration, eager launches (kernel traces)')
+  ap.add_argument('--gemm-mode', type=int, default=1, help='0 = split-K + reduce pair (round 2), 1 = one-launch few-row GEMM')
   args = ap.parse_args()
   dtype = 'bfloat16' if args.dtype == 'bf16' else 'float32'
   w = synthetic.make_weights(0, pyramid_level=1, extra_convs=True)   # the causal checkpoint's kwargs
   m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, use_causal_conv=True, weights=w,
                         dtype=dtype, device='cuda:0')
+  assert m._lib.tapir_debug_set_gemm_mode(m._ctx, args.gemm_mode) == 0
   S, Q = args.size, args.queries
   video = torch.as_tensor(synthetic.make_video(1, 8, S, S)).cuda()
   qp = torch.as_tensor(synthetic.make_queries(2, Q, 1, S, S)).cuda()
   rows = []
-  for conv_mode, use_graph in (('auto', False), ('auto', True), ('miopen', True), ('hip', True)):
+  configs = (('auto', False),) if args.eager_only else (('auto', False), ('auto', True), ('miopen', True), ('hip', True))
+  for conv_mode, use_graph in configs:
     if m._backbone.dtype != torch.bfloat16 and conv_mode == 'hip':
       continue
     m._backbone.conv_mode = conv_mode
@@ -48,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.frames * 1e3
     assert torch.isfinite(out['tracks']).all()
-    rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', backbone_convs=conv_mode, ms_per_frame=round(ms, 3),
+    rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', backbone_convs=conv_mode, gemm_mode=args.gemm_mode, ms_per_frame=round(ms, 3),
                      frames_per_s=round(1e3 / ms, 1), points_frames_per_s=round(Q * 1e3 / ms, 1)))
     print(json.dumps(dict(workload=f'online TAPIR {S}x{S}, Q={Q}, 4 iters/frame, {dtype}', **rows[-1])), flush=True)
 
