@@ -118,7 +118,9 @@ def gather_feature_grids(model, video_local, num_frames: int, group=None,
   if t_local > 0:
     # (the convolution implementation is chosen from the WHOLE clip's frame count, so a small shard runs
     # the kernels the unsharded call runs: bit-identical sharding, tapnet_amd/backbone.py)
-    fg = model.get_feature_grids(video_local, _global_frames=num_frames)
+    # (an engine-internal keyword: any other object with the reference's get_feature_grids works unchanged)
+    kw = {'_global_frames': num_frames} if hasattr(model, '_backbone') else {}
+    fg = model.get_feature_grids(video_local, **kw)
     res = tuple(fg.resolutions)
     levels = list(zip(fg.lowres, fg.hires))
   else:   # empty frame shard: contribute zero-length tensors of the right trailing shape

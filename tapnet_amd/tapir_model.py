@@ -535,10 +535,15 @@ class TAPIR:
                                       self._dev(query_points), query_chunk_size)
     p = self.num_pips_iter
     conv = (lambda t: t.cpu().numpy()) if numpy_out else (lambda t: t)
+
+    def level_mean(lst):   # mean over the refinement levels (:1142-1152); one level: that iteration as it is
+      sel = lst[p::p]
+      return sel[0] if len(sel) == 1 else torch.mean(torch.stack(sel), dim=0)
+
     out = dict(
-        occlusion=conv(torch.mean(torch.stack(traj['occlusion'][p::p]), dim=0)),
-        tracks=conv(torch.mean(torch.stack(traj['tracks'][p::p]), dim=0)),
-        expected_dist=conv(torch.mean(torch.stack(traj['expected_dist'][p::p]), dim=0)),
+        occlusion=conv(level_mean(traj['occlusion'])),
+        tracks=conv(level_mean(traj['tracks'])),
+        expected_dist=conv(level_mean(traj['expected_dist'])),
         unrefined_occlusion=[conv(t) for t in traj['occlusion'][:-1]],
         unrefined_tracks=[conv(t) for t in traj['tracks'][:-1]],
         unrefined_expected_dist=[conv(t) for t in traj['expected_dist'][:-1]],
