@@ -342,3 +342,50 @@ def test_extra_convs_hip_vs_torch_path():
   cos_t, cos_h = (ref[0] * t16[0]).sum(-1).min(), (ref[0] * h16[0]).sum(-1).min()
   print(f'min cosine to the f32 grids: torch path {float(cos_t):.5f}, HIP path {float(cos_h):.5f}')
   assert float(cos_h) > 0.998 and float(cos_h) > float(cos_t) - 5e-4
+
+
+def test_reloading_hot_path_weights_keeps_the_backbone():
+  """A second load_weights / load_state_dict with hot-path weights only (no resnet_torch.* keys) re-runs
+  tapir_finalize_weights; the backbone's packed weight streams -- and the hipGraphs that captured their addresses --
+  belong to the Backbone object and must survive it (round-2 ADVICE: they were freed with the hot-path weights and
+  the next get_feature_grids read freed memory).  A load WITH backbone weights rebuilds the backbone."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(21, 1, True)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='bfloat16')
+  frames = torch.as_tensor(synthetic.make_video(3, 8, 128, 128), device='cuda:0')
+  for _ in range(3):                                   # the third call captures the graph
+    ref = [t.clone() for t in m.get_feature_grids(frames).lowres]
+  bb = m._backbone
+  assert any('graph' in e for e in bb._graphs.values())
+  hot = {k: v for k, v in synthetic.make_weights(22, 1, True).items()
+         if not (k.startswith('resnet_torch.') or k.startswith('extra_convs.'))}
+  m.load_weights(hot)                                  # other mixer / head weights, same backbone
+  assert m._backbone is bb
+  junk = [torch.full((1 << 22,), 7.0, device='cuda:0') for _ in range(8)]   # reuse whatever was freed
+  torch.cuda.synchronize()
+  again = m.get_feature_grids(frames).lowres           # graph replay on the old packs
+  assert all(torch.equal(a, b) for a, b in zip(again, ref))
+  del junk
+  m.load_state_dict(synthetic.make_weights(23, 1, True))   # new backbone weights: rebuilt, old packs released
+  assert m._backbone is not bb and not bb._wstream and not bb._xstream
+  other = m.get_feature_grids(frames).lowres
+  assert not torch.equal(other[0], ref[0]) and torch.isfinite(other[0]).all()
+
+
+def test_chunked_feature_extraction_is_eager_and_identical():
+  """feature_extractor_chunk_size (tapir_model.py:689-703) bounds the backbone's scratch: chunked calls are launched
+  eagerly (a captured graph would keep full-clip static buffers) and give the bits of the unchunked call, whatever
+  the chunk length (every kernel is independent of the number of frames per launch; the convolution implementation is
+  chosen from the whole clip, so a short last chunk runs the same kernels)."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(21, 1, False)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=w, device='cuda:0', dtype='bfloat16')
+  bb = m._backbone
+  frames = torch.as_tensor(synthetic.make_video(4, 18, 128, 128), device='cuda:0').reshape(-1, 128, 128, 3).float()
+  ref = [t.clone() for t in bb.features(frames)]
+  keys = set(bb._graphs)
+  for chunk in (16, 5, 7):                             # 16 + 2 frames: the last chunk is below hip_min_frames
+    for _ in range(3):
+      out = bb.features(frames, chunk)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref)), chunk
+  assert set(bb._graphs) == keys                       # chunked calls never enter the graph cache

@@ -140,3 +140,28 @@ def test_bench_self_launch_command(monkeypatch):
   assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
   assert cmd[-4:] == ['--gpus', '4', '--steps', '3'] and cmd[-5].endswith('bench.py')
   assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_jax_style_antialiased_resize_matches_the_restatement():
+  """TAPIR(jax_antialias_resize=True): the JAX model's jax.image.resize(method='bilinear') anti-aliases when
+  DOWN-sampling (tapir_model.py:670), the torch twin does not (tapnet/torch/utils.py:39).  The product's
+  resize_bilinear(antialias=True) against the numpy restatement of jax/_src/image/scale.py's published algorithm
+  (oracle/jax_resize.py; JAX itself cannot run offline): 512 -> 256 (BASELINE configs[4]'s first level), a non-integer
+  factor, and up-sampling, where both agree with plain bilinear interpolation."""
+  import torch
+  from oracle import jax_resize
+  from tapnet_amd.backbone import resize_bilinear
+  rng = np.random.default_rng(0)
+  v = rng.uniform(-1, 1, (1, 2, 64, 48, 3)).astype(np.float32)
+  for res in ((32, 24), (40, 40), (24, 20)):                     # down-sampling: the antialiased kernel
+    got = resize_bilinear(torch.as_tensor(v), res, antialias=True).numpy()
+    np.testing.assert_allclose(got, jax_resize.resize_bilinear(v, res), atol=2e-5)   # (measured 6e-8 .. 4e-6: float32 weights)
+    plain = resize_bilinear(torch.as_tensor(v), res, antialias=False).numpy()
+    assert np.abs(plain - got).max() > 0.05                      # ... which the torch twin's resize is not
+  up = (96, 80)                                                  # up-sampling: identical to plain bilinear
+  got = resize_bilinear(torch.as_tensor(v), up, antialias=True).numpy()
+  np.testing.assert_allclose(got, jax_resize.resize_bilinear(v, up), atol=2e-5)
+  np.testing.assert_allclose(got, resize_bilinear(torch.as_tensor(v), up, antialias=False).numpy(), atol=1e-5)
+  # the 2x case has the closed form [1, 3, 3, 1] / 8 away from the borders
+  w = jax_resize.compute_weight_mat(8, 4)
+  np.testing.assert_allclose(w[1:5, 1], [0.125, 0.375, 0.375, 0.125], atol=1e-12)
