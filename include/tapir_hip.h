@@ -272,7 +272,8 @@ int tapir_stem_conv(tapir_ctx* ctx, const float* x, const void* wstream, void* y
  * tapir_xconv_plan : output rows per workgroup tile, tiles per image and input channels per LDS chunk for
  *   an [H, W, cin] map (W <= 64; cin, cout multiples of 256), TAPIR_ERR_UNSUPPORTED otherwise.
  * tapir_xconv_pack : w = the reference's [cout, cin, 3, 3] f32 kernel (torch OIHW, host memory) -> packed
- *   fragment streams for chunks of `cch` input channels (the value tapir_xconv_plan returned); owned like
+ *   fragment streams for chunks of `cch` input channels (the value tapir_xconv_plan returned for the map it will
+ *   be used on: tapir_xconv returns TAPIR_ERR_INVALID for a pack built with another chunk width); owned like
  *   a tapir_conv_pack (tapir_conv_free).
  * tapir_xconv      : y [N, H, W, cout] = conv3x3_SAME(x [N, H, W, cin]) + bias, then gelu (tanh form,
  *   jax.nn.gelu :184) if `gelu`, or + skip [N, H, W, cout] if skip != NULL (:185), rounded to the element

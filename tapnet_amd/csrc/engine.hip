@@ -50,6 +50,7 @@ struct tapir_ctx {
   std::map<std::string, HostTensor> host_w;
   bool finalized = false;
   std::vector<void*> owned;         // device weight allocations (hot path: rebuilt by tapir_finalize_weights)
+  std::map<const void*, int> xconv_cch;   // tapir_xconv_pack: input channels per chunk each pack was built for
   std::vector<void*> conv_owned;    // backbone weight packs (tapir_conv_pack / tapir_stem_pack): they belong to the
                                     // caller's Backbone object and outlive tapir_finalize_weights (tapir_conv_free)
 
@@ -1254,6 +1255,7 @@ int tapir_conv_free(tapir_ctx* c, void* wstream) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipFree(wstream));
   c->conv_owned.erase(it);
+  c->xconv_cch.erase(wstream);
   return TAPIR_OK;
 }
 
@@ -1342,6 +1344,7 @@ int tapir_xconv_pack(tapir_ctx* c, const float* w, int cout, int cin, int cch, v
   void* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, host.size()));
   c->conv_owned.push_back(d);
+  c->xconv_cch[d] = cch;
   HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
   *wstream = d;
   return TAPIR_OK;
@@ -1356,6 +1359,15 @@ int tapir_xconv(tapir_ctx* c, const void* x, const void* wstream, const float* b
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0, cch = 0;
   if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  {
+    // the stream is packed for ONE chunk width ([chunk][tap][k-step][row tile]): a pack made for another map
+    // width would be multiplied in the wrong order
+    auto it = c->xconv_cch.find(wstream);
+    if (it == c->xconv_cch.end()) return fail(c, TAPIR_ERR_INVALID, "xconv: wstream is not a tapir_xconv_pack of this context");
+    if (it->second != cch)
+      return fail(c, TAPIR_ERR_INVALID, "xconv: the pack was built for chunks of " + std::to_string(it->second) +
+                                           " input channels, this map needs " + std::to_string(cch) + " (tapir_xconv_plan)");
+  }
   XConvArgs xa{};
   xa.x = x; xa.wstream = (const uint4*)wstream; xa.frags_per_cg = xconv_frags_per_cg(cin, bf ? 32 : 16);
   xa.bias = bias; xa.skip = skip; xa.y = y;

@@ -110,3 +110,18 @@ def test_xconv_rejects_unsupported_shapes():
   assert lib.tapir_xconv_plan(ctx, 32, 32, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == 0
   assert (r.value, t.value, c.value) == (2, 16, 256)
   lib.tapir_destroy(ctx)
+
+
+def test_xconv_rejects_a_pack_built_for_another_chunk_width():
+  """The weight stream is ordered [chunk][tap][k-step][row tile] for ONE chunk width: using a pack made for a
+  32-wide map (chunks of 256 channels) on a 64-wide map (chunks of 128) must be an error, not a wrong result."""
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  w = np.zeros((256, 256, 3, 3), np.float32)
+  ws = ctypes.c_void_p()
+  assert lib.tapir_xconv_pack(ctx, _p(w), 256, 256, 256, ctypes.byref(ws)) == 0
+  x = np.zeros((1, 2, 64, 256), np.uint16); y = np.zeros((1, 2, 64, 256), np.uint16); b = np.zeros(256, np.float32)
+  rc = lib.tapir_xconv(ctx, _p(x), ws, _p(b), None, _p(y), 1, 2, 64, 256, 256, 0, None)
+  assert rc == _ffi.TAPIR_ERR_INVALID and b'chunks of 256' in lib.tapir_last_error(ctx)
+  assert lib.tapir_xconv(ctx, _p(x), _p(w), _p(b), None, _p(y), 1, 2, 64, 256, 256, 0, None) == _ffi.TAPIR_ERR_INVALID
+  lib.tapir_destroy(ctx)
