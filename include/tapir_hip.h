@@ -328,6 +328,9 @@ int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
 /* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
  * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
+/* refine_pips's state update (tapir_model.py:613-623): 1 (default) = applied by the output stage of the track-resident
+ * mixer kernels, 0 = always the separate update kernel on the mixer's [R,388] output (A/B, tests; bit-identical). */
+int tapir_debug_set_update_mode(tapir_ctx* ctx, int mode);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

@@ -3,6 +3,7 @@
 // stream; there is no host synchronisation and no CPU compute path.
 #include "../../include/tapir_hip.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -71,6 +72,7 @@ struct tapir_ctx {
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
+  int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
   // workspaces
@@ -550,9 +552,12 @@ int mixer_gemm(tapir_ctx* c, const GemmArgs& g, hipStream_t s) {
 }
 
 // PIPSMLPMixer on R = N*T token rows already staged in c->mlp_in -> c->res [R,388]
+// upd (nullable): the state update that follows the mixer in refine_pips; the track-resident kernels apply it in
+// their output stage and set *upd_done (the caller then skips update_kernel)
 template <typename TA>
 int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
-              float* ctx1_out, float* ctx2_out, hipStream_t s) {
+              float* ctx1_out, float* ctx2_out, hipStream_t s, const UpdateArgs* upd = nullptr,
+              bool* upd_done = nullptr) {
   const long R = (long)N * T;
   const int nb = c->cfg.num_mixer_blocks;
   // track-resident fused kernel (mixer_fused.hpp) for whole non-causal clips; separate launches for
@@ -593,6 +598,9 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
+      if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim) {
+        fa.fuse_update = 1; fa.upd = *upd; *upd_done = true;
+      }
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
       if (wide) launch_mixer_fused_wide(fa, s);
       else launch_mixer_fused<TA>(fa, s);
@@ -766,9 +774,8 @@ int refine_iter(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, float* 
   const long R = (long)B * Q * T;
   TRY(launch_patch<TA>(c, lg, B, Q, T, pos, occ, expd, first_of_level ? nullptr : feats, orig_h,
                        orig_w, s));
-  TRY(run_mixer<TA>(c, B * Q, T, c1i, c2i, c1o, c2o, s));
   UpdateArgs u{};
-  u.res = (const float*)c->res.p; u.pos = pos; u.occ = occ; u.expd = expd; u.feats = feats;
+  u.pos = pos; u.occ = occ; u.expd = expd; u.feats = feats;
   u.q_hires = lg.query[0]; u.q_lowres = lg.query[1];
   u.out_tracks = out_tracks; u.out_occ = out_occ; u.out_expd = out_expd;
   u.occ0 = occ0; u.expd0 = expd0; u.R = R; u.T = T;
@@ -776,7 +783,12 @@ int refine_iter(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, float* 
   u.vx = vx; u.vy = vy;
   u.first_of_level = first_of_level ? 1 : 0;
   u.last_of_level = last_of_level ? 1 : 0;
-  hipLaunchKernelGGL(update_kernel, dim3((unsigned)R), dim3(128), 0, s, u);
+  bool upd_done = false;
+  TRY(run_mixer<TA>(c, B * Q, T, c1i, c2i, c1o, c2o, s, &u, &upd_done));
+  if (!upd_done) {   // separate-launch mixer: res [R,388] in the workspace
+    u.res = (const float*)c->res.p;
+    hipLaunchKernelGGL(update_kernel, dim3((unsigned)R), dim3(128), 0, s, u);
+  }
   return TAPIR_OK;
 }
 
@@ -910,6 +922,9 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   // the LDS image of the fused mixer kernel (128 bf16 / 64 f32 elements)
   const int kq = cfg->dtype == TAPIR_BF16 ? 128 : 64;
   c->k0_pad = (c->in_dim + kq - 1) / kq * kq;
+  // (same-box A/B of builds from outside the process: tools/ab_env.sh)
+  if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
   *out = c;
   return TAPIR_OK;
 }
@@ -1486,6 +1501,12 @@ int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
 int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
   c->small_gemm = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_update_mode(tapir_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  c->fuse_update = mode;
   return TAPIR_OK;
 }
 

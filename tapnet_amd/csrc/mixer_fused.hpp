@@ -83,7 +83,40 @@ struct FusedArgs {
   int N, T;
   long long* dbg_times;          // TRACE build: [N][8 waves][8] shader-cycle totals per phase
   int pair_sim;                  // TAPIR_EXPERIMENTS builds: timing-only stand-in of the wide kernel (mixer_fused_wide.hpp)
+  // refine_pips's state update (tapir_model.py:613-623, 1026-1039) applied by the output stage itself instead of a
+  // separate launch that re-reads res [R,388]: pos += d_xy * (orig / resized), occ += d, expd += d, feats += d,
+  // this iteration's output slices.  fuse_update = 0: plain res output (tapir_pips_mixer).
+  int fuse_update;
+  UpdateArgs upd;
 };
+
+// Output of the mixer for token row r, output channels o0 .. o0 + 3 (o0 a multiple of 4, < 388): either stored to
+// res, or applied to the running estimate exactly as update_kernel does (same operations in the same order: the two
+// forms are bit-identical).  Channels 0..3 = [dx, dy, d_occ, d_expd] sit in ONE lane; channels 4.. are feats[o0 - 4 ..].
+__device__ __forceinline__ void fused_emit(const FusedArgs& a, long r, long bq, int o0, const f32x4& v) {
+  if (!a.fuse_update) {
+    *reinterpret_cast<f32x4*>(a.res + r * kMixOut + o0) = v;
+    return;
+  }
+  const UpdateArgs& u = a.upd;
+  if (o0 == 0) {
+    const float px = u.pos[r * 2 + 0] + v[0] * u.sx;
+    const float py = u.pos[r * 2 + 1] + v[1] * u.sy;
+    const float oc = u.occ[r] + v[2];
+    const float ex = u.expd[r] + v[3];
+    u.pos[r * 2 + 0] = px; u.pos[r * 2 + 1] = py;
+    u.out_tracks[r * 2 + 0] = px * u.vx; u.out_tracks[r * 2 + 1] = py * u.vy;
+    u.out_occ[r] = oc; u.out_expd[r] = ex;
+    u.occ[r] = u.last_of_level ? u.occ0[r] : oc;
+    u.expd[r] = u.last_of_level ? u.expd0[r] : ex;
+  } else {
+    const int f = o0 - 4;                          // feats channels f .. f + 3 (f and the 128 boundary are multiples of 4)
+    const float* src = !u.first_of_level ? u.feats + r * kFeatDim + f
+                       : (f < kHiresDim ? u.q_hires + bq * kHiresDim + f : u.q_lowres + bq * kLowresDim + (f - kHiresDim));
+    const f32x4 prev = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(u.feats + r * kFeatDim + f) = v + prev;
+  }
+}
 
 // Number of A fragments in one wave's stream (host packing and kernel must agree).
 template <typename TA>
@@ -575,8 +608,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int t = NT * c + i;
-        if (o0 < kMixOut && t < T)
-          *reinterpret_cast<f32x4*>(a.res + ((long)n * T + t) * kMixOut + o0) = oa[q][i];
+        if (o0 < kMixOut && t < T) fused_emit(a, (long)n * T + t, n, o0, oa[q][i]);
       }
     }
   }

@@ -302,8 +302,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           const int t = NTT * c + (i % NTT), trk = trk0 + i / NTT;
-          if (o0 < kMixOut && t < T && trk < a.N)
-            *reinterpret_cast<f32x4*>(a.res + ((long)trk * T + t) * kMixOut + o0) = oa[q][i];
+          if (o0 < kMixOut && t < T && trk < a.N) fused_emit(a, (long)trk * T + t, trk, o0, oa[q][i]);
         }
       }
     }

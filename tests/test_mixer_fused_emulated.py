@@ -94,3 +94,34 @@ def test_wide_fused_mixer_needs_bf16():
   p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
   assert e.lib.tapir_pips_mixer(e.ctx, p(x), 1, 48, p(out), None, None, None, None, None) == _ffi.TAPIR_ERR_UNSUPPORTED
   e.close()
+
+
+@pytest.mark.parametrize('mode,dtype,T,Q', [(2, _ffi.TAPIR_F32, 20, 3), (2, _ffi.TAPIR_BF16, 33, 2), (3, _ffi.TAPIR_BF16, 40, 3)])
+def test_fused_state_update_is_bit_identical(mode, dtype, T, Q):
+  """refine_pips's state update (tapir_model.py:613-623, 1026-1039: pos / occ / expd / feats, the per-iteration
+  output slices, the reset after a level) applied by the output stage of the track-resident mixer kernels
+  (fused_emit) against the separate update_kernel on the mixer's [R,388] output: the same operations in the same
+  order, so every output of estimate_trajectories -- two refinement levels, first / later iterations -- is
+  bit-identical; and (f32) equal to the oracle."""
+  w = synthetic.make_weights(4, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_pips_iter=2, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=dtype)
+  rng = np.random.default_rng(T)
+  S = 64
+  lows = [O.l2_normalize(rng.standard_normal((1, T, 8, 8, 256)).astype(np.float32)) for _ in range(2)]
+  his = [O.l2_normalize(rng.standard_normal((1, T, 16, 16, 128)).astype(np.float32)) for _ in range(2)]
+  lows, his, res = [lows[0], lows[0], lows[1]], [his[0], his[0], his[1]], [(S, S)] * 3
+  qp = synthetic.make_queries(5, Q, T, S, S)
+  ql, qh = O.get_query_features(lows, his, res, qp, (1, T, S, S, 3))
+  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, mode) == 0
+  outs = {}
+  for upd in (0, 1):
+    assert e.lib.tapir_debug_set_update_mode(e.ctx, upd) == 0
+    outs[upd] = e.estimate_trajectories((S, S), lows, his, res, ql, qh, qp)
+  for k in ('tracks', 'occlusion', 'expected_dist'):
+    np.testing.assert_array_equal(outs[0][k], outs[1][k])
+  if dtype == _ffi.TAPIR_F32:
+    ref = O.estimate_trajectories(w, (S, S), lows, his, res, ql, qh, qp, num_pips_iter=2, pyramid_level=1,
+                                  initial_resolution=(S, S), num_blocks=2)
+    for i in range(5):
+      np.testing.assert_allclose(outs[1]['occlusion'][i], ref['occlusion'][i], atol=2e-4)
+  e.close()
