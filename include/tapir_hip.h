@@ -244,7 +244,9 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  *   context's element type.
  *   part_in [N, slabs_in, cin, 2] are (mean, M2) summaries of x per slab of per_s_in pixels
  *   (0: ceil(HW / slabs_in)) -- from tapir_inorm_stats or from a previous call's part_out;
- *   ss: N * cin * 2 floats of scratch owned by the caller (the merged scale / shift); part_out, if not
+ *   ss: N * cin * 2 floats of scratch owned by the caller (the merged scale / shift; part_in == NULL: ss already
+ *   holds the pairs of this input and norm from a previous call -- conv_0 and proj_conv of a block -- and is
+ *   used as it is); part_out, if not
  *   NULL, [N, tiles, cout, 2] receives the summaries of y per tile (rows * W_out pixels each). */
 int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles);
 int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);

@@ -326,9 +326,10 @@ class Backbone:
     _, cin, cout, ks = self._wstream[conv_name]
     return self._plan(h, w, cin, cout, ks, stride) is not None
 
-  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True):
+  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True, reuse_ss=False):
     """conv(relu(instance_norm(x))) (+ shortcut) and the summaries of the result, one launch
-    (+ the tiny merge of the input summaries)."""
+    (+ the tiny merge of the input summaries; reuse_ss: the previous call on this stream merged the same
+    summaries with the same norm -- conv_0 after proj_conv -- and its (a, b) pairs are still in the scratch)."""
     lib, ctx = self.engine
     n, h, w, _ = x.shape
     ws, cin, cout, ks = self._wstream[conv_name]
@@ -339,7 +340,7 @@ class Backbone:
     ss = self._buf(('ss', n, cin), (n, cin, 2), torch.float32)
     assert y.data_ptr() != x.data_ptr() and (shortcut is None or y.data_ptr() != shortcut.data_ptr())
     self._check(lib.tapir_conv_fused(
-        ctx, x.data_ptr(), st.part.data_ptr(), st.slabs, st.per_s, self.w[norm_name + '.weight'].data_ptr(),
+        ctx, x.data_ptr(), None if reuse_ss else st.part.data_ptr(), st.slabs, st.per_s, self.w[norm_name + '.weight'].data_ptr(),
         self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), ws,
         shortcut.data_ptr() if shortcut is not None else None, y.data_ptr(),
         part.data_ptr() if stats else None, n, h, w, cin, cout, ks, stride, self._stream()), 'tapir_conv_fused')
@@ -362,7 +363,8 @@ class Backbone:
       else:
         shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
     if f0:
-      y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c', stride)
+      y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c', stride,
+                                 reuse_ss=bool(use_projection and fp))   # (proj_conv just merged bn_0's pairs into `ss`)
     else:
       y0 = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
       st0 = self._hip_stats(y0)

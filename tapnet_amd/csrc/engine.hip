@@ -1280,15 +1280,19 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
                      int cout, int ks, int stride, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!x || !part_in || !gamma || !beta || !ss || !wstream || !y || N < 1 || slabs_in < 1 || per_s_in < 0)
+  // part_in NULL: ss already holds the merged (a, b) pairs of this input and norm (a previous call: conv_0 and
+  // proj_conv of a block read the same normalised tensor) -- no second inorm_finalize launch
+  if (!x || !ss || !wstream || !y || N < 1 || (part_in && (!gamma || !beta || slabs_in < 1 || per_s_in < 0)))
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (shortcut && !(ks == 3 && stride == 1)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shortcut on a 3x3 stride-1 convolution only");
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0, waves = 0;
   if (!conv3_plan(H, W, cin, cout, ks, stride, bf ? 2 : 4, &rows, &tiles, &waves))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
-  NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, bf ? 8 : 4};
-  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
+  if (part_in != nullptr) {
+    NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, bf ? 8 : 4};
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
+  }
   Conv3Args ca{};
   ca.x = x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(cin, ks, bf ? 32 : 16);
   ca.shortcut = shortcut; ca.y = y; ca.part = part_out;
