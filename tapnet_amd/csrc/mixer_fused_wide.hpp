@@ -33,7 +33,7 @@ inline long fused_wide_frags_per_wave(int k0_pad, int nblocks) {
 // SIM (TAPIR_EXPERIMENTS builds only, tools/kbench.py): 1 = TIMING-ONLY stand-in for a paired design in which
 // two CUs share two tracks and each takes half of the hidden units of both -- one workgroup per track, token
 // mixing for one track, half of the hidden chunks for both; its outputs are meaningless.
-template <int NTT, int NTRK, bool RAGGED, int SIM = 0>
+template <int NTT, int NTRK, bool RAGGED, int SIM = 0, bool TRACE = false>
 __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs a) {
   typedef bf16_t TA;
   constexpr int NT = NTT * NTRK;
@@ -61,6 +61,20 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
   float2 (*const s_stat)[ROWS][8] = reinterpret_cast<float2 (*)[ROWS][8]>(s_h);
   const int ch_lane = 64 * wave + 4 * g;
   const int trk0 = SIM ? (int)(blockIdx.x & ~1u) : (int)blockIdx.x * NTRK;   // first track of this workgroup
+
+  // TRACE (tools/kbench.py --what widetrace): shader cycles per phase, summed per wave
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto tick = [&](int k) {
+#ifndef TAPIR_HIPEMU
+    if (TRACE) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+      if (k >= 0) tph[k] += t - tlast;
+      tlast = t;
+    }
+#endif
+  };
+  tick(-1);
 
   const uint4* wp = a.stream + ((long)wave * a.frags_per_wave) * 64 + lane;
   uint4 ring[RING];
@@ -93,6 +107,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
   }
   fused_gemm<TA, 4, NT, 0, NoEpilogue, RING, false>(wp, ring, s_xn, in_stride, a.ld_in / KS / (RING / 4), c, g, xr);
   lds_barrier();   // the block parameters and the LN summaries overwrite the input image
+  tick(0);
 
   float valid[NTT];   // the same for every track of the workgroup
 #pragma unroll
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
     }
     // LN1's summaries use the chunk region, the parameters the first 64 KiB of the LN2 image
     ln_stats(mean, rstd);
+    tick(1);
     // ---- token mixing, one track and one channel pair at a time (see mixer_fused.hpp)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
       }
     }
 
+    tick(2);
     // ---- channel MLP
     ln_stats(mean, rstd);   // (its barrier also ends every wave's reads of the parameters)
     write_xn(bp.ln2, mean, rstd);
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
     }
     *reinterpret_cast<f32x4*>(&s_bup[tid * 4]) = gload4(bp.bup + tid * 4);
     lds_barrier();
+    tick(3);
     for (int hc = 0; hc < (SIM ? NC / 2 : NC); ++hc) {
       f32x4 ua[RAU][NT];
 #pragma unroll
@@ -265,15 +283,20 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
       }
       fused_gemm<TA, RAU, NT, 0, NoEpilogue, RING, false>(wp, ring, s_xn, XN_STRIDE, (kHidden / KS) / (RING / RAU),
                                                           c, g, ua);
+      tick(4);
 #pragma unroll
       for (int r = 0; r < RAU; ++r)
 #pragma unroll
         for (int i = 0; i < NT; ++i)
           store_act4<TA>(s_h, H_STRIDE, 16 * i + c, hid_lane + 16 * r, c, gelu_tanh(ua[r][i][0]),
                          gelu_tanh(ua[r][i][1]), gelu_tanh(ua[r][i][2]), gelu_tanh(ua[r][i][3]));
+      tick(5);
       lds_barrier();
+      tick(7);
       fused_gemm<TA, 4, NT, 0, NoEpilogue, RING, false>(wp, ring, s_h, H_STRIDE, (HC / KS) / (RING / 4), c, g, xr);
+      tick(6);
       lds_barrier();
+      tick(7);
     }
   }
 
@@ -307,6 +330,12 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
       }
     }
   }
+  if (TRACE && a.dbg_times != nullptr && lane == 0) {
+    tick(0);
+    long long* o = a.dbg_times + ((long)blockIdx.x * FM_WAVES + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (long long)tph[k];
+  }
 }
 
 // shapes the wide kernel covers: bf16, non-causal; one track of 49..96 frames, or pairs of tracks of up
@@ -330,6 +359,10 @@ inline void launch_mixer_fused_wide(const FusedArgs& a, hipStream_t s) {
     else TAPIR_LAUNCH((mixer_fused_wide_kernel<NTT_, NTRK_, false>), grid, block, s, a);                  \
   } while (0)
 #ifdef TAPIR_EXPERIMENTS
+  if (a.dbg_times != nullptr && ntt == 3 && !ragged && !a.pair_sim) {   // phase trace (tools/kbench.py --what widetrace)
+    hipLaunchKernelGGL((mixer_fused_wide_kernel<3, 2, false, 0, true>), dim3((unsigned)((a.N + 1) / 2)), block, 0, s, a);
+    return;
+  }
   if (a.pair_sim && ntt == 3 && !ragged) {
     hipLaunchKernelGGL((mixer_fused_wide_kernel<3, 2, false, 1>), dim3((unsigned)a.N), block, 0, s, a);
     return;

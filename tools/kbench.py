@@ -440,6 +440,38 @@ def trace_fused(model):
           f'   waves min/max {per_wave.min():.0f}/{per_wave.max():.0f}')
 
 
+def trace_wide(model):
+  """per-phase shader-cycle totals of the WIDE fused mixer kernel (two tracks per workgroup; TRACE build:
+  -DTAPIR_EXPERIMENTS library): [in/out linear, LN1 (+ parameter copy), token mixing, LN2 + xn, up, GELU + h store,
+  down, barriers] for N = 1024 tracks x 48 frames."""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  N, T = 1024, 48
+  cin = 388 + 49 * (2 + model.pyramid_level)
+  x = torch.randn(N, T, cin, device=dev)
+  out = torch.empty(N, T, 388, device=dev)
+  nwg = N // 2
+  buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+  assert lib.tapir_debug_set_mixer_mode(ctx, 3) == 0
+  for it in range(3):
+    buf.zero_()
+    assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
+    rc = lib.tapir_pips_mixer(ctx, x.data_ptr(), N, T, out.data_ptr(), None, None, None, None, model._stream())
+    assert rc == 0, lib.tapir_last_error(ctx)
+    torch.cuda.synchronize()
+  lib.tapir_debug_set_trace(ctx, None)
+  lib.tapir_debug_set_mixer_mode(ctx, 0)
+  t = buf.view(nwg, 8, 8).double().cpu().numpy()
+  names = ['in+out linear', 'LN1 (+ parameter copy)', 'token mixing (2 tracks)', 'LN2 + xn write', 'up', 'GELU + h store',
+           'down', 'barriers of the chunk loop']
+  tot = t.sum(-1).mean()
+  print(f'wide fused mixer phase trace ({model.dtype}), N = {N} x T = {T}: mean shader cycles per wave, whole kernel {tot:.0f} cycles')
+  for k, nm in enumerate(names):
+    per_wave = t[:, :, k].mean(0)
+    print(f'  {nm:28s} {t[:, :, k].mean():10.0f} cycles  {100 * t[:, :, k].mean() / tot:5.1f} %   per block {t[:, :, k].mean() / 12:8.0f}'
+          f'   waves min/max {per_wave.min():.0f}/{per_wave.max():.0f}')
+
+
 def trace_conv(model):
   """per-phase shader-cycle totals of the fused 3x3 convolution (TRACE build: library built with
   -DTAPIR_EXPERIMENTS, TAPIR_HIP_LIB=...): mean over waves and workgroups."""
@@ -593,6 +625,8 @@ def main():
       trace_cv_fused(model)
     if 'fusedtrace' in what:
       trace_fused(model)
+    if 'widetrace' in what:
+      trace_wide(model)
     if 'mixtrace' in what:
       trace_mix(model)
     if 'mixer' in what:
