@@ -389,3 +389,22 @@ def test_chunked_feature_extraction_is_eager_and_identical():
       out = bb.features(frames, chunk)
     assert all(torch.equal(a, b) for a, b in zip(out, ref)), chunk
   assert set(bb._graphs) == keys                       # chunked calls never enter the graph cache
+
+
+@pytest.mark.parametrize('size,expect_hip', [(512, True), (576, False)])
+def test_extra_convs_map_widths(size, expect_hip):
+  """ExtraConvs on larger frames (f32 build): 512 x 512 -> a 64-wide low-res map (one output row per tile, input
+  channels in chunks of 64: BASELINE configs[4]) runs the HIP kernels and agrees with the MIOpen + torch path to
+  2e-5; 576 x 576 -> 72 cells per row is beyond the kernels (tapir_xconv_plan: TAPIR_ERR_UNSUPPORTED) and takes
+  the library path -- silently equal, never wrong."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(21, 1, True)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='float32')
+  bb = m._backbone
+  frames = torch.as_tensor(synthetic.make_video(3, 4, size, size), device='cuda:0').reshape(-1, size, size, 3).float()
+  bb.extra_convs_mode = 'torch'
+  ref = [t.clone() for t in bb.features(frames)]
+  bb.extra_convs_mode = 'hip'
+  got = bb.features(frames)
+  assert bool(bb._xstream) == expect_hip
+  assert float((ref[0] - got[0]).abs().max()) < 2e-5, float((ref[0] - got[0]).abs().max())
