@@ -288,25 +288,31 @@ def tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
 def tapnet_tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_feature,
                                   feature_grid, query_points, im_hw=(256, 256),
                                   softmax_temperature=10.0, return_stages=False):
-  """TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171), num_heads = 1.
+  """TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171).
 
   The TAP-Net head is the TAPIR head with three differences, all visible in the reference text:
   there is NO ReLU between the stride-2 convolution `hid3` and the spatial mean (:160-161 vs
   tapir_model.py:460-462), `occ_out` has ONE output (occlusion only, no expected distance; :90),
   and the softmax temperature is 10 (:61).  Conv3D kernels of shape [1,3,3] over (t, h, w) are 2-D
   3x3 convolutions per frame.  Weights: `tapnet_cost_volume_track_mods.{hid1,hid2,hid3,hid4,
-  occ_out}.{weight,bias}` in the torch layout of the TAPIR head (hid1 [16,1,3,3], ..., occ_out [1,16]).
+  occ_out}.{weight,bias}` in the torch layout of the TAPIR head (hid1 [16,heads,3,3], ..., occ_out [1,16]).
+  num_heads = hid1's input channels: channel c of the features belongs to head c % heads
+  ('b t h w (c d) -> b t h w c d', :247-254) and every head's cost map is one input channel of hid1.
 
-  Parity status: UNPINNED.  The reference has no torch twin of TAP-Net and JAX cannot run offline;
-  this restatement shares every line of arithmetic with `tracks_from_cost_volume` above (pinned to the
-  reference's torch TAPIR) except the three differences listed.
+  Parity status: pinned to the reference's OWN code executed over numpy stand-ins for jax / haiku
+  (oracle/hk_numpy_shim.py, oracle/make_tapnet_golden.py -> tests/golden/tapnet_head.npz,
+  tests/test_tapnet_reference_pin.py: tracks 2e-5 px, occlusion 1e-8) -- the reference has no torch twin
+  of TAP-Net and JAX cannot run offline, so the primitives (convolution padding, softmax,
+  map_coordinates) under the reference's lines are restated ones.
 
   interp_feature [B,N,C]; feature_grid [B,T,h,w,C]; returns points [B,N,T,2], occlusion [B,N,T]."""
   p = 'tapnet_cost_volume_track_mods.'
   dt = feature_grid.dtype
-  cv = build_cost_volume(interp_feature, feature_grid)  # [T,B,N,h,w]  ('bncd,bthwcd->tbnhwd', d = 1)
-  t, b, n, h, w = cv.shape
-  x = cv.reshape(t * b * n, h, w, 1)
+  heads = weights[p + 'hid1.weight'].shape[1]
+  cv = np.stack([build_cost_volume(interp_feature[..., d::heads], feature_grid[..., d::heads])
+                 for d in range(heads)], -1)              # [T,B,N,h,w,heads]  ('bncd,bthwcd->tbnhwd')
+  t, b, n, h, w, _ = cv.shape
+  x = cv.reshape(t * b * n, h, w, heads)
   hid1 = np.maximum(conv2d_same(x, weights[p + 'hid1.weight'], weights[p + 'hid1.bias']), 0)
   logits = conv2d_same(hid1, weights[p + 'hid2.weight'], weights[p + 'hid2.bias'])
   logits = logits.reshape(t, b, n, h, w).transpose(1, 2, 0, 3, 4)  # b n t h w

@@ -14,7 +14,9 @@ convolutions, softmax, soft arg max and the occlusion head in one launch.
 Out of scope: the TSM-ResNet backbone (tapnet/models/tsm_resnet.py).  ``__call__``
 therefore needs ``feature_grid`` (the L2-normalised [B,T,H/8,W/8,256] grid the reference returns as
 ``out['feature_grid']``); query features are sampled from it on the GPU (model_utils.interp,
-mode='nearest': tapir_get_query_features).  ``num_heads`` must be 1 (the released checkpoint).
+mode='nearest': tapir_get_query_features).  ``num_heads`` must be 1 (the constructor default; nothing in the reference sets another value).
+Pinned against the reference's own tapnet_model.py executed over numpy stand-ins for jax / haiku
+(oracle/make_tapnet_golden.py -> tests/golden/tapnet_head.npz, tests/test_tapnet_reference_pin.py).
 
 Weights: ``{'tapnet_cost_volume_track_mods.<hid1|hid2|hid3|hid4|occ_out>.<weight|bias>': array}`` in
 the torch layout of the TAPIR head (hid1 [16,1,3,3], hid2 [1,16,3,3], hid3 [32,16,3,3], hid4 [16,32],
