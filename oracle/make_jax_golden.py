@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/jax_*.npz by EXECUTING the reference's JAX/Haiku text
+(``tapnet/models/tapir_model.py``: TAPIR and its main entry point ParameterizedTAPIR; ``tapnet/models/resnet.py``;
+``tapnet/utils/model_utils.py``, ``transforms.py``) from /root/reference over the numpy stand-ins of
+``oracle/hk_numpy_shim.py`` (JAX / Haiku are not installable in the build container; that file says what is the
+reference's and what is restated).  The torch twin (oracle/make_golden.py) pins the oracle where twin and JAX text
+agree; this script covers what only the JAX text has: per-axis sampling on NON-SQUARE grids, the
+antialiased down-resize of the multi-resolution path, the Haiku parameter names / layouts, the causal-state keys.
+
+  python oracle/make_jax_golden.py [case ...]          # writes tests/golden/jax_<case>.npz
+  python oracle/make_jax_golden.py --check [case ...]  # re-runs the reference and compares with the committed files
+
+Parameters: tapnet_amd.synthetic.make_weights(seed) (torch names, what the fixtures of make_golden.py use) converted
+with the product's tapnet_amd.weights.torch_to_haiku_names.  Two checks happen HERE, with the reference present:
+  * hk.transform_with_state(...).init over the reference's module tree creates exactly the modules / leaves / shapes
+    the converted tree has (no missing, no extra: the five head modules tapir_model.py:362-376 declares and never
+    calls create none);
+  * ParameterizedTAPIR(params, state, tapir_kwargs) -- .apply looks every parameter up by the name the module
+    tree asks for and fails on a miss.
+The committed files hold inputs, per-level feature grids and outputs only (the weights are a seed).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+REFERENCE_ROOT = os.environ.get('TAPNET_REFERENCE', '/root/reference')
+GOLDEN = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+CASES = dict(
+    # TAPIR kwargs on a non-square clip at its training resolution; two ragged query chunks (random permutation)
+    tapir_nonsquare=dict(seed=31, kw=dict(pyramid_level=0, extra_convs=False, initial_resolution=(64, 96)),
+                         T=3, HW=(64, 96), Q=6, chunk=4),
+    # BootsTAPIR kwargs, clip at twice the training resolution: levels (64,96) [antialiased resize] and (128,192)
+    bootstapir_multires=dict(seed=32, kw=dict(pyramid_level=1, extra_convs=True, initial_resolution=(64, 96)),
+                             T=2, HW=(128, 192), Q=4, chunk=4),
+    # causal model driven frame by frame as tapnet/live_demo.py:51-77 does
+    causal_online=dict(seed=33, kw=dict(pyramid_level=1, extra_convs=True, initial_resolution=(64, 96),
+                                        use_causal_conv=True), T=3, HW=(64, 96), Q=4, chunk=4, online=True),
+)
+
+
+def tree_signature(tree):
+  return {f'{m}:{k}': tuple(np.shape(v)) for m, leaves in tree.items() for k, v in leaves.items()}
+
+
+def run_case(name, c, ref, hk):
+  from tapnet_amd import synthetic, weights
+  kw = dict(c['kw'])
+  w = synthetic.make_weights(c['seed'], kw['pyramid_level'], kw['extra_convs'])
+  params = weights.torch_to_haiku_names(w)
+  H, W = c['HW']
+  video = synthetic.make_video(c['seed'], c['T'], H, W).astype(np.float32)            # [1,T,H,W,3]
+  qp = synthetic.make_queries(c['seed'] + 1, c['Q'], c['T'], H, W).astype(np.float32)  # [1,Q,3] (t,y,x)
+  if c.get('online'):
+    qp[..., 0] = 0.0            # the online demo queries points on the first frame
+
+  # (1) the module tree of the reference creates exactly the converted tree
+  t0 = time.time()
+  init_fn = hk.transform_with_state(
+      lambda v, q: ref.TAPIR(**kw)(v, False, q, query_chunk_size=c['chunk']))
+  created, _ = init_fn.init(np.array([0, 1]), video[:, :2], qp[:, :1] * np.array([0.0, 1.0, 1.0], np.float32))
+  a, b = tree_signature(created), tree_signature(params)
+  assert a == b, ('only the reference creates', sorted(set(a.items()) - set(b.items()))[:8],
+                  'only the converter creates', sorted(set(b.items()) - set(a.items()))[:8])
+  print(f'[{name}] module tree: {len(created)} modules, {len(a)} leaves match  ({time.time() - t0:.0f} s)', flush=True)
+
+  # (2) the reference's entry point on the converted tree
+  model = ref.ParameterizedTAPIR(params, {}, tapir_kwargs=kw)
+  out = {'video': video, 'query_points': qp, 'seed': np.array(c['seed']),
+         'pyramid_level': np.array(kw['pyramid_level']), 'extra_convs': np.array(kw['extra_convs']),
+         'initial_resolution': np.array(kw['initial_resolution']), 'query_chunk_size': np.array(c['chunk']),
+         'use_causal_conv': np.array(bool(kw.get('use_causal_conv', False)))}
+  t0 = time.time()
+  if not c.get('online'):
+    fg = model.get_feature_grids(video, False)
+    res = model(video, False, qp, query_chunk_size=c['chunk'], feature_grids=fg)
+    for i, (lo, hi, r) in enumerate(zip(fg.lowres, fg.hires, fg.resolutions)):
+      out[f'lowres_{i}'], out[f'hires_{i}'] = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+      out[f'resolution_{i}'] = np.array(r.shape[:2])
+    for k in ('tracks', 'occlusion', 'expected_dist'):
+      out[k] = np.asarray(res[k], np.float32)
+    for k in ('unrefined_tracks', 'unrefined_occlusion', 'unrefined_expected_dist'):
+      out[k] = np.stack([np.asarray(v, np.float32) for v in res[k]])
+  else:
+    qf = model.get_query_features(video[:, :1], False, qp)
+    state = model.construct_initial_causal_state(c['Q'], len(qf.resolutions) - 1)
+    out['causal_state_keys'] = np.array(sorted(state[0]))
+    tracks, occ, expd = [], [], []
+    for t in range(c['T']):
+      fg = model.get_feature_grids(video[:, t:t + 1], False)
+      tr = model.estimate_trajectories(video.shape[-3:-1], False, fg, qf, None, query_chunk_size=c['chunk'],
+                                       causal_context=state, get_causal_context=True)
+      state = tr['causal_context']
+      tracks.append(np.asarray(tr['tracks'][-1], np.float32))
+      occ.append(np.asarray(tr['occlusion'][-1], np.float32))
+      expd.append(np.asarray(tr['expected_dist'][-1], np.float32))
+    out['tracks'] = np.concatenate(tracks, 2)
+    out['occlusion'] = np.concatenate(occ, 2)
+    out['expected_dist'] = np.concatenate(expd, 2)
+    out['query_lowres_0'] = np.asarray(qf.lowres[0], np.float32)
+    # causal state after the last frame, last refinement iteration: first and last mixer block
+    out['state_block_causal_1'] = np.asarray(state[-1]['tapir/~/pips_mlp_mixer/block_causal_1'], np.float32)
+    out['state_block_11_causal_2'] = np.asarray(state[-1]['tapir/~/pips_mlp_mixer/block_11_causal_2'], np.float32)
+  print(f'[{name}] reference run {time.time() - t0:.0f} s', flush=True)
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('cases', nargs='*', default=[])
+  ap.add_argument('--check', action='store_true')
+  a = ap.parse_args()
+  from oracle import hk_numpy_shim as shim
+  shim.install()
+  if REFERENCE_ROOT not in sys.path:
+    sys.path.insert(0, REFERENCE_ROOT)
+  import haiku as hk                                  # the stand-in
+  from tapnet.models import tapir_model as ref        # the reference, imported over the stand-ins
+  for name in (a.cases or list(CASES)):
+    out = run_case(name, CASES[name], ref, hk)
+    path = os.path.join(GOLDEN, f'jax_{name}.npz')
+    if a.check:
+      old = np.load(path)
+      assert sorted(old.files) == sorted(out), 'key sets differ'
+      worst = max(float(np.max(np.abs(old[k].astype(np.float64) - out[k]))) for k in out if out[k].dtype.kind == 'f')
+      print(f'[{name}] max |committed - regenerated| = {worst:.3g}')
+      assert worst < 1e-5
+    else:
+      np.savez_compressed(path, **out)
+      print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+  main()

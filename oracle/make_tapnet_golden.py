@@ -12,8 +12,9 @@ backbone -- out of scope, SURVEY.md 8 -- never runs):
   a: num_heads 1, 1 clip x 3 frames, 128x128 video (16x16 grid), 12 queries in ragged chunks of 5
   b: num_heads 1, 2 clips x 2 frames, 96x128 video (12x16 grid), 6 queries, get_query_feats
   c: num_heads 2, 1 clip x 2 frames, 64x64 video (8x8 grid), 5 queries          (restatement only)
-Parameters are drawn here in HAIKU layout ('tap_net/<module>': {'w','b'}; Conv3D kernels [1,3,3,in,out],
-Linear [in,out]) and stored under those names: the tests convert them with the product's
+Parameters are created by the stand-in's hk.transform_with_state(...).init in HAIKU layout and under the names
+the reference's module tree gives them ('tap_net/~/<module>': {'w','b'}; Conv3D kernels [1,3,3,in,out], Linear
+[in,out]) and stored under those names: the tests convert them with the product's
 tapnet_amd.tapnet_model.from_haiku_params, so the converter is inside the pin.
 """
 import argparse
@@ -28,23 +29,15 @@ REFERENCE_ROOT = os.environ.get('TAPNET_REFERENCE', '/root/reference')
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'tapnet_head.npz')
 
 
-def haiku_params(rng, num_heads):
-  n = lambda shape, s: (rng.standard_normal(shape) * s).astype(np.float32)
-  p = {}
-  for name, ci, co in (('cost_volume_regression_1', num_heads, 16), ('cost_volume_regression_2', 16, 1),
-                       ('cost_volume_occlusion_1', 16, 32)):
-    p['tap_net/' + name] = dict(w=n((1, 3, 3, ci, co), 1.0 / np.sqrt(9 * ci)), b=n((co,), 0.02))
-  for name, ci, co in (('cost_volume_occlusion_2', 32, 16), ('occlusion_out', 16, 1)):
-    p['tap_net/' + name] = dict(w=n((ci, co), 1.0 / np.sqrt(ci)), b=n((co,), 0.02))
-  # peaky heat maps (a trained head's are): channel 0 of hid1 passes the cost volume through, hid2 reads it
-  w1, w2 = p['tap_net/cost_volume_regression_1'], p['tap_net/cost_volume_regression_2']
+def make_peaky(p):
+  """Peaky heat maps (a trained head's are): channel 0 of hid1 passes the cost volume through, hid2 reads it."""
+  w1, w2 = p['tap_net/~/cost_volume_regression_1'], p['tap_net/~/cost_volume_regression_2']
   w1['w'][..., 0] = 0.0
   w1['w'][0, 1, 1, :, 0] = 1.0
   w1['b'][0] = 0.0
   w2['w'] *= np.float32(0.1)
   w2['w'][0, :, :, 0, 0] = 0.0
   w2['w'][0, 1, 1, 0, 0] = 3.0
-  return p
 
 
 def l2n(x):
@@ -58,24 +51,29 @@ CASES = dict(a=dict(heads=1, B=1, T=3, hw=(16, 16), Q=12, chunk=5, seed=1),
 
 def run_reference():
   from oracle import hk_numpy_shim as shim
+  shim.install()
+  if REFERENCE_ROOT not in sys.path:
+    sys.path.insert(0, REFERENCE_ROOT)
+  import haiku as hk                                  # the stand-in
+  from tapnet.models import tapnet_model as mod       # the reference, imported over the stand-ins
   out = {}
-  mod = None
   for tag, c in CASES.items():
     rng = np.random.default_rng(c['seed'])
-    params = haiku_params(rng, c['heads'])
-    shim.install(params)
-    if mod is None:
-      if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
-      from tapnet.models import tapnet_model as mod    # the reference, imported over the stand-ins
     h, w = c['hw']
     H, W = 8 * h, 8 * w
     grid = l2n(rng.standard_normal((c['B'], c['T'], h, w, 256)))
     qp = np.stack([rng.integers(0, c['T'], (c['B'], c['Q'])), rng.uniform(0, H, (c['B'], c['Q'])),
                    rng.uniform(0, W, (c['B'], c['Q']))], -1).astype(np.float32)
     video = np.zeros((c['B'], c['T'], H, W, 3), np.float32)
-    model = mod.TAPNet(num_heads=c['heads'])
-    res = model(video, False, qp, query_chunk_size=c['chunk'], get_query_feats=True, feature_grid=grid)
+
+    def forward(video, qp, grid):
+      model = mod.TAPNet(num_heads=c['heads'])
+      return model(video, False, qp, query_chunk_size=c['chunk'], get_query_feats=True, feature_grid=grid)
+
+    fn = hk.transform_with_state(forward)
+    params, state = fn.init(np.array([0, c['seed']]), video, qp, grid)   # names as the module tree creates them
+    make_peaky(params)
+    res, _ = fn.apply(params, state, None, video, qp, grid)
     for k, v in params.items():
       for kk, a in v.items():
         out[f'{tag}/params/{k}/{kk}'] = a

@@ -13,9 +13,14 @@ REFERENCE ITSELF: ``oracle/make_golden.py`` imports the reference PyTorch TAPIR
 from /root/reference, runs it on seeded inputs and commits stage-boundary
 tensors under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this
 file against those fixtures (and, when /root/reference is present, against the
-live reference).  The JAX path itself cannot be imported offline (no jax), so
-JAX-vs-torch differences listed in SURVEY.md section 8c are resolved in favour
-of the JAX source text (e.g. per-axis normalisation in ``interp``).
+live reference).  JAX / Haiku cannot be installed offline; JAX-vs-torch
+differences listed in SURVEY.md section 8c are resolved in favour of the JAX
+source text (e.g. per-axis normalisation in ``interp``), and since round 3 the
+JAX text itself is EXECUTED over numpy stand-ins for jax / haiku
+(``oracle/hk_numpy_shim.py``; ``oracle/make_jax_golden.py`` ->
+``tests/golden/jax_*.npz``; ``tests/test_jax_reference_pin.py``): non-square
+clips, the multi-resolution path with the antialiased resize, the online causal
+loop and the Haiku parameter tree agree with this file at 4e-5 px / 3e-6.
 
 Weights are a flat ``dict[str, np.ndarray]`` keyed by the reference's torch
 ``state_dict`` names (tapnet/torch/tapir_model.py:115-137).

@@ -528,8 +528,10 @@ def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int], antialias:
   (tapir_model.py:670) additionally anti-aliases when DOWN-sampling (triangle kernel widened by the
   scale factor); `antialias=True` selects that behaviour through F.interpolate(antialias=True), the
   same filter family.  Identical for up-sampling and for the no-op 256->256 case; it matters for
-  inputs larger than initial_resolution (e.g. 512 -> 256, BASELINE configs[4]).  The JAX variant
-  cannot be pinned offline (no jax), hence opt-in: TAPIR(..., jax_antialias_resize=True)."""
+  inputs larger than initial_resolution (e.g. 512 -> 256, BASELINE configs[4]).  Opt-in for torch-named
+  weights (TAPIR(..., jax_antialias_resize=True)), the default when ParameterizedTAPIR is given a Haiku tree;
+  held to a restatement of jax/_src/image/scale.py and, through it, to the JAX text run over numpy stand-ins
+  (tests/test_jax_reference_pin.py::test_gpu_matches_the_jax_text[bootstapir_multires])."""
   b, t, h, w, c = video.shape
   x = video.permute(0, 1, 4, 2, 3).reshape(b, t * c, h, w)
   down = resolution[0] < h or resolution[1] < w

@@ -45,7 +45,8 @@ LOWRES_DIM = 256
 
 
 class FeatureGrids(NamedTuple):
-  """tapir_model.py:251-270.  ``resolutions`` are (H, W) tuples (torch twin convention)."""
+  """tapir_model.py:251-270.  ``resolutions`` are (H, W) tuples (torch twin convention) that also carry
+  ``.shape`` (JAX convention): see Resolution."""
   lowres: Sequence[Any]
   hires: Sequence[Any]
   resolutions: Sequence[Tuple[int, int]]
@@ -67,6 +68,16 @@ class CausalState(list):
 
 def _is_numpy(x) -> bool:
   return isinstance(x, np.ndarray)
+
+
+class Resolution(tuple):
+  """An (H, W) tuple -- the torch twin's convention (tapnet/torch/tapir_model.py:45) -- that also answers
+  ``.shape`` like the JAX model's zero-size shape carriers (``video_resize[0, 0, :, :, 0:0]``, :259-265, :724),
+  so ``feature_grids.resolutions[i].shape[:2]`` and ``resolutions[i][0]`` both read the resolution."""
+
+  @property
+  def shape(self) -> Tuple[int, int, int]:
+    return (int(self[0]), int(self[1]), 0)
 
 
 def _res_hw(r) -> Tuple[int, int]:
@@ -311,7 +322,7 @@ class TAPIR:
         hires = hi.reshape(b, t, *hi.shape[1:])
       feature_grid.append(latent)
       hires_feats.append(hires)
-      resize_im_shape.append(tuple(resolution))
+      resize_im_shape.append(Resolution(resolution))
     return FeatureGrids(tuple(feature_grid), tuple(hires_feats), tuple(resize_im_shape))
 
   # ------------------------------------------------------------------ R8
@@ -326,7 +337,7 @@ class TAPIR:
     shape = tuple(video.shape) if hasattr(video, 'shape') else tuple(video)
     qp = self._dev(query_points)
     B, Q = qp.shape[:2]
-    resolutions = [_res_hw(r) for r in feature_grids.resolutions]
+    resolutions = [Resolution(_res_hw(r)) for r in feature_grids.resolutions]
     q_low, q_hi = [], []
     curr = (-1, -1)
     for i, res in enumerate(resolutions):
@@ -596,8 +607,11 @@ class ParameterizedTAPIR:
     from tapnet_amd import weights as weights_lib
     kwargs = dict(tapir_kwargs) if tapir_kwargs else {}
     flat = weights_lib.to_torch_names(params) if params is not None else None
-    self._model = TAPIR(**kwargs, weights=flat,
-                        haiku_state_names=weights_lib.is_haiku_params(params), **engine_kwargs)
+    is_haiku = weights_lib.is_haiku_params(params)
+    # a Haiku tree means the caller drives the JAX model: its causal-state keys and its antialiased
+    # down-resize (tapir_model.py:670; tests/test_jax_reference_pin.py) unless told otherwise
+    engine_kwargs.setdefault('jax_antialias_resize', is_haiku)
+    self._model = TAPIR(**kwargs, weights=flat, haiku_state_names=is_haiku, **engine_kwargs)
     for fn in ('estimate_trajectories', 'get_query_features', 'get_feature_grids',
                'construct_initial_causal_state', 'update_query_features'):
       setattr(self, fn, getattr(self._model, fn))

@@ -21,7 +21,7 @@ Pinned against the reference's own tapnet_model.py executed over numpy stand-ins
 Weights: ``{'tapnet_cost_volume_track_mods.<hid1|hid2|hid3|hid4|occ_out>.<weight|bias>': array}`` in
 the torch layout of the TAPIR head (hid1 [16,1,3,3], hid2 [1,16,3,3], hid3 [32,16,3,3], hid4 [16,32],
 occ_out [1,16]); ``from_haiku_params`` converts the reference's Haiku tree
-(``tap_net/cost_volume_regression_1`` ...).
+(``tap_net/~/cost_volume_regression_1`` ...).
 """
 from __future__ import annotations
 
@@ -40,10 +40,13 @@ HAIKU_NAMES = {   # tapnet_model.py:64-107 (hk.Conv3D kernels are [1,3,3,in,out]
 
 
 def from_haiku_params(params: Mapping[str, Mapping[str, Any]], scope: str = 'tap_net') -> dict:
-  """Haiku params of the reference TAPNet head -> the flat torch-layout dict this module loads."""
+  """Haiku params of the reference TAPNet head -> the flat torch-layout dict this module loads.
+  The head's modules are constructed in TAPNet.__init__ (tapnet_model.py:79-108), so Haiku files them under
+  '<scope>/~/<name>' ('tap_net/~/cost_volume_regression_1'); a tree without the '~' level is accepted too."""
   out = {}
   for short, hk_name in HAIKU_NAMES.items():
-    mod = params[f'{scope}/{hk_name}']
+    key = f'{scope}/~/{hk_name}'
+    mod = params[key] if key in params else params[f'{scope}/{hk_name}']
     w, b = np.asarray(mod['w'], np.float32), np.asarray(mod['b'], np.float32)
     if w.ndim == 5:      # Conv3D [1,3,3,in,out] -> [out,in,3,3]
       w = np.transpose(w[0], (3, 2, 0, 1))

@@ -4,8 +4,10 @@ state_dict, tapnet/torch/tapir_model.py:115-137) and Haiku ``.npy`` params
 
 The Haiku -> torch-name conversion follows the module names in
 tapnet/models/tapir_model.py:341-384 and tapnet/models/resnet.py:185-222,
-399-448.  It could not be exercised against a real Haiku checkpoint offline
-(no network, no jax): it is checked for shape consistency only.
+399-448.  It is held to the parameter tree the reference's own modules create
+when run over numpy stand-ins for jax / haiku (oracle/make_jax_golden.py,
+tests/test_jax_reference_pin.py); a real released ``.npy`` could not be fetched
+offline.
 """
 from __future__ import annotations
 
@@ -109,5 +111,65 @@ def haiku_to_torch_names(params: Mapping[str, Mapping[str, Any]]) -> Dict[str, n
     c1 = ec + f'conv2_d_{2 * n + 1}'
     out[p + 'conv.weight'] = _conv_w(get(c0, 'w')); out[p + 'conv.bias'] = get(c0, 'b')
     out[p + 'conv_1.weight'] = _conv_w(get(c1, 'w')); out[p + 'conv_1.bias'] = get(c1, 'b')
+    n += 1
+  return out
+
+
+def torch_to_haiku_names(weights: Mapping[str, Any]) -> Dict[str, Dict[str, np.ndarray]]:
+  """Inverse of haiku_to_torch_names: a flat torch-named dict -> the Haiku tree ``{module: {leaf: array}}``
+  the reference's ``ParameterizedTAPIR(params, state, tapir_kwargs)`` consumes (tapir_model.py:1199-1260).
+  Used to run the reference's JAX text on this package's weights (oracle/make_jax_golden.py) and to export."""
+  w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+  out: Dict[str, Dict[str, np.ndarray]] = {}
+  hwio = lambda a: np.ascontiguousarray(np.transpose(a, (2, 3, 1, 0)))
+  root = 'tapir/~/'
+  for t, h in (('hid1', 'cost_volume_regression_1'), ('hid2', 'cost_volume_regression_2'),
+               ('hid3', 'cost_volume_occlusion_1')):
+    out[root + h] = {'w': hwio(w[f'torch_cost_volume_track_mods.{t}.weight']),
+                     'b': w[f'torch_cost_volume_track_mods.{t}.bias']}
+  for t, h in (('hid4', 'cost_volume_occlusion_2'), ('occ_out', 'occlusion_out')):
+    out[root + h] = {'w': w[f'torch_cost_volume_track_mods.{t}.weight'].T.copy(),
+                     'b': w[f'torch_cost_volume_track_mods.{t}.bias']}
+  mx = root + 'pips_mlp_mixer/'
+  for t in ('linear', 'linear_1'):
+    out[mx + t] = {'w': w[f'torch_pips_mixer.{t}.weight'].T.copy(), 'b': w[f'torch_pips_mixer.{t}.bias']}
+  out[mx + 'layer_norm'] = {'scale': w['torch_pips_mixer.layer_norm.weight']}
+  i = 0
+  while f'torch_pips_mixer.blocks.{i}.mlp1_up.weight' in w:
+    p = f'torch_pips_mixer.blocks.{i}.'
+    blk = mx + ('block' if i == 0 else f'block_{i}') + '/'
+    out[blk + 'layer_norm'] = {'scale': w[p + 'layer_norm.weight']}
+    out[blk + 'layer_norm_1'] = {'scale': w[p + 'layer_norm_1.weight']}
+    for t in ('mlp1_up', 'mlp1_up_1'):   # torch depthwise Conv1d [C*mult, 1, k] -> hk.DepthwiseConv1D [k, 1, C*mult]
+      out[blk + t] = {'w': np.ascontiguousarray(np.transpose(w[p + t + '.weight'], (2, 1, 0))),
+                      'b': w[p + t + '.bias']}
+    for t in ('mlp2_up', 'mlp2_down'):
+      out[blk + t] = {'w': w[p + f'conv_channels_mixer.{t}.weight'].T.copy(),
+                      'b': w[p + f'conv_channels_mixer.{t}.bias']}
+    i += 1
+  rn = root + 'resnet/~/'
+  if 'resnet_torch.initial_conv.weight' in w:
+    out[rn + 'initial_conv'] = {'w': hwio(w['resnet_torch.initial_conv.weight'])}
+    g = 0
+    while f'resnet_torch.block_groups.{g}.blocks.0.conv_0.weight' in w:
+      b = 0
+      while f'resnet_torch.block_groups.{g}.blocks.{b}.conv_0.weight' in w:
+        p = f'resnet_torch.block_groups.{g}.blocks.{b}.'
+        blk = f'{rn}block_group_{g}/~/block_{b}/~/'
+        if p + 'proj_conv.weight' in w:
+          out[blk + 'shortcut_conv'] = {'w': hwio(w[p + 'proj_conv.weight'])}
+        for j in (0, 1):
+          out[blk + f'conv_{j}'] = {'w': hwio(w[p + f'conv_{j}.weight'])}
+          out[blk + f'instancenorm_{j}'] = {'scale': w[p + f'bn_{j}.weight'], 'offset': w[p + f'bn_{j}.bias']}
+        b += 1
+      g += 1
+  n = 0
+  while f'extra_convs.blocks.{n}.conv.weight' in w:
+    p = f'extra_convs.blocks.{n}.'
+    ec = root + 'extra_convs/'
+    out[ec + ('layer_norm' if n == 0 else f'layer_norm_{n}')] = {'scale': w[p + 'layer_norm.weight'],
+                                                                'offset': w[p + 'layer_norm.bias']}
+    out[ec + ('conv2_d' if n == 0 else f'conv2_d_{2 * n}')] = {'w': hwio(w[p + 'conv.weight']), 'b': w[p + 'conv.bias']}
+    out[ec + f'conv2_d_{2 * n + 1}'] = {'w': hwio(w[p + 'conv_1.weight']), 'b': w[p + 'conv_1.bias']}
     n += 1
   return out

@@ -25,8 +25,9 @@ def _case(tag):
   params = {}
   for k in GOLD.files:
     if k.startswith(tag + '/params/'):
-      _, _, scope, mod, leaf = k.split('/')
-      params.setdefault(scope + '/' + mod, {})[leaf] = GOLD[k]
+      mod, leaf = k[len(tag + '/params/'):].rsplit('/', 1)      # 'tap_net/~/cost_volume_regression_1', 'w'
+      params.setdefault(mod, {})[leaf] = GOLD[k]
+  assert all(m.startswith('tap_net/~/') for m in params)       # constructed in TAPNet.__init__
   w = tapnet_model.from_haiku_params(params)
   return (w, GOLD[tag + '/feature_grid'], GOLD[tag + '/query_points'],
           tuple(int(v) for v in GOLD[tag + '/video_shape']),
