@@ -40,6 +40,13 @@ CASES = dict(
     # causal model driven frame by frame as tapnet/live_demo.py:51-77 does
     causal_online=dict(seed=33, kw=dict(pyramid_level=1, extra_convs=True, initial_resolution=(64, 96),
                                         use_causal_conv=True), T=3, HW=(64, 96), Q=4, chunk=4, online=True),
+    # the same loop with a mid-stream point replacement: update_query_features(..., causal_state) (:1172-1203)
+    causal_update=dict(seed=34, kw=dict(pyramid_level=1, extra_convs=False, initial_resolution=(48, 80),
+                                        use_causal_conv=True), T=4, HW=(48, 80), Q=5, chunk=5, online=True,
+                       update_frame=2, update_idx=(1, 3)),
+    # two clips in one call, backbone in frame chunks of 2 (feature_extractor_chunk_size, :680-700)
+    batch2_chunked=dict(seed=35, kw=dict(pyramid_level=1, extra_convs=False, initial_resolution=(48, 80),
+                                         feature_extractor_chunk_size=2), T=3, HW=(48, 80), Q=5, chunk=3, B=2),
 )
 
 
@@ -53,8 +60,9 @@ def run_case(name, c, ref, hk):
   w = synthetic.make_weights(c['seed'], kw['pyramid_level'], kw['extra_convs'])
   params = weights.torch_to_haiku_names(w)
   H, W = c['HW']
-  video = synthetic.make_video(c['seed'], c['T'], H, W).astype(np.float32)            # [1,T,H,W,3]
-  qp = synthetic.make_queries(c['seed'] + 1, c['Q'], c['T'], H, W).astype(np.float32)  # [1,Q,3] (t,y,x)
+  nb = c.get('B', 1)
+  video = np.concatenate([synthetic.make_video(c['seed'] + 10 * b, c['T'], H, W) for b in range(nb)]).astype(np.float32)
+  qp = np.concatenate([synthetic.make_queries(c['seed'] + 1 + 10 * b, c['Q'], c['T'], H, W) for b in range(nb)]).astype(np.float32)
   if c.get('online'):
     qp[..., 0] = 0.0            # the online demo queries points on the first frame
 
@@ -92,6 +100,13 @@ def run_case(name, c, ref, hk):
     tracks, occ, expd = [], [], []
     for t in range(c['T']):
       fg = model.get_feature_grids(video[:, t:t + 1], False)
+      if t == c.get('update_frame', -1):       # replace some points by new queries on the current frame
+        idx = tuple(c['update_idx'])
+        new_qp = synthetic.make_queries(c['seed'] + 5, len(idx), 1, H, W).astype(np.float32)
+        new_qp[..., 0] = 0.0
+        new_qf = model.get_query_features(video[:, t:t + 1], False, new_qp, feature_grids=fg)
+        qf, state = model.update_query_features(qf, new_qf, idx, state)
+        out['new_query_points'] = new_qp
       tr = model.estimate_trajectories(video.shape[-3:-1], False, fg, qf, None, query_chunk_size=c['chunk'],
                                        causal_context=state, get_causal_context=True)
       state = tr['causal_context']

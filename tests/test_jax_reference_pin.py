@@ -20,25 +20,29 @@ from oracle import tapir_oracle as O
 from tapnet_amd import synthetic, weights
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLIPS = ['tapir_nonsquare', 'bootstapir_multires']
+CLIPS = ['tapir_nonsquare', 'bootstapir_multires', 'batch2_chunked']
+ONLINE = ['causal_online', 'causal_update']
 
 
 def _load(name):
   g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', f'jax_{name}.npz')))
-  kw = dict(pyramid_level=int(g['pyramid_level']), extra_convs=bool(g['extra_convs']),
-            initial_resolution=tuple(int(v) for v in g['initial_resolution']),
-            use_causal_conv=bool(g['use_causal_conv']))
-  w = synthetic.make_weights(int(g['seed']), kw['pyramid_level'], kw['extra_convs'])
+  from oracle import make_jax_golden as gen       # the case table only; nothing of the reference is imported
+  c = gen.CASES[name]
+  kw = dict(c['kw'])
+  assert kw['pyramid_level'] == int(g['pyramid_level']) and int(g['seed']) == c['seed']
+  w = synthetic.make_weights(c['seed'], kw['pyramid_level'], kw['extra_convs'])
+  g['case'] = c
   return g, kw, w
 
 
 def _levels(g):
-  n = sum(1 for k in g if k.startswith('lowres_'))
+  n = sum(1 for k in g if k.startswith('lowres_') and k[7:].isdigit())
   return ([g[f'lowres_{i}'] for i in range(n)], [g[f'hires_{i}'] for i in range(n)],
           [tuple(int(v) for v in g[f'resolution_{i}']) for i in range(n)])
 
 
 def _features(w, extra, frames):
+  """Plain-PyTorch backbone restatement, frame by frame semantics (InstanceNorm: per frame)."""
   b, t, h, wd, _ = frames.shape
   lo, hi = backbone_torch.TorchBackbone(w, extra).features(torch.as_tensor(frames).reshape(-1, h, wd, 3))
   return lo.numpy().reshape(b, t, *lo.shape[1:]), hi.numpy().reshape(b, t, *hi.shape[1:])
@@ -69,24 +73,32 @@ def test_oracle_matches_the_jax_text(name):
     np.testing.assert_allclose(o, g['unrefined_occlusion'][i], atol=1e-4)
 
 
-def test_oracle_online_matches_the_jax_text():
-  """tapnet/live_demo.py:51-77 driven through the JAX text: features of frame 0, then one frame at a time."""
-  g, kw, w = _load('causal_online')
+@pytest.mark.parametrize('name', ONLINE)
+def test_oracle_online_matches_the_jax_text(name):
+  """tapnet/live_demo.py:51-77 driven through the JAX text: features of frame 0, then one frame at a time;
+  causal_update replaces two points mid-stream (update_query_features with the causal state, :1172-1203)."""
+  g, kw, w = _load(name)
+  c = g['case']
   video, qp = g['video'], g['query_points']
   res = O.generate_default_resolutions(video.shape[2:4], kw['initial_resolution'])
   res = [kw['initial_resolution']] + [tuple(r) for r in res]
   lo, hi = _features(w, kw['extra_convs'], video)
-  ql, qh = O.get_query_features([lo[:, :1]] * len(res), [hi[:, :1]] * len(res), res, qp, video[:, :1].shape)
-  np.testing.assert_allclose(ql[0], g['query_lowres_0'], atol=2e-5)
+  f1 = video[:, :1].shape
+  ql, qh = O.get_query_features([lo[:, :1]] * len(res), [hi[:, :1]] * len(res), res, qp, f1)
   state = O.construct_initial_causal_state(qp.shape[1], len(res) - 1)
   tr, oc, ex = [], [], []
   for t in range(video.shape[1]):
-    traj = O.estimate_trajectories(w, video.shape[2:4], [lo[:, t:t + 1]] * len(res), [hi[:, t:t + 1]] * len(res), res,
-                                   ql, qh, None, causal_context=state, get_causal_context=True,
-                                   pyramid_level=kw['pyramid_level'], softmax_temperature=20.0,
-                                   initial_resolution=kw['initial_resolution'], use_causal_conv=True)
+    lt, ht = [lo[:, t:t + 1]] * len(res), [hi[:, t:t + 1]] * len(res)
+    if t == c.get('update_frame', -1):
+      nl, nh = O.get_query_features(lt, ht, res, g['new_query_points'], f1)
+      ql, qh, state = O.update_query_features(ql, qh, nl, nh, c['update_idx'], state)
+    traj = O.estimate_trajectories(w, video.shape[2:4], lt, ht, res, ql, qh, None, causal_context=state,
+                                   get_causal_context=True, pyramid_level=kw['pyramid_level'],
+                                   softmax_temperature=20.0, initial_resolution=kw['initial_resolution'],
+                                   use_causal_conv=True)
     state = traj['causal_context']
     tr.append(traj['tracks'][-1]); oc.append(traj['occlusion'][-1]); ex.append(traj['expected_dist'][-1])
+  np.testing.assert_allclose(ql[0], g['query_lowres_0'], atol=2e-5)       # the query features after the updates
   np.testing.assert_allclose(np.concatenate(tr, 2), g['tracks'], atol=1e-3)
   np.testing.assert_allclose(np.concatenate(oc, 2), g['occlusion'], atol=1e-4)
   np.testing.assert_allclose(np.concatenate(ex, 2), g['expected_dist'], atol=1e-4)
@@ -116,7 +128,7 @@ def test_committed_goldens_regenerate_from_the_reference():
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'make_jax_golden.py'), '--check'],
                      capture_output=True, text=True, timeout=1200)
   assert r.returncode == 0, r.stdout + r.stderr
-  assert r.stdout.count('leaves match') == 3
+  assert r.stdout.count('leaves match') == 5
 
 
 # ----------------------------------------------------------------------------------------------- engine
@@ -149,8 +161,10 @@ def test_gpu_matches_the_jax_text(name):
 
 
 @pytest.mark.gpu
-def test_gpu_online_matches_the_jax_text():
-  g, kw, w = _load('causal_online')
+@pytest.mark.parametrize('name', ONLINE)
+def test_gpu_online_matches_the_jax_text(name):
+  g, kw, w = _load(name)
+  c = g['case']
   m = _model(kw, w)
   video, qp = g['video'], g['query_points']
   qf = m.get_query_features(video[:, :1], False, qp)
@@ -159,7 +173,10 @@ def test_gpu_online_matches_the_jax_text():
   tr, oc, ex = [], [], []
   for t in range(video.shape[1]):
     fg = m.get_feature_grids(video[:, t:t + 1], False)
-    traj = m.estimate_trajectories(video.shape[2:4], False, fg, qf, None, query_chunk_size=4,
+    if t == c.get('update_frame', -1):
+      new_qf = m.get_query_features(video[:, t:t + 1], False, g['new_query_points'], feature_grids=fg)
+      qf, state = m.update_query_features(qf, new_qf, tuple(c['update_idx']), state)
+    traj = m.estimate_trajectories(video.shape[2:4], False, fg, qf, None, query_chunk_size=c['chunk'],
                                    causal_context=state, get_causal_context=True)
     state = traj['causal_context']
     tr.append(_np(traj['tracks'][-1])); oc.append(_np(traj['occlusion'][-1]))
