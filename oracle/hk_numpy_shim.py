@@ -449,6 +449,9 @@ def install(params=None):
   img = types.ModuleType('jax.image')
   img.resize = _resize
   jax = types.ModuleType('jax')
+  jax.jit = lambda f, **k: f                       # tapnet/robotap/tapir_clustering.py:943-952
+  jax.custom_vjp = lambda f: f
+  jax.Array = np.ndarray
   jax.numpy, jax.nn, jax.lax, jax.scipy, jax.vmap, jax.random, jax.tree_util, jax.image = (
       jnp, nn, lax, jsp, vmap, rnd, tu, img)
   hk = types.ModuleType('haiku')
@@ -457,6 +460,10 @@ def install(params=None):
   hk.remat = lambda f: f
   hk.transform_with_state = Transformed
   hk.next_rng_key = lambda: np.array([0, 7], np.uint32)
+  hk.Params = hk.State = dict
+  hk.data_structures = types.ModuleType('haiku.data_structures')
+  hk.data_structures.tree_size = lambda t: sum(int(np.size(v)) for m in t.values() for v in m.values())
+  hk.data_structures.tree_bytes = lambda t: sum(int(np.asarray(v).nbytes) for m in t.values() for v in m.values())
   hk.experimental = types.ModuleType('haiku.experimental')
   hk.experimental.current_name = current_name
   for n in ('BatchNorm', 'MaxPool'):
@@ -468,6 +475,7 @@ def install(params=None):
   absl.logging = types.ModuleType('absl.logging')
   absl.logging.info = absl.logging.warning = lambda *a, **k: None
   optax = types.ModuleType('optax')
+  optax.OptState = object
   for name, mod in (('jax', jax), ('jax.numpy', jnp), ('jax.nn', nn), ('jax.lax', lax), ('jax.scipy', jsp),
                     ('jax.scipy.ndimage', jnd), ('jax.random', rnd), ('jax.tree_util', tu), ('jax.image', img),
                     ('haiku', hk), ('haiku.experimental', hk.experimental), ('chex', chex), ('absl', absl),

@@ -124,6 +124,49 @@ def run_case(name, c, ref, hk):
   return out
 
 
+ROBOTAP = dict(seed=36, videos=dict(a=3, b=2), HW=(48, 64), frame_stride=2, points_per_frame=2, point_batch_size=4)
+
+
+def robotap_videos():
+  from tapnet_amd import synthetic
+  c = ROBOTAP
+  return {k: np.round((synthetic.make_video(c['seed'] + i, t, *c['HW'])[0] + 1.0) * 127.5).astype(np.uint8)
+          for i, (k, t) in enumerate(c['videos'].items())}
+
+
+def robotap_checkpoint(path):
+  """A Haiku checkpoint FILE as tapnet/robotap/tapir_clustering.py:923-924 and tapnet/live_demo.py:31-33 read it:
+  np.load(path, allow_pickle=True).item() -> {'params', 'state'} (default TAPIR kwargs, causal)."""
+  from tapnet_amd import synthetic, weights
+  params = weights.torch_to_haiku_names(synthetic.make_weights(ROBOTAP['seed'], 1, False))
+  np.save(path, {'params': params, 'state': {}}, allow_pickle=True)
+
+
+def run_robotap():
+  """tapnet/robotap/tapir_clustering.py:1023-1179 track_many_points, the reference's own driver: build_models
+  (checkpoint file -> hk.transform_with_state -> jit), np.random.seed(42) sampling, per-frame init calls, batches of
+  point_batch_size with the last one padded, every batch streamed through every video from a zero causal state."""
+  import tempfile
+  from tapnet.robotap import tapir_clustering as rc
+  c = ROBOTAP
+  videos = robotap_videos()
+  t0 = time.time()
+  with tempfile.TemporaryDirectory() as d:
+    path = os.path.join(d, 'causal_tapir_checkpoint.npy')
+    robotap_checkpoint(path)
+    res = rc.track_many_points(videos, list(videos), path, frame_stride=c['frame_stride'],
+                               points_per_frame=c['points_per_frame'], point_batch_size=c['point_batch_size'])
+  print(f'[robotap] reference run {time.time() - t0:.0f} s', flush=True)
+  out = {}
+  for k in videos:
+    out[f'tracks_{k}'] = np.asarray(res['separation_tracks'][k], np.float32)
+    out[f'visibility_{k}'] = np.asarray(res['separation_visibility'][k])
+  for i, a in enumerate(res['query_points']):
+    out[f'query_points_{i}'] = np.asarray(a, np.float64)
+  out['query_lowres_0'] = np.asarray(res['query_features'].lowres[0], np.float32)
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('cases', nargs='*', default=[])
@@ -135,8 +178,8 @@ def main():
     sys.path.insert(0, REFERENCE_ROOT)
   import haiku as hk                                  # the stand-in
   from tapnet.models import tapir_model as ref        # the reference, imported over the stand-ins
-  for name in (a.cases or list(CASES)):
-    out = run_case(name, CASES[name], ref, hk)
+  for name in (a.cases or list(CASES) + ['robotap']):
+    out = run_robotap() if name == 'robotap' else run_case(name, CASES[name], ref, hk)
     path = os.path.join(GOLDEN, f'jax_{name}.npz')
     if a.check:
       old = np.load(path)

@@ -124,11 +124,15 @@ def test_haiku_tree_round_trip(pyr, extra):
 @pytest.mark.skipif(not ref_import.reference_available(), reason='reference tree not present')
 def test_committed_goldens_regenerate_from_the_reference():
   """Re-runs the reference's JAX text over the stand-ins in a subprocess (they shadow `jax` in sys.modules);
-  this is also where the Haiku tree of the converter is held to the tree the reference's modules create."""
-  r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'make_jax_golden.py'), '--check'],
-                     capture_output=True, text=True, timeout=1200)
+  this is also where the Haiku tree of the converter is held to the tree the reference's modules create.
+  Two cases by default (25 s); TAPNET_FULL_REGEN=1 re-runs all of them and the robotap driver (2.5 min)."""
+  full = os.environ.get('TAPNET_FULL_REGEN') == '1'
+  cases = [] if full else ['tapir_nonsquare', 'causal_online']
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'make_jax_golden.py'), '--check'] + cases,
+                     capture_output=True, text=True, timeout=1800)
   assert r.returncode == 0, r.stdout + r.stderr
-  assert r.stdout.count('leaves match') == 5
+  assert r.stdout.count('leaves match') == (5 if full else 2)
+  assert not full or '[robotap] max' in r.stdout
 
 
 # ----------------------------------------------------------------------------------------------- engine
@@ -186,3 +190,51 @@ def test_gpu_online_matches_the_jax_text(name):
   np.testing.assert_allclose(np.concatenate(ex, 2), g['expected_dist'], atol=1e-3)
   np.testing.assert_allclose(_np(state[-1]['tapir/~/pips_mlp_mixer/block_11_causal_2']),
                              g['state_block_11_causal_2'], atol=1e-3)
+
+
+# ------------------------------------------------------------------------- robotap bulk tracking (8f row 3)
+def _robotap():
+  from oracle import make_jax_golden as gen
+  return gen, dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'jax_robotap.npz')))
+
+
+def test_bulk_sampling_and_checkpoint_file_match_the_reference_driver(tmp_path):
+  """tests/golden/jax_robotap.npz = the reference's OWN track_many_points (tapir_clustering.py:1023-1179) run over
+  the stand-ins on a Haiku checkpoint FILE: the sampled query points of tapnet_amd.bulk_tracking (draw order of
+  np.random.seed(42)) and the .npy reader of tapnet_amd.weights on the same file."""
+  from tapnet_amd import bulk_tracking as bt
+  gen, g = _robotap()
+  c = gen.ROBOTAP
+  videos = gen.robotap_videos()
+  s = bt.sample_query_points([v.shape for v in videos.values()], c['frame_stride'], c['points_per_frame'])
+  np.testing.assert_array_equal(np.concatenate([np.full(len(yx), v) for v, _, yx in s]), g['query_points_0'])
+  np.testing.assert_array_equal(np.concatenate([np.full(len(yx), i) for _, i, yx in s]), g['query_points_1'])
+  np.testing.assert_allclose(np.concatenate([yx for _, _, yx in s]), g['query_points_2'], atol=1e-12)
+  path = str(tmp_path / 'causal_tapir_checkpoint.npy')
+  gen.robotap_checkpoint(path)
+  w = weights.load_checkpoint(path)
+  ref = synthetic.make_weights(c['seed'], 1, False)
+  assert set(w) == set(ref)
+  for k in ref:
+    np.testing.assert_array_equal(w[k], ref[k])
+
+
+@pytest.mark.gpu
+def test_gpu_track_many_points_matches_the_reference_driver(tmp_path):
+  from tapnet_amd import bulk_tracking as bt
+  from tapnet_amd import tapir_model
+  gen, g = _robotap()
+  c = gen.ROBOTAP
+  videos = gen.robotap_videos()
+  path = str(tmp_path / 'causal_tapir_checkpoint.npy')
+  gen.robotap_checkpoint(path)
+  model = tapir_model.TAPIR(use_causal_conv=True, weights=weights.load_checkpoint(path), device='cuda:0')
+  res = bt.track_many_points(videos, list(videos), model, frame_stride=c['frame_stride'],
+                             points_per_frame=c['points_per_frame'], point_batch_size=c['point_batch_size'])
+  np.testing.assert_allclose(res['query_features'].lowres[0], g['query_lowres_0'], atol=5e-4)
+  for k in videos:
+    assert res['separation_tracks'][k].shape == g[f'tracks_{k}'].shape
+    np.testing.assert_allclose(res['separation_tracks'][k], g[f'tracks_{k}'], atol=2e-3)
+    assert np.mean(res['separation_visibility'][k] == g[f'visibility_{k}']) == 1.0
+  for i in range(3):
+    np.testing.assert_allclose(res['query_points'][i], g[f'query_points_{i}'], atol=1e-12)
