@@ -320,7 +320,8 @@ int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
  * with >= 128 tracks, separate launches otherwise), 1 = always separate
  * launches (token-mixing kernel + tiled GEMMs), 2 = always the fused kernel, 3 = always its wide form
  * (bf16: two tracks or one 49..96-frame track per workgroup) (TAPIR_ERR_UNSUPPORTED where they do
- * not apply; automatic: wide above 256 tracks and for clips of 49..96 frames).  Both are HIP paths; tests and tools/kbench.py A/B them. */
+ * not apply; automatic: wide above 256 tracks and for clips of 49..96 frames).  Both are HIP paths; tests and tools/kbench.py A/B them.
+ * -DTAPIR_EXPERIMENTS builds add 4 (timing-only pair simulation) and 5 (the half-CU kernel, mixer_fused_half.hpp). */
 int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
 /* Cost-volume stage (tapir_tracks_from_cost_volume and the first stage of
  * tapir_estimate_trajectories): 0 = automatic (ONE kernel -- einsum on the matrix cores into LDS +

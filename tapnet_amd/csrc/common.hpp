@@ -260,6 +260,12 @@ inline LaunchTimer& launch_timer() { static thread_local LaunchTimer t; return t
 
 }  // namespace tapir
 
+// occupancy the register allocator has to respect (waves per SIMD); nothing for the host emulator
+#ifdef TAPIR_HIPEMU
+#define TAPIR_WAVES_PER_EU(lo, hi)
+#else
+#define TAPIR_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 #ifdef TAPIR_HIPEMU
 #define TAPIR_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #else

@@ -21,6 +21,9 @@
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
 #include "mixer_fused_wide.hpp"
+#ifdef TAPIR_EXPERIMENTS
+#include "mixer_fused_half.hpp"   // measured and not adopted: experiments builds only
+#endif
 #include "pips.hpp"
 
 using namespace tapir;
@@ -69,8 +72,11 @@ struct tapir_ctx {
   // track-resident fused mixer (mixer_fused.hpp): per-wave A-fragment streams + per-block vectors
   uint4* fused_stream = nullptr; long fused_fpw = 0;
   uint4* fused_wide_stream = nullptr; long fused_wide_fpw = 0;   // bf16: the 6-tile kernel's chunking (mixer_fused_wide.hpp)
+  uint4* fused_half_stream = nullptr; long fused_half_fpw = 0;   // bf16: the 4-wave kernel's packing (mixer_fused_half.hpp)
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
+  int half_skew_div = 0;                          // half-CU kernel: start skew of every other group of this many workgroups (TAPIR_HALF_SKEW_DIV; measured: no gain)
+  int half_min_tracks = 0;                        // auto mode: half-CU kernel from this many tracks on (0: never); TAPIR_HALF_MIN_TRACKS
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
@@ -383,6 +389,60 @@ int build_fused_wide_weights(tapir_ctx* c) {
   return TAPIR_OK;
 }
 
+#ifdef TAPIR_EXPERIMENTS
+// the same matrices for the half-CU kernel (mixer_fused_half.hpp): FOUR wave streams, a wave owns 128 output rows
+// (8 row tiles per k-step), chunks of 128 hidden units in the pipelined order U0 U1 D0 U2 D1 ... D15
+int build_fused_half_weights(tapir_ctx* c) {
+  typedef bf16_t TA;
+  const int nb = c->cfg.num_mixer_blocks;
+  const long fpw = fused_half_frags_per_wave(c->k0_pad, nb);
+  std::vector<uint8_t> host((size_t)FMH_WAVES * fpw * 1024, 0);
+  const std::string mx = "torch_pips_mixer.";
+  const HostTensor *w0, *wout;
+  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
+  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
+  constexpr int HC = FMH_HC, RAU = FMH_RAU, NC = FMH_NC, QA = FMH_QA, RW = kHidden / FMH_WAVES;
+  for (int w = 0; w < FMH_WAVES; ++w) {
+    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
+    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
+      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
+      q += 1024;
+    };
+    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
+      for (int a = 0; a < QA; ++a) put(w0, kHidden, c->in_dim, RW * w + 16 * a, ks * 32);
+    for (int b = 0; b < nb; ++b) {
+      const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
+      const HostTensor *wup, *wdn;
+      TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup));
+      TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn));
+      auto put_up = [&](int hc) {
+        for (int ks = 0; ks < kHidden / 32; ++ks)
+          for (int a = 0; a < RAU; ++a) put(wup, kHidden4, kHidden, hc * HC + w * (HC / FMH_WAVES) + 16 * a, ks * 32);
+      };
+      auto put_dn = [&](int hc) {
+        for (int ks = 0; ks < HC / 32; ++ks)
+          for (int a = 0; a < QA; ++a) put(wdn, kHidden, kHidden4, RW * w + 16 * a, hc * HC + ks * 32);
+      };
+      put_up(0);
+      for (int hc = 1; hc < NC; ++hc) { put_up(hc); put_dn(hc - 1); }
+      put_dn(NC - 1);
+    }
+    for (int ks = 0; ks < kHidden / 32; ++ks)
+      for (int a = 0; a < QA; ++a) put(wout, kMixOut, kHidden, RW * w + 16 * a, ks * 32);
+    if (q + (size_t)FMH_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
+      return fail(c, TAPIR_ERR_WEIGHTS, "half fused stream layout mismatch");
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  c->fused_half_stream = (uint4*)d;
+  c->fused_half_fpw = fpw;
+  return TAPIR_OK;
+}
+
+#endif
+
 // ----------------------------------------------------------------------------
 // small helper kernels
 // ----------------------------------------------------------------------------
@@ -570,13 +630,22 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
     bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
                 fused_wide_supported(T, c->k0_pad, causal, has_ctx);
+    // half-CU form (bf16): one track per 4-wave workgroup, two workgroups per CU (17..48 frames)
+#ifdef TAPIR_EXPERIMENTS
+    bool half = sizeof(TA) == 2 && c->fused_half_stream != nullptr && fused_half_supported(T, c->k0_pad, causal, has_ctx);
+#else
+    bool half = false;
+#endif
+    if (c->mixer_mode == 5 && !half)
+      return fail(c, TAPIR_ERR_UNSUPPORTED, "half-CU fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 2 && !fused)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 3 && !wide)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
-    if (c->mixer_mode == 1) fused = wide = false;
-    if (c->mixer_mode == 2) wide = false;
-    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
+    if (c->mixer_mode == 1) fused = wide = half = false;
+    if (c->mixer_mode == 2) wide = half = false;
+    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = half = false;
+    if (c->mixer_mode == 5) fused = wide = false;
     if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
@@ -584,24 +653,32 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       // split-K GEMMs on all rows are faster than a mostly idle chip
       if (fused) fused = N >= 128 && R >= 4096;
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
-      if (wide) fused = false;
+      // two independent tracks per CU beat two tracks in one workgroup (TAPIR_HALF_MIN_TRACKS; 0 = never)
+      if (half) half = c->half_min_tracks > 0 && N >= c->half_min_tracks && T <= 48;
+      if (half) wide = false;
+      if (wide || half) fused = false;
     }
-    if (fused || wide) {
+    if (fused || wide || half) {
       TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
       FusedArgs fa{};
       fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
-      fa.stream = wide ? c->fused_wide_stream : c->fused_stream;
-      fa.frags_per_wave = wide ? c->fused_wide_fpw : c->fused_fpw;
+      fa.stream = half ? c->fused_half_stream : wide ? c->fused_wide_stream : c->fused_stream;
+      fa.frags_per_wave = half ? c->fused_half_fpw : wide ? c->fused_wide_fpw : c->fused_fpw;
       fa.b0 = c->b0; fa.nblocks = nb;
       for (int i = 0; i < nb; ++i) fa.blocks[i] = c->fused_blocks[i];
       fa.dbg_times = (long long*)c->dbg_times;
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
+      fa.skew_div = half ? c->half_skew_div : 0;
       if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim) {
         fa.fuse_update = 1; fa.upd = *upd; *upd_done = true;
       }
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
+#ifdef TAPIR_EXPERIMENTS
+      if (half) launch_mixer_fused_half(fa, s);
+      else
+#endif
       if (wide) launch_mixer_fused_wide(fa, s);
       else launch_mixer_fused<TA>(fa, s);
       return TAPIR_OK;
@@ -925,6 +1002,8 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   // (same-box A/B of builds from outside the process: tools/ab_env.sh)
   if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_HALF_MIN_TRACKS")) c->half_min_tracks = atoi(e);
+  if (const char* e = getenv("TAPIR_HALF_SKEW_DIV")) c->half_skew_div = atoi(e);
   *out = c;
   return TAPIR_OK;
 }
@@ -972,6 +1051,7 @@ int tapir_finalize_weights(tapir_ctx* c) {
   c->tapnet_ready = false; c->tapir_ready = false;
   c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
   c->fused_wide_stream = nullptr; c->fused_wide_fpw = 0;
+  c->fused_half_stream = nullptr; c->fused_half_fpw = 0;
   const bool has_tapnet = c->host_w.count("tapnet_cost_volume_track_mods.hid1.weight") != 0;
   bool has_tapir = !has_tapnet;   // a context without TAP-Net head weights must be a complete TAPIR
   for (const auto& kv : c->host_w)
@@ -1018,7 +1098,12 @@ static int finalize_tapir(tapir_ctx* c) {
     c->blocks.push_back(b);
   }
   if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
-    if (c->cfg.dtype == TAPIR_BF16) { TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c)); }
+    if (c->cfg.dtype == TAPIR_BF16) {
+      TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c));
+#ifdef TAPIR_EXPERIMENTS
+      TRY(build_fused_half_weights(c));
+#endif
+    }
     else TRY(build_fused_weights<float>(c));
   }
   return TAPIR_OK;
@@ -1492,12 +1577,11 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 }
 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
+  bool ok = mode >= 0 && mode <= 3;
 #ifdef TAPIR_EXPERIMENTS
-  const int max_mode = 4;   // 4: timing-only pair simulation of the wide kernel (tools/kbench.py)
-#else
-  const int max_mode = 3;
+  ok = ok || mode == 4 || mode == 5;   // 4: timing-only pair simulation of the wide kernel; 5: the half-CU kernel
 #endif
-  if (!c || mode < 0 || mode > max_mode) return TAPIR_ERR_INVALID;
+  if (!c || !ok) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
   return TAPIR_OK;
 }
