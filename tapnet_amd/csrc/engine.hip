@@ -23,6 +23,7 @@
 #include "mixer_fused_wide.hpp"
 #ifdef TAPIR_EXPERIMENTS
 #include "mixer_fused_half.hpp"   // measured and not adopted: experiments builds only
+#include "mixer_fused_x16.hpp"
 #endif
 #include "pips.hpp"
 
@@ -72,6 +73,7 @@ struct tapir_ctx {
   // track-resident fused mixer (mixer_fused.hpp): per-wave A-fragment streams + per-block vectors
   uint4* fused_stream = nullptr; long fused_fpw = 0;
   uint4* fused_wide_stream = nullptr; long fused_wide_fpw = 0;   // bf16: the 6-tile kernel's chunking (mixer_fused_wide.hpp)
+  uint4* fused16_stream = nullptr; long fused16_fpw = 0;         // bf16: sixteen wave streams (mixer_fused_x16.hpp)
   uint4* fused_half_stream = nullptr; long fused_half_fpw = 0;   // bf16: the 4-wave kernel's packing (mixer_fused_half.hpp)
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
@@ -390,6 +392,59 @@ int build_fused_wide_weights(tapir_ctx* c) {
 }
 
 #ifdef TAPIR_EXPERIMENTS
+// the 8-wave kernel's stream order (U0 U1 D0 U2 D1 ... per block, chunks of 512 hidden units) for SIXTEEN waves:
+// a wave owns 32 output rows (2 row tiles per k-step) and 32 hidden rows per chunk
+int build_fused16_weights(tapir_ctx* c) {
+  typedef bf16_t TA;
+  const int nb = c->cfg.num_mixer_blocks;
+  const long fpw = fused16_frags_per_wave(c->k0_pad, nb);
+  std::vector<uint8_t> host((size_t)FX_WAVES * fpw * 1024, 0);
+  const std::string mx = "torch_pips_mixer.";
+  const HostTensor *w0, *wout;
+  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
+  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
+  constexpr int HC = 512, RAU = HC / FX_WAVES / 16, NC = kHidden4 / HC, QA = FX_QA, RW = kHidden / FX_WAVES;
+  for (int w = 0; w < FX_WAVES; ++w) {
+    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
+    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
+      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
+      q += 1024;
+    };
+    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
+      for (int a = 0; a < QA; ++a) put(w0, kHidden, c->in_dim, RW * w + 16 * a, ks * 32);
+    for (int b = 0; b < nb; ++b) {
+      const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
+      const HostTensor *wup, *wdn;
+      TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup));
+      TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn));
+      auto put_up = [&](int hc) {
+        for (int ks = 0; ks < kHidden / 32; ++ks)
+          for (int a = 0; a < RAU; ++a) put(wup, kHidden4, kHidden, hc * HC + w * (HC / FX_WAVES) + 16 * a, ks * 32);
+      };
+      auto put_dn = [&](int hc) {
+        for (int ks = 0; ks < HC / 32; ++ks)
+          for (int a = 0; a < QA; ++a) put(wdn, kHidden, kHidden4, RW * w + 16 * a, hc * HC + ks * 32);
+      };
+      put_up(0);
+      for (int hc = 1; hc < NC; ++hc) { put_up(hc); put_dn(hc - 1); }
+      put_dn(NC - 1);
+    }
+    for (int ks = 0; ks < kHidden / 32; ++ks)
+      for (int a = 0; a < QA; ++a) put(wout, kMixOut, kHidden, RW * w + 16 * a, ks * 32);
+    if (q + (size_t)FX_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
+      return fail(c, TAPIR_ERR_WEIGHTS, "16-wave fused stream layout mismatch");
+  }
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  c->fused16_stream = (uint4*)d;
+  c->fused16_fpw = fpw;
+  return TAPIR_OK;
+}
+#endif
+
+#ifdef TAPIR_EXPERIMENTS
 // the same matrices for the half-CU kernel (mixer_fused_half.hpp): FOUR wave streams, a wave owns 128 output rows
 // (8 row tiles per k-step), chunks of 128 hidden units in the pipelined order U0 U1 D0 U2 D1 ... D15
 int build_fused_half_weights(tapir_ctx* c) {
@@ -633,8 +688,11 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     // half-CU form (bf16): one track per 4-wave workgroup, two workgroups per CU (17..48 frames)
 #ifdef TAPIR_EXPERIMENTS
     bool half = sizeof(TA) == 2 && c->fused_half_stream != nullptr && fused_half_supported(T, c->k0_pad, causal, has_ctx);
+    bool x16 = sizeof(TA) == 2 && c->fused16_stream != nullptr && fused16_supported(T, c->k0_pad, causal, has_ctx);
+    if (c->mixer_mode == 6 && !x16)
+      return fail(c, TAPIR_ERR_UNSUPPORTED, "16-wave fused mixer forced, but it does not cover this shape");
 #else
-    bool half = false;
+    bool half = false, x16 = false;
 #endif
     if (c->mixer_mode == 5 && !half)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "half-CU fused mixer forced, but it does not cover this shape");
@@ -646,6 +704,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     if (c->mixer_mode == 2) wide = half = false;
     if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = half = false;
     if (c->mixer_mode == 5) fused = wide = false;
+    if (c->mixer_mode == 6) fused = wide = half = false; else x16 = false;
     if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
@@ -658,12 +717,12 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       if (half) wide = false;
       if (wide || half) fused = false;
     }
-    if (fused || wide || half) {
+    if (fused || wide || half || x16) {
       TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
       FusedArgs fa{};
       fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
-      fa.stream = half ? c->fused_half_stream : wide ? c->fused_wide_stream : c->fused_stream;
-      fa.frags_per_wave = half ? c->fused_half_fpw : wide ? c->fused_wide_fpw : c->fused_fpw;
+      fa.stream = x16 ? c->fused16_stream : half ? c->fused_half_stream : wide ? c->fused_wide_stream : c->fused_stream;
+      fa.frags_per_wave = x16 ? c->fused16_fpw : half ? c->fused_half_fpw : wide ? c->fused_wide_fpw : c->fused_fpw;
       fa.b0 = c->b0; fa.nblocks = nb;
       for (int i = 0; i < nb; ++i) fa.blocks[i] = c->fused_blocks[i];
       fa.dbg_times = (long long*)c->dbg_times;
@@ -676,7 +735,8 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       }
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
 #ifdef TAPIR_EXPERIMENTS
-      if (half) launch_mixer_fused_half(fa, s);
+      if (x16) launch_mixer_fused16(fa, s);
+      else if (half) launch_mixer_fused_half(fa, s);
       else
 #endif
       if (wide) launch_mixer_fused_wide(fa, s);
@@ -1052,6 +1112,7 @@ int tapir_finalize_weights(tapir_ctx* c) {
   c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
   c->fused_wide_stream = nullptr; c->fused_wide_fpw = 0;
   c->fused_half_stream = nullptr; c->fused_half_fpw = 0;
+  c->fused16_stream = nullptr; c->fused16_fpw = 0;
   const bool has_tapnet = c->host_w.count("tapnet_cost_volume_track_mods.hid1.weight") != 0;
   bool has_tapir = !has_tapnet;   // a context without TAP-Net head weights must be a complete TAPIR
   for (const auto& kv : c->host_w)
@@ -1102,6 +1163,7 @@ static int finalize_tapir(tapir_ctx* c) {
       TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c));
 #ifdef TAPIR_EXPERIMENTS
       TRY(build_fused_half_weights(c));
+      TRY(build_fused16_weights(c));
 #endif
     }
     else TRY(build_fused_weights<float>(c));
@@ -1579,7 +1641,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
   bool ok = mode >= 0 && mode <= 3;
 #ifdef TAPIR_EXPERIMENTS
-  ok = ok || mode == 4 || mode == 5;   // 4: timing-only pair simulation of the wide kernel; 5: the half-CU kernel
+  ok = ok || (mode >= 4 && mode <= 6);   // 4: timing-only pair simulation of the wide kernel; 5: the half-CU kernel; 6: 16 waves
 #endif
   if (!c || !ok) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;

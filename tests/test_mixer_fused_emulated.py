@@ -112,6 +112,20 @@ def test_half_cu_fused_mixer_bf16(T, N):
   e.close()
 
 
+@pytest.mark.parametrize('T,N', [(48, 2), (40, 1)])
+def test_sixteen_wave_fused_mixer_bf16(T, N):
+  """16-wave form (mixer_fused_x16.hpp, mode 6, experiments builds): a wave owns 32 channels, four waves per SIMD,
+  sixteen weight streams with a 4-deep ring, LayerNorm summaries inside the activation region."""
+  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
+  x = np.random.default_rng(T + N).standard_normal((N, T, 535)).astype(np.float32)
+  x16 = _mixer(e, x, 6)
+  ref16, _ = O.pips_mlp_mixer(w, x, num_blocks=2, rnd=O.bf16_round)
+  d = np.abs(x16 - ref16)
+  assert np.isfinite(x16).all() and d.max() < 4e-3 and np.median(d) < 1e-4, (d.max(), np.median(d))
+  e.close()
+
+
 def test_wide_fused_mixer_needs_bf16():
   w = synthetic.make_weights(3, 1, False, num_mixer_blocks=1, backbone=False)
   e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64))   # f32 build
