@@ -100,7 +100,8 @@ int tapir_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, const floa
                                   float* points, float* occlusion, float* expected_dist,
                                   void* stream);
 
-/* TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171), num_heads = 1: the TAPIR
+/* TAPNet.tracks_from_cost_volume (tapnet/models/tapnet_model.py:111-171), num_heads 1, 2 or 4 (= the input
+ * channels of hid1.weight [16,num_heads,3,3]; channel c of the features belongs to head c % num_heads): the TAPIR
  * head kernel with the TAP-Net differences (no ReLU after the stride-2 convolution, ONE occlusion
  * logit, softmax temperature 10).  Needs the head's weights under the names
  * "tapnet_cost_volume_track_mods.{hid1,hid2,hid3,hid4,occ_out}.{weight,bias}" (torch layout of the

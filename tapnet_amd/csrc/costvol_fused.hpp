@@ -64,9 +64,33 @@ __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <typename TA, bool TRACE = false>
+// Channels of head hd among the EPC elements of a 16-byte chunk: channel = chunk * EPC + e, head = channel % HEADS =
+// e % HEADS (EPC is a multiple of HEADS): keeps element e of every chunk where e % HEADS == hd.
+template <typename TA, int HEADS>
+__device__ __forceinline__ uint4 keep_head(uint4 v, int hd) {
+  if (HEADS == 1) return v;
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (sizeof(TA) == 2) {                       // word k = elements 2 k (low half), 2 k + 1 (high half)
+      const unsigned lo = ((2 * k) % HEADS == hd) ? 0x0000ffffu : 0u;
+      const unsigned hi = ((2 * k + 1) % HEADS == hd) ? 0xffff0000u : 0u;
+      w[k] &= lo | hi;
+    } else {                                     // word k = element k
+      w[k] = (k % HEADS == hd) ? w[k] : 0u;
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// HEADS > 1: TAP-Net's num_heads (tapnet_model.py:247-254, 145-149): channel c of the features belongs to head
+// c % HEADS, every head's cost map is one input channel of hid1.  A tile holds QPW / HEADS queries x HEADS maps
+// (map index = query * HEADS + head: the query features with the other heads' channels zeroed).
+template <typename TA, bool TRACE = false, int HEADS = 1>
 __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   constexpr int QPW = CvFusedCfg<TA>::QPW;
+  constexpr int QPT = QPW / HEADS;                   // queries per tile
+  static_assert(QPW % HEADS == 0 && (16 / (int)sizeof(TA)) % HEADS == 0, "heads");
   constexpr int EPC = 16 / (int)sizeof(TA);          // elements per 16-byte chunk
   constexpr int KCH = kLowresDim / EPC / 4;          // chunk-steps over K = 256 (4 chunks per step)
   constexpr bool BF = sizeof(TA) == 2;
@@ -84,7 +108,7 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   const int c = lane & 15, g = lane >> 4;
   const int h = a.h, w = a.w, hw = h * w;
   const int pw = w + 2, pn = pw * (h + 2);
-  const int qtiles = (a.Q + QPW - 1) / QPW;
+  const int qtiles = (a.Q + QPT - 1) / QPT;
   // Consecutive workgroup ids go round the 8 XCDs (each with its own L2): XCD x takes the x-th CONTIGUOUS
   // eighth of the (frame, query tile) units, i.e. all query tiles of its frames -- a frame's grid (512 KiB)
   // comes into ONE L2 once.  (In launch order the 16 tiles of a frame landed on all eight XCDs: 202 MB
@@ -97,8 +121,8 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   const long frame = unit / qtiles;                  // b * T + t
   const int t = (int)(frame % a.T);
   const long b = frame / a.T;
-  const int q0 = qt * QPW;
-  const int nq = min(QPW, a.Q - q0);                 // valid queries of this tile
+  const int q0 = qt * QPT;
+  const int nq = min(QPT, a.Q - q0);                 // valid queries of this tile
 
   // TRACE (tools/kbench.py --what cvtrace): shader cycles per phase, wave 0 of every workgroup
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -122,12 +146,12 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
 
   // ---- G: cost maps.  B operand: lane (query c, chunk group g) holds chunks 4 s + g of its row.
   {
-    const int qrow = min(q0 + (c < QPW ? c : 0), a.Q - 1);
+    const int qrow = min(q0 + (c < QPW ? c / HEADS : 0), a.Q - 1);
     const uint4* qsrc = reinterpret_cast<const uint4*>(
         reinterpret_cast<const TA*>(a.qfeat) + (b * a.Q + qrow) * kLowresDim);
     uint4 fq[KCH];
 #pragma unroll
-    for (int s = 0; s < KCH; ++s) fq[s] = qsrc[4 * s + g];
+    for (int s = 0; s < KCH; ++s) fq[s] = keep_head<TA, HEADS>(qsrc[4 * s + g], c % HEADS);
     const TA* gbase = reinterpret_cast<const TA*>(a.grid) + frame * (long)hw * kLowresDim;
     const int ntile = (hw + 15) / 16;
     lds_barrier();   // zero fill done before the first cost values land
@@ -142,8 +166,8 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KCH; ++s) MfmaStep<TA>::run(f[s], fq[s], acc);
-      // D: lane holds cells it*16 + 4 g + r of query c
-      if (c < nq) {
+      // D: lane holds cells it*16 + 4 g + r of map c (= query c / HEADS, head c % HEADS)
+      if (c < nq * HEADS) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int p = it * 16 + 4 * g + r;
@@ -168,12 +192,13 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   // ---- per-lane constants of the two small convolutions (exact-f32 MFMA operands)
   //   conv 1: A1[ch = c][k-slot g] of MFMA j = W1[c][tap 4 j + g]          (taps >= 9: 0)
   //   conv 2: A2[tap = c][k-slot g] of MFMA j = W2[ch 4 g + j][tap c]      (taps >= 9: 0)
-  float a1[3], a2[4];
+  float a1[HEADS][3], a2[4];     // W1 is [16][HEADS][3][3]
   int off1[3];   // LDS offset of tap 4 j + g relative to the pixel's halo index
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int tap = 4 * j + g;
-    a1[j] = tap < 9 ? a.wt.w1[c * 9 + tap] : 0.f;
+#pragma unroll
+    for (int hd = 0; hd < HEADS; ++hd) a1[hd][j] = tap < 9 ? a.wt.w1[(c * HEADS + hd) * 9 + tap] : 0.f;
     const int tc = min(tap, 8);
     off1[j] = (tc / 3 - 1) * pw + (tc % 3 - 1);
   }
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
   for (int m = 0; m < nq; ++m) {
     lds_barrier();   // cost maps complete (m = 0) / previous map's readers of s_h1, s_p done
     tick(1);
-    const float* cm = s_cm[m];
+    const float* cm = s_cm[m * HEADS];                 // head hd of this query: cm + hd * CVF_PAD
     // ---- M1: hid1 = relu(conv1(cm) + b1) -> s_h1, P = per-tap contraction of hid1 with W2 -> s_p
     // two pixel tiles at a time: the MFMAs of a tile form dependent chains (40-cycle latency each)
 #pragma unroll
@@ -225,10 +250,12 @@ __global__ __launch_bounds__(CVF_THREADS) void cv_fused_kernel(CvFusedArgs a) {
         const int h0 = thidx[k], h1 = thidx[k + 1 < TPW ? k + 1 : k];
         f32x4 d1a = b1v, d1b = b1v;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          d1a = mfma_f32(a1[j], cm[h0 + off1[j]], d1a);
-          d1b = mfma_f32(a1[j], cm[h1 + off1[j]], d1b);
-        }
+        for (int hd = 0; hd < HEADS; ++hd)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            d1a = mfma_f32(a1[hd][j], cm[hd * CVF_PAD + h0 + off1[j]], d1a);
+            d1b = mfma_f32(a1[hd][j], cm[hd * CVF_PAD + h1 + off1[j]], d1b);
+          }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { d1a[r] = fmaxf(d1a[r], 0.f); d1b[r] = fmaxf(d1b[r], 0.f); }
         f32x4 d2a = f32x4{0.f, 0.f, 0.f, 0.f}, d2b = d2a;
@@ -412,8 +439,17 @@ inline bool cv_fused_supported(int h, int w) {
 }
 
 template <typename TA>
-inline void launch_cv_fused(const CvFusedArgs& a, hipStream_t s) {
-  const int qtiles = (a.Q + CvFusedCfg<TA>::QPW - 1) / CvFusedCfg<TA>::QPW;
+inline void launch_cv_fused(const CvFusedArgs& a, hipStream_t s, int heads = 1) {
+  const int qpt = CvFusedCfg<TA>::QPW / heads;
+  const int qtiles = (a.Q + qpt - 1) / qpt;
+  if (heads == 2) {
+    TAPIR_LAUNCH((cv_fused_kernel<TA, false, 2>), dim3((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), dim3(CVF_THREADS), s, a);
+    return;
+  }
+  if (heads == 4) {
+    TAPIR_LAUNCH((cv_fused_kernel<TA, false, 4>), dim3((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), dim3(CVF_THREADS), s, a);
+    return;
+  }
 #ifdef TAPIR_EXPERIMENTS
   if (a.dbg_times != nullptr) {
     hipLaunchKernelGGL((cv_fused_kernel<TA, true>), dim3((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), dim3(CVF_THREADS), 0, s, a);

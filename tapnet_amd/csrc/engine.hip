@@ -63,6 +63,7 @@ struct tapir_ctx {
   CvHeadWeights cvw;
   CvHeadWeights tapnet_cvw;          // TAP-Net head (tapnet_model.py:64-107), uploaded when its weights are set
   bool tapnet_ready = false;
+  int tapnet_heads = 1;              // num_heads of the TAP-Net head: input channels of its hid1
   bool tapir_ready = false;          // the TAPIR weights (heads + mixer) are uploaded
   // mixer weights
   int in_dim = 0, k0_pad = 0;       // 388 + 49*(2+pyr), padded to the GEMM k-step
@@ -203,10 +204,10 @@ int get_w(tapir_ctx* c, const std::string& name, std::vector<int64_t> shape, con
 
 // uploads one cost-volume head (TAPIR: tapir_model.py:342-361, n_out = 2; TAP-Net:
 // tapnet_model.py:64-107, n_out = 1) from the host tensors named prefix + {hid1..occ_out}
-int upload_cv_head(tapir_ctx* c, const std::string& cv, int n_out, CvHeadWeights* out) {
+int upload_cv_head(tapir_ctx* c, const std::string& cv, int n_out, CvHeadWeights* out, int heads = 1) {
   const HostTensor* t;
   float* tmp;
-  TRY(get_w(c, cv + "hid1.weight", {16, 1, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); out->w1 = tmp;
+  TRY(get_w(c, cv + "hid1.weight", {16, heads, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), (size_t)144 * heads, &tmp)); out->w1 = tmp;
   TRY(get_w(c, cv + "hid1.bias", {16}, &t)); TRY(upload_f32(c, t->data.data(), 16, &tmp)); out->b1 = tmp;
   TRY(get_w(c, cv + "hid2.weight", {1, 16, 3, 3}, &t)); TRY(upload_f32(c, t->data.data(), 144, &tmp)); out->w2 = tmp;
   TRY(get_w(c, cv + "hid2.bias", {1}, &t)); TRY(upload_f32(c, t->data.data(), 1, &tmp)); out->b2 = tmp;
@@ -614,7 +615,7 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     fa.img_h = (float)c->cfg.initial_h; fa.img_w = (float)c->cfg.initial_w;
     fa.dbg_times = (long long*)c->dbg_times;
     ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
-    launch_cv_fused<TA>(fa, s);
+    launch_cv_fused<TA>(fa, s, tapnet ? c->tapnet_heads : 1);
     return TAPIR_OK;
   }
   if (tapnet) return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells");
@@ -1118,7 +1119,13 @@ int tapir_finalize_weights(tapir_ctx* c) {
   for (const auto& kv : c->host_w)
     if (kv.first.rfind("torch_", 0) == 0) has_tapir = true;
   if (has_tapnet) {
-    TRY(upload_cv_head(c, "tapnet_cost_volume_track_mods.", 1, &c->tapnet_cvw));
+    // TAP-Net's num_heads = input channels of hid1 (tapnet_model.py:145-152): 1, 2 or 4
+    const auto& s1 = c->host_w["tapnet_cost_volume_track_mods.hid1.weight"].shape;
+    const int heads = s1.size() == 4 ? (int)s1[1] : 0;
+    if (heads != 1 && heads != 2 && heads != 4)
+      return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: num_heads (input channels of hid1) must be 1, 2 or 4");
+    TRY(upload_cv_head(c, "tapnet_cost_volume_track_mods.", 1, &c->tapnet_cvw, heads));
+    c->tapnet_heads = heads;
     c->tapnet_ready = true;
   }
   if (has_tapir) {

@@ -14,12 +14,13 @@ convolutions, softmax, soft arg max and the occlusion head in one launch.
 Out of scope: the TSM-ResNet backbone (tapnet/models/tsm_resnet.py).  ``__call__``
 therefore needs ``feature_grid`` (the L2-normalised [B,T,H/8,W/8,256] grid the reference returns as
 ``out['feature_grid']``); query features are sampled from it on the GPU (model_utils.interp,
-mode='nearest': tapir_get_query_features).  ``num_heads`` must be 1 (the constructor default; nothing in the reference sets another value).
+mode='nearest': tapir_get_query_features).  ``num_heads`` 1 (the constructor default; nothing in the reference sets another value), 2 or 4: the head count is
+the number of input channels of ``hid1`` in the weights.
 Pinned against the reference's own tapnet_model.py executed over numpy stand-ins for jax / haiku
 (oracle/make_tapnet_golden.py -> tests/golden/tapnet_head.npz, tests/test_tapnet_reference_pin.py).
 
 Weights: ``{'tapnet_cost_volume_track_mods.<hid1|hid2|hid3|hid4|occ_out>.<weight|bias>': array}`` in
-the torch layout of the TAPIR head (hid1 [16,1,3,3], hid2 [1,16,3,3], hid3 [32,16,3,3], hid4 [16,32],
+the torch layout of the TAPIR head (hid1 [16,num_heads,3,3], hid2 [1,16,3,3], hid3 [32,16,3,3], hid4 [16,32],
 occ_out [1,16]); ``from_haiku_params`` converts the reference's Haiku tree
 (``tap_net/~/cost_volume_regression_1`` ...).
 """
@@ -64,8 +65,8 @@ class TAPNet:
                num_frames: int = 24, *, weights: Optional[Mapping[str, Any]] = None,
                dtype: str = 'float32', device: Any = None):
     del cross_replica_axis, num_frames
-    if num_heads != 1:
-      raise ValueError('the HIP head is built for num_heads=1 (the released TAP-Net checkpoint)')
+    if num_heads not in (1, 2, 4):
+      raise ValueError('the HIP head is built for num_heads 1, 2 or 4')
     if feature_grid_stride != 8:
       raise ValueError('feature_grid_stride must be 8')
     if dtype not in ('float32', 'bfloat16'):
@@ -113,6 +114,8 @@ class TAPNet:
         continue
       a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
       a = np.ascontiguousarray(a, dtype=np.float32)
+      if k.endswith('hid1.weight') and (a.ndim != 4 or a.shape[1] != self.num_heads):
+        raise ValueError(f'hid1.weight {a.shape} does not have num_heads={self.num_heads} input channels')
       shape = (ctypes.c_int64 * a.ndim)(*a.shape)
       self._check(self._lib.tapir_set_weight(self._ctx, k.encode(), a.ctypes.data_as(ctypes.c_void_p),
                                              shape, a.ndim), f'tapir_set_weight({k})')
@@ -124,10 +127,10 @@ class TAPNet:
     im_shp [B,T,H,W,3].  Returns (points [B,N,T,2] (x,y) in im_shp pixels, occlusion [B,N,T])."""
     numpy_out = isinstance(interp_feature_heads, np.ndarray)
     qf, g = self._dev(interp_feature_heads), self._dev(feature_grid_heads)
-    if qf.ndim == 4:
-      if qf.shape[-1] != 1:
-        raise ValueError('num_heads must be 1')
-      qf, g = qf[..., 0].contiguous(), g[..., 0].contiguous()
+    if qf.ndim == 4:     # [B,N,C/d,d] and [B,T,h,w,C/d,d]: 'b n (c d)' is the same memory as [B,N,C]
+      if qf.shape[-1] != self.num_heads:
+        raise ValueError(f'expected {self.num_heads} heads, got {qf.shape[-1]}')
+      qf, g = qf.reshape(*qf.shape[:2], -1), g.reshape(*g.shape[:4], -1)
     B, Q, C = qf.shape
     _, T, h, w, _ = g.shape
     if C != 256:
@@ -171,7 +174,9 @@ class TAPNet:
     if get_query_feats:
       out['query_feats'] = conv(interp)
     if compute_regression:
-      pts, occ = self.tracks_from_cost_volume(interp[..., None], fg[..., None], qp, im_shp=shape)
+      d = self.num_heads
+      pts, occ = self.tracks_from_cost_volume(interp.reshape(B, Q, C // d, d), fg.reshape(B, T, h, w, C // d, d), qp,
+                                              im_shp=shape)
       out['occlusion'] = conv(occ)
       out['tracks'] = conv(pts)
     return out

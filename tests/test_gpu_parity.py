@@ -560,4 +560,4 @@ def test_tapnet_head_vs_oracle_gpu(dtype):
   with pytest.raises(NotImplementedError):
     m(np.zeros((B, T, H, H, 3), np.float32), False, qp)
   with pytest.raises(ValueError):
-    tapnet_model.TAPNet(num_heads=2, weights=w, device='cuda:0')
+    tapnet_model.TAPNet(num_heads=3, weights=w, device='cuda:0')

@@ -3,8 +3,8 @@
 tests/golden/tapnet_head.npz holds outputs of /root/reference's tapnet/models/tapnet_model.py
 (TAPNet.__call__ :173-290 with feature_grid=, tracks_from_cost_volume :111-171) and model_utils.py executed
 over numpy stand-ins for jax / haiku (oracle/hk_numpy_shim.py; generator oracle/make_tapnet_golden.py).
-CPU: the numpy restatement (oracle.tapir_oracle.tapnet_tracks_from_cost_volume, incl. num_heads = 2) and the
-emulated HIP kernel against it; `-m gpu`: tapnet_amd.tapnet_model.TAPNet on the device.  The parameters are
+CPU: the numpy restatement (oracle.tapir_oracle.tapnet_tracks_from_cost_volume) and the emulated HIP kernel
+(case c: num_heads = 2) against it; `-m gpu`: tapnet_amd.tapnet_model.TAPNet on the device.  The parameters are
 stored in Haiku layout and go through the product's from_haiku_params."""
 import os
 import subprocess
@@ -46,7 +46,7 @@ def test_restatement_matches_the_reference_code(tag):
   np.testing.assert_allclose(occ, ref['occlusion'], atol=1e-6)                # (measured 6e-9)
 
 
-@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_emulated_kernel_matches_the_reference_code(tag):
   from tests.emu_engine import EmuEngine
   w, grid, qp, shp, ref = _case(tag)
@@ -58,10 +58,10 @@ def test_emulated_kernel_matches_the_reference_code(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_gpu_head_matches_the_reference_code(tag):
   w, grid, qp, shp, ref = _case(tag)
-  m = tapnet_model.TAPNet(weights=w, device='cuda:0')
+  m = tapnet_model.TAPNet(num_heads=int(GOLD[tag + '/num_heads']), weights=w, device='cuda:0')
   out = m(shp, False, qp, query_chunk_size=4, get_query_feats=True, feature_grid=grid)
   np.testing.assert_allclose(out['query_feats'], ref['query_feats'], atol=2e-6)
   np.testing.assert_allclose(out['occlusion'], ref['occlusion'], atol=1e-4)
