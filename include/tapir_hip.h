@@ -248,7 +248,20 @@ int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, i
  *   ss: N * cin * 2 floats of scratch owned by the caller (the merged scale / shift; part_in == NULL: ss already
  *   holds the pairs of this input and norm from a previous call -- conv_0 and proj_conv of a block -- and is
  *   used as it is); part_out, if not
- *   NULL, [N, tiles, cout, 2] receives the summaries of y per tile (rows * W_out pixels each). */
+ *   NULL, [N, tiles, cout, 2] receives the summaries of y per tile (rows * W_out pixels each).
+ *
+ * The _nn forms ("next norm") also merge the summaries of y into the (a, b) pairs of the InstanceNorm that READS y,
+ * inside the same launch: every workgroup publishes its tile summary write-through and takes a ticket from the
+ * image's arrival counter; the one that draws the last ticket merges the image's summaries exactly as the separate
+ * merge kernel does (bit-identical pairs) and resets the counter -- no waiting anywhere.  next->ss [N, cout, 2]
+ * (pass it as `ss` with part_in = NULL to the call that consumes y), next->arrive [N] int32, ZERO before the first
+ * launch (every launch leaves it zero).  next == NULL: the plain forms. */
+typedef struct tapir_next_norm {
+  const float* gamma;   /* [cout] scale of the norm that reads y */
+  const float* beta;    /* [cout] offset */
+  float* ss;            /* [N, cout, 2] out */
+  int* arrive;          /* [N] arrival counters */
+} tapir_next_norm;
 int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles);
 int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);
 int tapir_conv_free(tapir_ctx* ctx, void* wstream);
@@ -256,6 +269,10 @@ int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int sl
                      const float* gamma, const float* beta, float* ss, const void* wstream,
                      const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                      int cout, int ks, int stride, void* stream);
+int tapir_conv_fused_nn(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                        const float* gamma, const float* beta, float* ss, const void* wstream,
+                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
+                        int cout, int ks, int stride, const tapir_next_norm* next, void* stream);
 
 /* The stem of the ResNet (resnet.py:356-364: initial_conv, 7x7 / stride 2 / SAME, 3 -> 64 channels):
  * x = the f32 frames [N,H,W,3] as the model receives them (bf16 contexts: rounded to bf16 on load, as the
@@ -266,6 +283,8 @@ int tapir_stem_plan(tapir_ctx* ctx, int H, int W, int* rows, int* tiles);
 int tapir_stem_pack(tapir_ctx* ctx, const float* w, void** wstream);
 int tapir_stem_conv(tapir_ctx* ctx, const float* x, const void* wstream, void* y, float* part_out, int N,
                     int H, int W, void* stream);
+int tapir_stem_conv_nn(tapir_ctx* ctx, const float* x, const void* wstream, void* y, float* part_out, int N,
+                       int H, int W, const tapir_next_norm* next, void* stream);
 
 /* BootsTAPIR's ExtraConvs (tapnet/models/tapir_model.py:159-186, class ExtraConvs; torch twin
  * tapnet/torch/nets.py:25-89): five blocks  y = LayerNorm(x) * scale + offset;  r = gelu(conv3x3(y) + b);

@@ -34,6 +34,10 @@ class TapirCfg(ctypes.Structure):
               ('initial_h', c_int), ('initial_w', c_int), ('dtype', c_int)]
 
 
+class TapirNextNorm(ctypes.Structure):   # tapir_next_norm (include/tapir_hip.h)
+  _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('ss', c_void_p), ('arrive', c_void_p)]
+
+
 class TapirPyramid(ctypes.Structure):
   _fields_ = [('n_levels', c_int), ('query', c_void_p * 3), ('grid', c_void_p * 3),
               ('h', c_int * 3), ('w', c_int * 3), ('C', c_int * 3)]
@@ -98,6 +102,11 @@ PROTOTYPES = {
     'tapir_xconv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_void_p]),
     'tapir_stem_conv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'tapir_stem_conv_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   POINTER(TapirNextNorm), c_void_p]),
+    'tapir_conv_fused_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, POINTER(TapirNextNorm), c_void_p]),
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),

@@ -39,6 +39,8 @@ class _Stats(NamedTuple):
   part: torch.Tensor
   slabs: int
   per_s: int
+  ss: Optional[torch.Tensor] = None      # the (a, b) pairs of norm `ss_norm`, merged by the producing launch itself
+  ss_norm: Optional[str] = None
 
 
 def _same_pad(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
@@ -94,6 +96,9 @@ class Backbone:
     self._wstream: Dict[str, int] = {}
     self._xstream: Dict[tuple, int] = {}     # ExtraConvs weight packs, by (conv name, input channels per chunk)
     self._xhost: Dict[str, 'np.ndarray'] = {}
+    # the producing convolution merges the next InstanceNorm's (a, b) pairs itself (tapir_conv_fused_nn) instead of a
+    # merge launch in front of the consuming convolution; '0' = the separate launches (the A/B switch)
+    self.fuse_finalize = os.environ.get('TAPIR_FUSE_FINALIZE', '1') != '0'
     self.extra_convs_mode = os.environ.get('TAPIR_EXTRA_CONVS', 'hip')   # 'hip' | 'torch' (MIOpen convolutions + torch glue: the A/B switch)
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
@@ -326,7 +331,19 @@ class Backbone:
     _, cin, cout, ks = self._wstream[conv_name]
     return self._plan(h, w, cin, cout, ks, stride) is not None
 
-  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True, reuse_ss=False):
+  def _next_norm(self, next_norm, n, cout, tag):
+    """tapir_next_norm for the launch that produces the input of `next_norm` (None: no in-launch merge)."""
+    if not (self.fuse_finalize and next_norm is not None):
+      return None, None
+    from tapnet_amd import _ffi
+    ssn = self._buf(('ssn', tag, n, cout), (n, cout, 2), torch.float32)
+    arrive = self._buf(('arrive', n), (n,), torch.int32, zero=True)     # zero once; every launch leaves it zero
+    nn = _ffi.TapirNextNorm(self.w[next_norm + '.weight'].data_ptr(), self.w[next_norm + '.bias'].data_ptr(),
+                            ssn.data_ptr(), arrive.data_ptr())
+    return nn, ssn
+
+  def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True, reuse_ss=False,
+                  next_norm=None):
     """conv(relu(instance_norm(x))) (+ shortcut) and the summaries of the result, one launch
     (+ the tiny merge of the input summaries; reuse_ss: the previous call on this stream merged the same
     summaries with the same norm -- conv_0 after proj_conv -- and its (a, b) pairs are still in the scratch)."""
@@ -337,16 +354,20 @@ class Backbone:
     ho, wo = -(-h // stride), -(-w // stride)
     y = self._buf(('fy', tag, n, ho, wo, cout), (n, ho, wo, cout), self.dtype)
     part = self._buf(('fpart', tag, n, tiles, cout), (n, tiles, cout, 2), torch.float32) if stats else None
-    ss = self._buf(('ss', n, cin), (n, cin, 2), torch.float32)
+    merged = st.ss is not None and st.ss_norm == norm_name     # the producer of x merged this norm's pairs already
+    ss = st.ss if merged else self._buf(('ss', n, cin), (n, cin, 2), torch.float32)
     assert y.data_ptr() != x.data_ptr() and (shortcut is None or y.data_ptr() != shortcut.data_ptr())
-    self._check(lib.tapir_conv_fused(
-        ctx, x.data_ptr(), None if reuse_ss else st.part.data_ptr(), st.slabs, st.per_s, self.w[norm_name + '.weight'].data_ptr(),
-        self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), ws,
+    import ctypes
+    nn, ssn = self._next_norm(next_norm if stats else None, n, cout, tag)
+    self._check(lib.tapir_conv_fused_nn(
+        ctx, x.data_ptr(), None if (reuse_ss or merged) else st.part.data_ptr(), st.slabs, st.per_s,
+        self.w[norm_name + '.weight'].data_ptr(), self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), ws,
         shortcut.data_ptr() if shortcut is not None else None, y.data_ptr(),
-        part.data_ptr() if stats else None, n, h, w, cin, cout, ks, stride, self._stream()), 'tapir_conv_fused')
-    return y, (_Stats(part, tiles, rows * wo) if stats else None)
+        part.data_ptr() if stats else None, n, h, w, cin, cout, ks, stride,
+        ctypes.byref(nn) if nn is not None else None, self._stream()), 'tapir_conv_fused_nn')
+    return y, (_Stats(part, tiles, rows * wo, ssn, next_norm if nn is not None else None) if stats else None)
 
-  def _hip_block(self, x, st: '_Stats', p, stride, use_projection, tag, parity):
+  def _hip_block(self, x, st: '_Stats', p, stride, use_projection, tag, parity, next_norm=None):
     """One BlockV2 (resnet.py:185-257).  x: the raw residual stream, st: its InstanceNorm summaries.
     Every convolution that has a HIP kernel for its shape reads x (or conv_0's raw output) directly;
     the normalised tensor is only materialised for the ones that go through MIOpen."""
@@ -364,13 +385,14 @@ class Backbone:
         shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
     if f0:
       y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c', stride,
-                                 reuse_ss=bool(use_projection and fp))   # (proj_conv just merged bn_0's pairs into `ss`)
+                                 reuse_ss=bool(use_projection and fp),   # (proj_conv just merged bn_0's pairs into `ss`)
+                                 next_norm=p + 'bn_1')
     else:
       y0 = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)
       st0 = self._hip_stats(y0)
     if self._fusable(p + 'conv_1', y0.shape[1], y0.shape[2], 1):
       # the result becomes the next block's residual stream: it may not alias this block's (the shortcut)
-      return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}')
+      return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}', next_norm=next_norm)
     y, _ = self._hip_norm_relu(y0, st0, p + 'bn_1', tag + 'b')
     y1 = self._hip_conv(y, p + 'conv_1', 1, 1)
     return y1, self._hip_stats(y1, shortcut)   # y1 += shortcut, fused with the next norm's statistics
@@ -398,9 +420,12 @@ class Backbone:
         fr = frames_nhwc.contiguous()
         x = self._buf(('stem', n, ho, wo), (n, ho, wo, 64), self.dtype)
         part = self._buf(('stempart', n, tiles.value), (n, tiles.value, 64, 2), torch.float32)
-        self._check(lib.tapir_stem_conv(ctx, fr.data_ptr(), self._stem_ws, x.data_ptr(), part.data_ptr(), n, h, w,
-                                        self._stream()), 'tapir_stem_conv')
-        st = _Stats(part, tiles.value, rows.value * wo)
+        first = 'resnet_torch.block_groups.0.blocks.0.bn_0'
+        nn, ssn = self._next_norm(first, n, 64, 'stem')
+        self._check(lib.tapir_stem_conv_nn(ctx, fr.data_ptr(), self._stem_ws, x.data_ptr(), part.data_ptr(), n, h, w,
+                                           ctypes.byref(nn) if nn is not None else None, self._stream()),
+                    'tapir_stem_conv_nn')
+        st = _Stats(part, tiles.value, rows.value * wo, ssn, first if nn is not None else None)
     if st is None:
       x = frames_nhwc.to(self.dtype).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
       w0 = self.w['resnet_torch.initial_conv.weight']
@@ -408,11 +433,12 @@ class Backbone:
       st = self._hip_stats(x)
     strides = (1, 2, 2, 1)
     unit1 = None
-    for g in range(4):
-      for b in range(self.blocks_per_group[g]):
-        x, st = self._hip_block(x, st, f'resnet_torch.block_groups.{g}.blocks.{b}.',
-                                strides[g] if b == 0 else 1, b == 0, f'g{g}', b & 1)
-      if g == 1:
+    blocks = [(g, b) for g in range(4) for b in range(self.blocks_per_group[g])]
+    for i, (g, b) in enumerate(blocks):
+      nxt = 'resnet_torch.block_groups.%d.blocks.%d.bn_0' % blocks[i + 1] if i + 1 < len(blocks) else None
+      x, st = self._hip_block(x, st, f'resnet_torch.block_groups.{g}.blocks.{b}.',
+                              strides[g] if b == 0 else 1, b == 0, f'g{g}', b & 1, next_norm=nxt)
+      if g == 1 and b == self.blocks_per_group[g] - 1:
         unit1 = x
     if self.extra_convs:
       # (like the ResNet convolutions: a single frame -- the online model -- gives the HIP kernels 16-64

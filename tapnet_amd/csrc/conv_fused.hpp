@@ -38,6 +38,19 @@ template <typename T> struct CvT;
 template <> struct CvT<bf16_t> { static constexpr int EPC = 8, KSTEP = 32; };
 template <> struct CvT<float> { static constexpr int EPC = 4, KSTEP = 16; };
 
+// The NEXT InstanceNorm's (a, b) pairs, merged inside this launch: every workgroup publishes its tile summary
+// write-through and takes a ticket from the image's arrival counter; the workgroup that draws the last ticket merges
+// all tile summaries of the image exactly as inorm_finalize_kernel does (same operations in the same order:
+// bit-identical pairs) and resets the counter.  No waiting anywhere: nothing can hang.  ss == null: off (the consumer
+// launches inorm_finalize_kernel on `part`).
+struct FinArgs {
+  const float* gamma;     // [C_out] of the norm that reads this output
+  const float* beta;
+  float* ss;              // [N, C_out, 2] in the planar layout of NormFinalizeArgs
+  int* arrive;            // [N] arrival counters, zero before the launch and after it
+  int planar;             // 8 | 4 (elements per 16-byte chunk of the context's type)
+};
+
 struct Conv3Args {
   const void* x;          // [N, H, W, C_in] raw input of the norm (T)
   const float* ss;        // [N, C_in / EPC, 2, EPC] (a of a 16-byte chunk of channels, then its b): operand = relu(a * x + b)
@@ -52,6 +65,7 @@ struct Conv3Args {
   int TH, tiles;          // output rows per tile, tiles per image = ceil(Ho / TH)
   int waves;              // 4 or 8 (conv3_plan)
   long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
+  FinArgs fin;
 };
 
 inline long conv3_frags_per_cg(int cin, int ks, int kstep) { return (long)ks * ks * (cin / kstep) * 4 + cv3_ring(ks); }
@@ -105,9 +119,72 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned p) {
 // to T and stored as 16-byte pieces (2 for bf16, 4 for f32) per pixel and lane; the (mean, M2) summary of the STORED values of
 // the workgroup's TP pixels goes to part[COUT][2] (Chan merge of the per-wave two-pass summaries).
 // `scratch` = LDS nobody reads any more (WAVES x 64 float2).
+// Last arriver of image n: inorm_finalize_kernel's arithmetic (64 channels x 4 slab lanes per pass, the four partial
+// sums of a channel meeting in LDS) over the image's tile summaries, read past the non-coherent caches.
+template <int COUT, int THREADS>
+__device__ __forceinline__ void fin_merge(const FinArgs& fin, const float* part_img, int n, int slabs, int per_s,
+                                          int HW, float* s_red /* [4][64] */) {
+  const int tid = threadIdx.x;
+  const int ch = tid & 63, q = (tid >> 6) & 3;
+  const bool act = tid < 256;
+  auto slab_n = [&](int s) { return s < slabs ? (float)max(0, min(HW, (s + 1) * per_s) - s * per_s) : 0.f; };
+  const float inv_hw = 1.0f / (float)HW;
+  const bool one_round = slabs <= NORM_FIN_LANES * NORM_FIN_MAXS;
+  for (int c0 = 0; c0 < COUT; c0 += 64) {
+    const int c = c0 + ch;
+    const float* ps = part_img + (long)c * 2;
+    float2 v[NORM_FIN_MAXS];
+    float s1 = 0.f;
+    for (int s0 = q; s0 < slabs; s0 += NORM_FIN_LANES * NORM_FIN_MAXS) {
+#pragma unroll
+      for (int k = 0; k < NORM_FIN_MAXS; ++k) v[k] = agent_load_f2(ps + (long)min(s0 + k * NORM_FIN_LANES, slabs - 1) * COUT * 2);
+#pragma unroll
+      for (int k = 0; k < NORM_FIN_MAXS; ++k) s1 = fmaf(slab_n(s0 + k * NORM_FIN_LANES), v[k].x, s1);
+    }
+    if (act) s_red[q * 64 + ch] = s1;
+    lds_barrier();
+    float mean = 0.f;
+#pragma unroll
+    for (int k = 0; k < NORM_FIN_LANES; ++k) mean += s_red[k * 64 + ch];
+    mean *= inv_hw;
+    float m2 = 0.f;
+    for (int s0 = q; s0 < slabs; s0 += NORM_FIN_LANES * NORM_FIN_MAXS) {
+      if (!one_round) {
+#pragma unroll
+        for (int k = 0; k < NORM_FIN_MAXS; ++k) v[k] = agent_load_f2(ps + (long)min(s0 + k * NORM_FIN_LANES, slabs - 1) * COUT * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < NORM_FIN_MAXS; ++k) {
+        const float nk = slab_n(s0 + k * NORM_FIN_LANES);
+        const float d = v[k].x - mean;
+        m2 += nk > 0.f ? fmaf(nk * d, d, v[k].y) : 0.f;
+      }
+    }
+    lds_barrier();        // every lane has read the first partial sums
+    if (act) s_red[q * 64 + ch] = m2;
+    lds_barrier();
+    if (act && q == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NORM_FIN_LANES; ++k) tot += s_red[k * 64 + ch];
+      const float rstd = 1.0f / sqrtf(tot * inv_hw + kInEps);
+      const float sc = rstd * fin.gamma[c];
+      const int P = fin.planar;
+      const long i0 = P ? ((long)n * COUT + (c & ~(P - 1))) * 2 + (c & (P - 1)) : ((long)n * COUT + c) * 2;
+      fin.ss[i0] = sc;
+      fin.ss[i0 + (P ? P : 1)] = fin.beta[c] - mean * sc;
+    }
+    lds_barrier();        // s_red is reused by the next 64 channels
+  }
+}
+
+// part = this tile's summary slot; with fin.ss != null also: part_img = the image's [tiles][COUT][2] summaries,
+// n = image, tiles / per_s / HW = the slab geometry inorm_finalize_kernel would get for them.
 template <typename T, int COUT, int NT, int WAVES>
 __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const int (&qpix)[NT], int TP,
-                                             T* ytile, float* part, char* scratch) {
+                                             T* ytile, float* part, char* scratch, const FinArgs& fin = FinArgs{},
+                                             const float* part_img = nullptr, int n = 0, int tiles = 0,
+                                             int per_s = 0, int HW = 0) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int CG = COUT / 64, PG = WAVES / CG;
   const int tid = threadIdx.x;
@@ -196,8 +273,21 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
       const float2 sv = s_stat[p * CG + cgi][ch];
       merge_stats(cn, mean, m2, nb, sv.x, sv.y);
     }
-    *reinterpret_cast<float2*>(part + tid * 2) = make_float2(mean, m2);
+    if (fin.ss != nullptr) agent_store_f2(part + tid * 2, mean, m2);      // write-through: read by another workgroup
+    else *reinterpret_cast<float2*>(part + tid * 2) = make_float2(mean, m2);
   }
+  if (fin.ss == nullptr) return;
+  dma_wait<0>();          // every wave: its summary stores have been written through
+  lds_barrier();          // (also: the reads of s_stat above are done, the scratch is reused below)
+  int* const s_flag = reinterpret_cast<int*>(scratch);
+  if (tid == 0) {
+    const int last = agent_fetch_add(fin.arrive + n, 1) == tiles - 1;
+    if (last) agent_store_int(fin.arrive + n, 0);
+    *s_flag = last;
+  }
+  lds_barrier();
+  if (*s_flag == 0) return;
+  fin_merge<COUT, WAVES * 64>(fin, part_img, n, tiles, per_s, HW, reinterpret_cast<float*>(scratch) + 16);
 }
 
 template <typename T, int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
@@ -415,7 +505,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
 
   // ---- epilogue: round, store, per-channel (mean, M2) of what was stored
   cv3_epilogue<T, COUT, NT, WAVES>(acc, qpix, TP, reinterpret_cast<T*>(a.y) + img * COUT,
-                                   a.part ? a.part + ((long)n * a.tiles + t) * COUT * 2 : nullptr, tile);
+                                   a.part ? a.part + ((long)n * a.tiles + t) * COUT * 2 : nullptr, tile, a.fin,
+                                   a.part ? a.part + (long)n * a.tiles * COUT * 2 : nullptr, n, a.tiles, a.TH * a.Wo,
+                                   a.Ho * a.Wo);
   tick(4);
   if (TRACE && a.dbg_times != nullptr && lane == 0) {
     tick(5);
@@ -493,6 +585,7 @@ struct StemArgs {
   void* y;                // [N, Ho, Wo, 64] (the context's element type)
   float* part;            // null, or [N, tiles, 64, 2]
   int N, H, W, Ho, Wo, pad_y, pad_x, TH, tiles;
+  FinArgs fin;
 };
 
 // bytes per LDS row of the input image: (2 Wo + 5) pixels x 3 channels + 64 bytes of slack for the padded k
@@ -612,7 +705,9 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
   lds_barrier();
   const long img = ((long)n * a.Ho + r0) * Wo;
   cv3_epilogue<T, 64, NT, WAVES>(acc, qpix, TP, reinterpret_cast<T*>(a.y) + img * 64,
-                                 a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile);
+                                 a.part ? a.part + ((long)n * a.tiles + t) * 64 * 2 : nullptr, tile, a.fin,
+                                 a.part ? a.part + (long)n * a.tiles * 64 * 2 : nullptr, n, a.tiles, a.TH * Wo,
+                                 a.Ho * Wo);
 }
 
 template <typename T>

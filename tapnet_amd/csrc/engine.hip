@@ -1432,7 +1432,20 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
                      const float* gamma, const float* beta, float* ss, const void* wstream,
                      const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                      int cout, int ks, int stride, void* stream) {
+  return tapir_conv_fused_nn(c, x, part_in, slabs_in, per_s_in, gamma, beta, ss, wstream, shortcut, y, part_out, N, H, W,
+                             cin, cout, ks, stride, nullptr, stream);
+}
+
+static bool next_norm_ok(const tapir_next_norm* nx, const float* part_out) {
+  return nx == nullptr || (nx->gamma && nx->beta && nx->ss && nx->arrive && part_out);
+}
+
+int tapir_conv_fused_nn(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                        const float* gamma, const float* beta, float* ss, const void* wstream,
+                        const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
+                        int cout, int ks, int stride, const tapir_next_norm* next, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
+  if (!next_norm_ok(next, part_out)) return fail(c, TAPIR_ERR_INVALID, "next norm: gamma, beta, ss, arrive and part_out are all needed");
   HIP_TRY(c, hipSetDevice(c->device));
   // part_in NULL: ss already holds the merged (a, b) pairs of this input and norm (a previous call: conv_0 and
   // proj_conv of a block read the same normalised tensor) -- no second inorm_finalize launch
@@ -1454,6 +1467,7 @@ int tapir_conv_fused(tapir_ctx* c, const void* x, const float* part_in, int slab
   ca.pad_y = conv3_pad_lo(H, ks, stride); ca.pad_x = conv3_pad_lo(W, ks, stride);
   ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
   ca.dbg_times = (long long*)c->dbg_times;
+  if (next != nullptr) ca.fin = FinArgs{next->gamma, next->beta, next->ss, next->arrive, bf ? 8 : 4};
   if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   HIP_TRY(c, hipGetLastError());
@@ -1592,9 +1606,15 @@ int tapir_stem_pack(tapir_ctx* c, const float* w, void** wstream) {
 
 int tapir_stem_conv(tapir_ctx* c, const float* x, const void* wstream, void* y, float* part_out, int N, int H,
                     int W, void* stream) {
+  return tapir_stem_conv_nn(c, x, wstream, y, part_out, N, H, W, nullptr, stream);
+}
+
+int tapir_stem_conv_nn(tapir_ctx* c, const float* x, const void* wstream, void* y, float* part_out, int N, int H,
+                       int W, const tapir_next_norm* next, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!x || !wstream || !y || N < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  if (!next_norm_ok(next, part_out)) return fail(c, TAPIR_ERR_INVALID, "next norm: gamma, beta, ss, arrive and part_out are all needed");
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0;
   if (!stem_plan(H, W, bf ? 2 : 4, &rows, &tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "stem_conv: shape");
@@ -1603,6 +1623,7 @@ int tapir_stem_conv(tapir_ctx* c, const float* x, const void* wstream, void* y, 
   sa.N = N; sa.H = H; sa.W = W; sa.Ho = (H + 1) / 2; sa.Wo = (W + 1) / 2;
   sa.pad_y = conv3_pad_lo(H, 7, 2); sa.pad_x = conv3_pad_lo(W, 7, 2);
   sa.TH = rows; sa.tiles = tiles;
+  if (next != nullptr) sa.fin = FinArgs{next->gamma, next->beta, next->ss, next->arrive, bf ? 8 : 4};
   if (bf) launch_stem_conv<bf16_t>(sa, (hipStream_t)stream);
   else launch_stem_conv<float>(sa, (hipStream_t)stream);
   HIP_TRY(c, hipGetLastError());

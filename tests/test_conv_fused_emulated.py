@@ -279,3 +279,65 @@ def test_conv_rejects_bad_shapes():
   assert plan(ctx, 128, 128, 64, 128, 3, 2) == 0 and rows.value >= 2
   assert plan(ctx, 128, 128, 64, 128, 1, 2) == 0
   lib.tapir_destroy(ctx)
+
+
+@pytest.mark.parametrize('C,H,W,dtype', [(64, 40, 24, _ffi.TAPIR_BF16), (256, 9, 8, _ffi.TAPIR_BF16),
+                                         (128, 70, 12, _ffi.TAPIR_BF16), (64, 12, 16, _ffi.TAPIR_F32)])
+def test_next_norm_pairs_merged_in_the_launch(C, H, W, dtype):
+  """tapir_conv_fused_nn: the workgroup that draws the last ticket of an image merges the tile summaries into the
+  (a, b) pairs of the NEXT InstanceNorm -- bit-identical to the separate merge launch of the consuming call, counters
+  back at zero, y and the tile summaries unchanged.  (70 x 12: more tiles than one round of the merge holds.)"""
+  lib = emu_lib()
+  ctx = _ctx(lib, dtype)
+  bf = dtype == _ffi.TAPIR_BF16
+  rng = np.random.default_rng(C + H)
+  N = 3
+  x = _r(rng.standard_normal((N, H, W, C)) * 1.5 + 0.5)
+  w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  g0, b0 = rng.uniform(0.5, 1.5, C).astype(np.float32), (rng.standard_normal(C) * 0.3).astype(np.float32)
+  g1, b1 = rng.uniform(0.5, 1.5, C).astype(np.float32), (rng.standard_normal(C) * 0.3).astype(np.float32)
+  xb = to_bf16_bits(x) if bf else x.astype(np.float32)
+  slabs = 2
+  part_in = np.zeros((N, slabs, C, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, C, slabs, None) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, _p(np.ascontiguousarray(w)), C, C, 3, ctypes.byref(ws)) == 0
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, H, W, C, C, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  ydt = np.uint16 if bf else np.float32
+
+  def call(nn):
+    y = np.zeros((N, H, W, C), ydt)
+    part = np.zeros((N, tiles.value, C, 2), np.float32)
+    ss = np.zeros((N, C, 2), np.float32)
+    rc = lib.tapir_conv_fused_nn(ctx, _p(xb), _p(part_in), slabs, 0, _p(g0), _p(b0), _p(ss), ws, None, _p(y), _p(part),
+                                 N, H, W, C, C, 3, 1, ctypes.byref(nn) if nn is not None else None, None)
+    assert rc == 0, lib.tapir_last_error(ctx)
+    return y, part
+
+  y_ref, part_ref = call(None)
+  # the consuming call's own merge launch: its `ss` is what the _nn form has to reproduce
+  ss_ref = np.zeros((N, C, 2), np.float32)
+  y2 = np.zeros((N, H, W, C), ydt)
+  assert lib.tapir_conv_fused(ctx, _p(y_ref), _p(part_ref), tiles.value, rows.value * W, _p(g1), _p(b1), _p(ss_ref), ws,
+                              None, _p(y2), None, N, H, W, C, C, 3, 1, None) == 0
+  ssn = np.full((N, C, 2), np.nan, np.float32)
+  arrive = np.zeros(N, np.int32)
+  nn = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn.ctypes.data, arrive.ctypes.data)
+  for _ in range(2):          # twice: the counters come back to zero
+    y, part = call(nn)
+    assert (arrive == 0).all()
+    np.testing.assert_array_equal(y, y_ref)
+    np.testing.assert_array_equal(part, part_ref)
+    np.testing.assert_array_equal(ssn, ss_ref)
+    ssn[:] = np.nan
+  # and the consumer takes the pairs as they are (part_in = NULL)
+  call(nn)
+  y3 = np.zeros((N, H, W, C), ydt)
+  assert lib.tapir_conv_fused(ctx, _p(y_ref), None, 0, 0, None, None, _p(ssn), ws, None, _p(y3), None, N, H, W, C, C, 3,
+                              1, None) == 0
+  np.testing.assert_array_equal(y3, y2)
+  bad = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn.ctypes.data, None)
+  assert lib.tapir_conv_fused_nn(ctx, _p(xb), _p(part_in), slabs, 0, _p(g0), _p(b0), _p(ss_ref), ws, None, _p(y3), _p(part),
+                                 N, H, W, C, C, 3, 1, ctypes.byref(bad), None) == _ffi.TAPIR_ERR_INVALID
+  lib.tapir_destroy(ctx)

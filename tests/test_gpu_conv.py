@@ -408,3 +408,33 @@ def test_extra_convs_map_widths(size, expect_hip):
   got = bb.features(frames)
   assert bool(bb._xstream) == expect_hip
   assert float((ref[0] - got[0]).abs().max()) < 2e-5, float((ref[0] - got[0]).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float32'])
+def test_next_norm_merged_in_the_launch_is_bit_identical(dtype, monkeypatch):
+  """The producing convolution merges the next InstanceNorm's (a, b) pairs itself (tapir_conv_fused_nn: write-through
+  tile summaries, an arrival counter per image, the last workgroup merges) instead of a merge launch in front of the
+  consumer: the feature grids are bit-identical to the separate launches -- eager and as a replayed hipGraph, twelve
+  times over with other work in flight (a stale or torn summary would show as a changed pair) -- and the arrival
+  counters are back at zero."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(5, 0, False)
+  video = synthetic.make_video(7, 24, 256, 256)
+  monkeypatch.setenv('TAPIR_FUSE_FINALIZE', '0')
+  ref_model = tapir_model.TAPIR(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0')
+  assert not ref_model._backbone.fuse_finalize
+  fg0 = ref_model.get_feature_grids(video, False)
+  low0, hi0 = fg0.lowres[0].clone(), fg0.hires[0].clone()
+  monkeypatch.setenv('TAPIR_FUSE_FINALIZE', '1')
+  m = tapir_model.TAPIR(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0')
+  assert m._backbone.fuse_finalize
+  noise = torch.randn(4096, 4096, device='cuda:0')
+  for i in range(12):
+    if i % 3 == 0:
+      noise = noise @ noise.t() * 1e-4          # other kernels in flight around the backbone's streams
+    fg = m.get_feature_grids(video, False)
+    assert torch.equal(fg.lowres[0], low0) and torch.equal(fg.hires[0], hi0), i
+  torch.cuda.synchronize()
+  arrive = [t for k, t in m._backbone._bufs.items() if 'arrive' in k]
+  assert arrive and all(int(t.abs().sum()) == 0 for t in arrive)
