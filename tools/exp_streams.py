@@ -9,7 +9,7 @@ for extra in (False, True):
   m = TAPIR(pyramid_level=1 if extra else 0, extra_convs=extra, weights=w, device='cuda:0', dtype='bfloat16')
   bb = m._backbone
   frames = torch.rand(48, 256, 256, 3, device='cuda:0') * 2 - 1
-  for streams in (2, 4, 2, 4, 3):
+  for streams in (2, 4, 6, 3, 4, 2, 8):
     bb.streams = streams
     for _ in range(5):
       bb.features(frames, borrow=True)
