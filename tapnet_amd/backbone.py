@@ -156,8 +156,9 @@ class Backbone:
                      if k not in self.hip_convs)
     if hip and self._stem_ws is not None and self._wstream and not missing:
       s = ('HIP: 7x7 stem + every ResNet block convolution (3x3 / 1x1, stride 1 / 2) as fused implicit-GEMM MFMA '
-           'kernels (InstanceNorm+ReLU in the operand load, residual add + next-norm statistics in the epilogue), '
-           'HIP finalize / L2-normalise kernels')
+           'kernels (InstanceNorm+ReLU in the operand load, residual add + next-norm statistics in the epilogue' +
+           (', the next norm\'s (a, b) pairs merged by the last-arriving workgroup of each image), HIP L2-normalise kernel'
+            if self.fuse_finalize else '), HIP finalize / L2-normalise kernels'))
     elif hip:
       s = 'HIP fused convolutions except ' + ', '.join(missing or ['(unpacked shapes)']) + ' (MIOpen) + HIP norm kernels'
     else:
