@@ -76,7 +76,9 @@ class Backbone:
     # alternating with them (1.86 -> 1.64 / 1.57 ms with 2 / 4 streams for a 48-frame clip, bit-identical: every kernel here is
     # independent of how many frames a launch covers).  1 = everything on the caller's stream; applies
     # to clips of at least 8 frames per stream.
-    self.streams = 4 if dtype == torch.bfloat16 else 1
+    # With BootsTAPIR's ExtraConvs (large, MFMA-bound launches that fill the chip on their own) two groups are 3.5 %
+    # faster than four (3.49-3.54 against 3.64-3.69 ms per clip, tools/exp_streams.py, same box).
+    self.streams = (2 if extra_convs else 4) if dtype == torch.bfloat16 else 1
     self._side_streams = []
     self._lane = 0
     # 'auto': the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2: everything but the 7x7
