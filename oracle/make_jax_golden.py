@@ -45,6 +45,10 @@ CASES = dict(
                                         use_causal_conv=True), T=4, HW=(48, 80), Q=5, chunk=5, online=True,
                        update_frame=2, update_idx=(1, 3)),
     # two clips in one call, backbone in frame chunks of 2 (feature_extractor_chunk_size, :680-700)
+    # the north_star shape (BASELINE.json configs[1]): 48 frames of 256x256, 256 queries, TAPIR kwargs, chunks of 64.
+    # ~10 minutes of numpy; the file holds outputs only (video and queries are seeds) -- not part of --check's default
+    north_star=dict(seed=41, kw=dict(pyramid_level=0, extra_convs=False, initial_resolution=(256, 256)),
+                    T=48, HW=(256, 256), Q=256, chunk=64, outputs_only=True),
     batch2_chunked=dict(seed=35, kw=dict(pyramid_level=1, extra_convs=False, initial_resolution=(48, 80),
                                          feature_extractor_chunk_size=2), T=3, HW=(48, 80), Q=5, chunk=3, B=2),
 )
@@ -54,17 +58,25 @@ def tree_signature(tree):
   return {f'{m}:{k}': tuple(np.shape(v)) for m, leaves in tree.items() for k, v in leaves.items()}
 
 
-def run_case(name, c, ref, hk):
-  from tapnet_amd import synthetic, weights
-  kw = dict(c['kw'])
-  w = synthetic.make_weights(c['seed'], kw['pyramid_level'], kw['extra_convs'])
-  params = weights.torch_to_haiku_names(w)
+def case_inputs(c):
+  """Seeded clip [B,T,H,W,3] in [-1,1] and queries [B,Q,3] (t,y,x) of a case (tests regenerate them from here)."""
+  from tapnet_amd import synthetic
   H, W = c['HW']
   nb = c.get('B', 1)
   video = np.concatenate([synthetic.make_video(c['seed'] + 10 * b, c['T'], H, W) for b in range(nb)]).astype(np.float32)
   qp = np.concatenate([synthetic.make_queries(c['seed'] + 1 + 10 * b, c['Q'], c['T'], H, W) for b in range(nb)]).astype(np.float32)
   if c.get('online'):
     qp[..., 0] = 0.0            # the online demo queries points on the first frame
+  return video, qp
+
+
+def run_case(name, c, ref, hk):
+  from tapnet_amd import synthetic, weights
+  kw = dict(c['kw'])
+  w = synthetic.make_weights(c['seed'], kw['pyramid_level'], kw['extra_convs'])
+  params = weights.torch_to_haiku_names(w)
+  H, W = c['HW']
+  video, qp = case_inputs(c)
 
   # (1) the module tree of the reference creates exactly the converted tree
   t0 = time.time()
@@ -78,16 +90,19 @@ def run_case(name, c, ref, hk):
 
   # (2) the reference's entry point on the converted tree
   model = ref.ParameterizedTAPIR(params, {}, tapir_kwargs=kw)
-  out = {'video': video, 'query_points': qp, 'seed': np.array(c['seed']),
+  out = {'seed': np.array(c['seed']),
          'pyramid_level': np.array(kw['pyramid_level']), 'extra_convs': np.array(kw['extra_convs']),
          'initial_resolution': np.array(kw['initial_resolution']), 'query_chunk_size': np.array(c['chunk']),
          'use_causal_conv': np.array(bool(kw.get('use_causal_conv', False)))}
+  if not c.get('outputs_only'):
+    out['video'], out['query_points'] = video, qp
   t0 = time.time()
   if not c.get('online'):
     fg = model.get_feature_grids(video, False)
     res = model(video, False, qp, query_chunk_size=c['chunk'], feature_grids=fg)
     for i, (lo, hi, r) in enumerate(zip(fg.lowres, fg.hires, fg.resolutions)):
-      out[f'lowres_{i}'], out[f'hires_{i}'] = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+      if not c.get('outputs_only'):
+        out[f'lowres_{i}'], out[f'hires_{i}'] = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
       out[f'resolution_{i}'] = np.array(r.shape[:2])
     for k in ('tracks', 'occlusion', 'expected_dist'):
       out[k] = np.asarray(res[k], np.float32)
@@ -178,7 +193,7 @@ def main():
     sys.path.insert(0, REFERENCE_ROOT)
   import haiku as hk                                  # the stand-in
   from tapnet.models import tapir_model as ref        # the reference, imported over the stand-ins
-  for name in (a.cases or list(CASES) + ['robotap']):
+  for name in (a.cases or [k for k, c in CASES.items() if not c.get('outputs_only')] + ['robotap']):
     out = run_robotap() if name == 'robotap' else run_case(name, CASES[name], ref, hk)
     path = os.path.join(GOLDEN, f'jax_{name}.npz')
     if a.check:

@@ -238,3 +238,23 @@ def test_gpu_track_many_points_matches_the_reference_driver(tmp_path):
     assert np.mean(res['separation_visibility'][k] == g[f'visibility_{k}']) == 1.0
   for i in range(3):
     np.testing.assert_allclose(res['query_points'][i], g[f'query_points_{i}'], atol=1e-12)
+
+
+# ------------------------------------------------------------------------- the north_star shape
+@pytest.mark.gpu
+def test_gpu_north_star_shape_matches_the_jax_text():
+  """BASELINE.json configs[1] -- 48 frames of 256x256, 256 queries, TAPIR kwargs, query chunks of 64 -- through the
+  reference's JAX text over the stand-ins (tests/golden/jax_north_star.npz: outputs only; clip, queries and weights
+  are seeds) against the f32 engine loaded from the Haiku tree: video -> tracks at 1e-3, every refinement iteration."""
+  from oracle import make_jax_golden as gen
+  g, kw, w = _load('north_star')
+  video, qp = gen.case_inputs(g['case'])
+  m = _model(kw, w)
+  out = m(video, False, qp, query_chunk_size=int(g['query_chunk_size']))
+  for k in ('tracks', 'occlusion', 'expected_dist'):
+    d = np.abs(_np(out[k]) - g[k])
+    print(k, 'max', d.max(), 'median', np.median(d))
+    assert d.max() < 1e-3, (k, d.max())
+  for i in range(len(out['unrefined_tracks'])):
+    np.testing.assert_allclose(_np(out['unrefined_tracks'][i]), g['unrefined_tracks'][i], atol=1e-3)
+    np.testing.assert_allclose(_np(out['unrefined_occlusion'][i]), g['unrefined_occlusion'][i], atol=1e-3)
