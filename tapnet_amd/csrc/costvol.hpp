@@ -36,6 +36,7 @@ struct CvHeadWeights {
 
 struct CvHeadArgs {
   const float* cv;        // [maps, h*w] cost volume, map index = (b*Q + q)*T + t
+  long ld;                // 0, or floats between the rows of consecutive queries (>= T*h*w: rows padded to 16 bytes)
   CvHeadWeights wt;
   const float* qpts;      // [B*Q, 3] (t, y, x) in initial_resolution coordinates, or null
   float* points;          // [maps, 2] (x, y) in initial_resolution pixels
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(CV_THREADS) void cv_heads_kernel(CvHeadArgs a) {
   const long map = blockIdx.x;
   const int h = a.h, w = a.w, hw = h * w;
   const int pw = w + 2, ph = h + 2, pn = pw * ph;
-  const float* cv = a.cv + map * hw;
+  const float* cv = a.ld ? a.cv + (map / a.T) * a.ld + (map % a.T) * hw : a.cv + map * hw;
 
   // ---- cost map + zero halos
   for (int i = tid; i < pn; i += CV_THREADS) {
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(NT, 2) void cv_heads_mfma_kernel(CvHeadArgs a) {
   // processed, so their HBM latency hides under ~10 us of arithmetic.
   float cmv[CM_PT];
   auto fetch = [&](long m) {
-    const float* cvp = a.cv + m * hw;
+    const float* cvp = a.ld ? a.cv + (m / a.T) * a.ld + (m % a.T) * hw : a.cv + m * hw;
 #pragma unroll
     for (int s = 0; s < CM_PT; ++s) {
       const int i = tid + s * NT;

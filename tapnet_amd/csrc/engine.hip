@@ -553,8 +553,11 @@ int cost_volume_gemm(tapir_ctx* c, const void* qf, const void* grid, int Q, int 
   g.A = qf; g.lda = C;
   g.W = grid; g.ldw = C;
   g.bias = nullptr; g.resid = nullptr; g.ldr = 0;
-  g.C = vol; g.ldc = (long)T * hw;
-  g.M = Q; g.N = T * hw; g.K = C;
+  // T*hw not a multiple of 4 (odd grids x odd frame counts): the GEMM stores 4 columns at a time, so it runs over the
+  // next multiple with W's rows clamped to the real ones; the volume's rows carry the padding (launch_cv_heads: ld)
+  const int n = T * hw, n4 = (n + 3) & ~3;
+  g.C = vol; g.ldc = n4;
+  g.M = Q; g.N = n4; g.K = C; g.w_rows = n == n4 ? 0 : n;
   { ProfScope ps(c, TAPIR_PROF_CV_GEMM, s); launch_gemm<TA, float, EPI_BIAS>(g, s); }
   return TAPIR_OK;
 }
@@ -565,6 +568,7 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
   a.cv = cv; a.wt = c->cvw; a.qpts = qpts_init;
   a.points = points; a.occ = occ; a.expd = expd;
   a.T = T; a.h = h; a.w = w; a.maps = maps;
+  a.ld = ((long)T * h * w) % 4 ? (((long)T * h * w + 3) & ~3L) : 0;
   a.temperature = c->cfg.softmax_temperature;
   a.img_h = (float)c->cfg.initial_h; a.img_w = (float)c->cfg.initial_w;
   a.dbg_times = (long long*)c->dbg_times;
@@ -621,9 +625,10 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   if (tapnet) return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells");
   // grids beyond 32 x 32 cells (or cv_mode 1, tools): einsum into a workspace of <= 256 MiB per
   // launch, then the heads kernel
-  long qc = (256L << 20) / ((long)T * hw * 4);
+  const long row = ((long)T * hw + 3) & ~3L;            // volume row of a query, padded to 16 bytes
+  long qc = (256L << 20) / (row * 4);
   qc = std::max<long>(1, std::min<long>(qc, Q));
-  TRY(ensure(c, c->cv, (size_t)qc * T * hw * sizeof(float)));
+  TRY(ensure(c, c->cv, (size_t)qc * row * sizeof(float)));
   for (int b = 0; b < B; ++b) {
     for (long q0 = 0; q0 < Q; q0 += qc) {
       const int nq = (int)std::min<long>(qc, Q - q0);
@@ -1227,7 +1232,6 @@ int tapir_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float*
   REQUIRE_READY(c);
   if (!qfeat || !grid || !points || !occlusion || !expected_dist || B < 1 || Q < 1 || T < 1)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
-  if (((long)T * h * w) % 4 != 0) return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
   c->cast_src[1] = nullptr;   // (the cast cache is only valid within one API call: the caller may have rewritten the grid)
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points,
                   occlusion, expected_dist, (hipStream_t)stream);
@@ -1727,8 +1731,6 @@ int tapir_estimate_trajectories(tapir_ctx* c, const tapir_traj_args* a, void* st
       return fail(c, TAPIR_ERR_INVALID, "null feature level");
     if (a->res_h[l] < 1 || a->res_w[l] < 1) return fail(c, TAPIR_ERR_INVALID, "bad resolution");
   }
-  if (((long)a->T * a->lowres_h[0] * a->lowres_w[0]) % 4 != 0)
-    return fail(c, TAPIR_ERR_UNSUPPORTED, "T*h*w must be a multiple of 4");
   if ((a->ctx1_in || a->ctx1_out) && !c->cfg.use_causal_conv)
     return fail(c, TAPIR_ERR_INVALID, "causal context needs use_causal_conv");
   if ((a->ctx1_in == nullptr) != (a->ctx2_in == nullptr) ||

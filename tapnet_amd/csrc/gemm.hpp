@@ -52,6 +52,8 @@ struct GemmArgs {
   const float* resid; long ldr;            // EPI_BIAS_RESID: [M, ldr] f32
   void* C; long ldc;
   int M, N, K;                             // K multiple of (128 / sizeof(T)); N, ldc multiples of 4
+  int w_rows;                              // 0, or the rows W really has (< N: N is rounded up to a multiple of 4 for the
+                                           // vector stores; the extra columns repeat W's last row and land in C's row padding)
   long long* dbg_times;                    // null, or [workgroups][16] wall-clock stamps (tools/kbench.py --what gemmtrace)
 };
 
@@ -164,7 +166,7 @@ struct GemmStager {
     for (int s = 0; s < TL::CH_W; ++s) {
       const int id = tid + TL::THREADS * s;
       const int row = id >> 3, p = id & 7;
-      offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
+      offW[s] = (long)min(n0 + row, (g.w_rows ? g.w_rows : g.N) - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
     }
   }
   // LDS stage layout: A rows [0, BM), W rows [BM, BM+BN); chunk id = row*8 + p (lane-linear)
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(TL::THREADS + PW * 64) void gemm_ws_kernel(GemmArgs
       for (int s = 0; s < CH_W; ++s) {
         const int id = t + PT * s;
         const int row = id >> 3, p = id & 7;
-        offW[s] = (long)min(n0 + row, g.N - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
+        offW[s] = (long)min(n0 + row, (g.w_rows ? g.w_rows : g.N) - 1) * g.ldw + (p ^ TL::template swz_w<PAIR>(row)) * EPC;
       }
     };
     int i_local = slot, i_kt = 0;
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < FM; ++i) pa[i] = A + (long)min(m0 + 16 * i + c, g.M - 1) * g.lda + EPC * gq;
 #pragma unroll
-  for (int j = 0; j < FN; ++j) pw[j] = W + (long)min(n0 + 16 * j + c, g.N - 1) * g.ldw + EPC * gq;
+  for (int j = 0; j < FN; ++j) pw[j] = W + (long)min(n0 + 16 * j + c, (g.w_rows ? g.w_rows : g.N) - 1) * g.ldw + EPC * gq;
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int j = 0; j < FN; ++j)

@@ -561,3 +561,28 @@ def test_tapnet_head_vs_oracle_gpu(dtype):
     m(np.zeros((B, T, H, H, 3), np.float32), False, qp)
   with pytest.raises(ValueError):
     tapnet_model.TAPNet(num_heads=3, weights=w, device='cuda:0')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw,T', [((56, 88), 9), ((264, 264), 3)])
+def test_odd_grids_times_odd_frame_counts(hw, T):
+  """Frames x grid cells not a multiple of four -- 9 frames of a 7 x 11 grid (fused cost-volume kernel) and 3 frames of
+  a 33 x 33 grid (workspace path: the einsum GEMM stores four columns at a time; it runs over the next multiple with
+  the grid's rows clamped and the volume's rows padded) -- used to be refused (found by tools/fuzz_parity.py).
+  f32 engine from feature grids against the oracle."""
+  from tapnet_amd import tapir_model
+  H, W = hw
+  w = synthetic.make_weights(23, 0, False)
+  m = tapir_model.TAPIR(pyramid_level=0, initial_resolution=hw, weights=w, device='cuda:0')
+  rng = np.random.default_rng(T)
+  Q = 7
+  low = O.l2_normalize(rng.standard_normal((1, T, H // 8, W // 8, 256)).astype(np.float32))
+  hi = O.l2_normalize(rng.standard_normal((1, T, H // 4, W // 4, 128)).astype(np.float32))
+  qp = synthetic.make_queries(4, Q, T, H, W)
+  fg = tapir_model.FeatureGrids((low, low), (hi, hi), (hw, hw))
+  out = m(np.zeros((1, T, H, W, 3), np.float32), False, qp, feature_grids=fg)
+  ref = O.tapir_from_grids(w, (1, T, H, W, 3), [low, low], [hi, hi], [hw, hw], qp, pyramid_level=0,
+                           softmax_temperature=20.0, initial_resolution=hw)
+  np.testing.assert_allclose(out['tracks'], ref['tracks'], atol=2e-3)
+  np.testing.assert_allclose(out['occlusion'], ref['occlusion'], atol=1e-3)
+  np.testing.assert_allclose(out['expected_dist'], ref['expected_dist'], atol=1e-3)

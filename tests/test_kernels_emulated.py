@@ -310,3 +310,29 @@ def test_tapnet_head_vs_oracle(dtype, hw):
                                            out.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), None)
   assert rc == _ffi.TAPIR_ERR_WEIGHTS
   e.close()
+
+
+@pytest.mark.parametrize('dtype', [_ffi.TAPIR_F32, _ffi.TAPIR_BF16])
+def test_cost_volume_stage_when_frames_x_cells_is_not_a_multiple_of_four(dtype):
+  """A 7 x 11 grid with 3 frames (231 values per query row): the fused kernel does not care, and the workspace path
+  (cv_mode 1: einsum GEMM into a volume, then the heads) runs its GEMM over the next multiple of four with the grid's
+  rows clamped and the volume's rows padded -- both against the oracle, and equal to each other."""
+  w = synthetic.make_weights(3, 0, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, pyramid_level=0, num_mixer_blocks=1, initial_resolution=(56, 88), dtype=dtype)
+  rng = np.random.default_rng(5)
+  Q, T, h, wd = 6, 3, 7, 11
+  grid = O.l2_normalize(rng.standard_normal((1, T, h, wd, 256)).astype(np.float32))
+  qp = synthetic.make_queries(6, Q, T, 56, 88)
+  qf, _ = O.get_query_features([grid], [grid[..., :128]], [(56, 88)], qp, (1, T, 56, 88, 3))
+  g_ref, q_ref = (bf16_round(grid), bf16_round(qf[0])) if dtype == _ffi.TAPIR_BF16 else (grid, qf[0])
+  rp, ro, re, st = O.tracks_from_cost_volume(w, q_ref, g_ref, qp, (56, 88), 20.0, return_stages=True)
+  ok = st['top2_rel_gap'] > 1e-3
+  outs = []
+  for mode in (0, 1):
+    assert e.lib.tapir_debug_set_cv_mode(e.ctx, mode) == 0
+    pts, occ, expd = e.tracks_from_cost_volume(qf[0], grid, qp)
+    np.testing.assert_allclose(occ, ro, atol=1e-4 if dtype == _ffi.TAPIR_F32 else 3e-2)
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3 if dtype == _ffi.TAPIR_F32 else 5e-3)
+    outs.append(pts)
+  np.testing.assert_allclose(outs[0][ok], outs[1][ok], atol=1e-3 if dtype == _ffi.TAPIR_F32 else 5e-3)
+  e.close()
