@@ -22,12 +22,14 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--cases', type=int, default=20)
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--tmax', type=int, default=20)
+  ap.add_argument('--qmax', type=int, default=24)
   a = ap.parse_args()
   rng = np.random.default_rng(a.seed)
   worst = 0.0
   for i in range(a.cases):
     pyr, extra = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
-    T, Q = int(rng.integers(1, 21)), int(rng.integers(1, 25))
+    T, Q = int(rng.integers(1, a.tmax + 1)), int(rng.integers(1, a.qmax + 1))
     ih, iw = 8 * int(rng.integers(6, 13)), 8 * int(rng.integers(6, 13))          # initial_resolution 48..96
     scale = float(rng.choice([1.0, 1.0, 1.5, 2.0]))
     H, W = 8 * int(round(ih * scale / 8)), 8 * int(round(iw * scale / 8))
