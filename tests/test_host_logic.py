@@ -165,3 +165,16 @@ def test_jax_style_antialiased_resize_matches_the_restatement():
   # the 2x case has the closed form [1, 3, 3, 1] / 8 away from the borders
   w = jax_resize.compute_weight_mat(8, 4)
   np.testing.assert_allclose(w[1:5, 1], [0.125, 0.375, 0.375, 0.125], atol=1e-12)
+
+
+def test_resolution_answers_both_conventions():
+  """FeatureGrids / QueryFeatures.resolutions entries: (H, W) tuples as in the torch twin
+  (tapnet/torch/tapir_model.py:45) that also answer `.shape[:2]` like the JAX model's zero-size shape carriers
+  (tapnet/models/tapir_model.py:259-265, 724)."""
+  from tapnet_amd.tapir_model import Resolution, _res_hw
+  r = Resolution((64, 96))
+  assert r == (64, 96) and r[0] == 64 and tuple(r) == (64, 96)
+  assert r.shape == (64, 96, 0) and r.shape[:2] == (64, 96)
+  assert _res_hw(r) == (64, 96) and _res_hw((64, 96)) == (64, 96)
+  import numpy as np
+  assert _res_hw(np.zeros((64, 96, 0), np.float32)) == (64, 96)       # a JAX-style carrier passed in
