@@ -170,24 +170,6 @@ def test_strided_and_projection_convs(cin, cout, ks, stride, H, W):
   tot_M2 = (pM2 + cnt[None, :, None] * (pm - tot_mean[:, None]) ** 2).sum(1)
   np.testing.assert_allclose(tot_mean, got.mean((1, 2), dtype=np.float64), atol=1e-5)
   np.testing.assert_allclose(tot_M2 / (Ho * Wo), got.astype(np.float64).var((1, 2)), rtol=1e-4, atol=1e-6)
-  # tapir_stem_conv_nn: the first InstanceNorm's (a, b) pairs merged inside the launch == the merge launch of the
-  # convolution that consumes the stem's output
-  g1, b1 = rng.uniform(0.5, 1.5, 64).astype(np.float32), (rng.standard_normal(64) * 0.3).astype(np.float32)
-  wc = (rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
-  wcs = ctypes.c_void_p()
-  assert lib.tapir_conv_pack(ctx, _p(np.ascontiguousarray(wc)), 64, 64, 3, ctypes.byref(wcs)) == 0
-  ss_ref = np.zeros((N, 64, 2), np.float32)
-  y2 = np.zeros((N, Ho, Wo, 64), y.dtype)
-  assert lib.tapir_conv_fused(ctx, _p(y), _p(part), tiles.value, rows.value * Wo, _p(g1), _p(b1), _p(ss_ref), wcs, None,
-                              _p(y2), None, N, Ho, Wo, 64, 64, 3, 1, None) == 0
-  ssn, arrive = np.full((N, 64, 2), np.nan, np.float32), np.zeros(N, np.int32)
-  nn = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn.ctypes.data, arrive.ctypes.data)
-  y3, part3 = np.zeros_like(y), np.zeros_like(part)
-  assert lib.tapir_stem_conv_nn(ctx, _p(x), ws, _p(y3), _p(part3), N, H, W, ctypes.byref(nn), None) == 0
-  np.testing.assert_array_equal(y3, y)
-  np.testing.assert_array_equal(part3, part)
-  np.testing.assert_array_equal(ssn, ss_ref)
-  assert (arrive == 0).all()
   lib.tapir_destroy(ctx)
 
 
