@@ -346,7 +346,10 @@ int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
 /* Cost-volume stage (tapir_tracks_from_cost_volume and the first stage of
  * tapir_estimate_trajectories): 0 = automatic (ONE kernel -- einsum on the matrix cores into LDS +
  * heads, no volume in HBM -- for grids of up to 32 x 32 cells; larger grids take the path below),
- * 1 = einsum GEMM into a workspace followed by the heads kernel (round-1 path; tools A/B it). */
+ * 1 = einsum GEMM into a workspace followed by the heads kernel (round-1 path; tools A/B it),
+ * 2 = the fused kernel in its pixel-tiled form (costvol_fused.hpp: one map at a time over the whole
+ * workgroup) also where automatic picks the row-streamed form (costvol_rows.hpp: every wave owns whole
+ * maps; rows of up to 32 cells). */
 int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
 /* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
  * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */

@@ -43,6 +43,7 @@ constexpr int CVF_CPT = 2;           // cells per thread: h*w <= 1024
 struct CvFusedArgs {
   const void* qfeat;      // [B*Q, 256] operand type
   const void* grid;       // [B*T, h*w, 256] operand type
+  const void* grid_tiled; // costvol_rows.hpp, bf16: the same grid as [B*T][tiles of 16 cells][32 chunks][16 cells][8] (or null)
   CvHeadWeights wt;
   const float* qpts;      // [B*Q, 3] (t, y, x) in initial_resolution coordinates, or null
   float* points;          // [B*Q*T, 2]

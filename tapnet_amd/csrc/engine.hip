@@ -16,15 +16,14 @@
 #include "conv_fused.hpp"
 #include "costvol.hpp"
 #include "costvol_fused.hpp"
+#include "costvol_rows.hpp"
 #include "extra_convs.hpp"
 #include "gemm.hpp"
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
 #include "mixer_fused_wide.hpp"
 #ifdef TAPIR_EXPERIMENTS
-#include "mixer_fused_half.hpp"   // measured and not adopted: experiments builds only
-#include "mixer_fused_x16.hpp"
-#include "mixer_fused_fp8w.hpp"   // fp8 weight stream: written without GPU time left, emulator-checked only
+#include "experiments/mixer_fused_fp8w.hpp"   // fp8 weight stream: opt-in third precision class, experiments builds only
 #endif
 #include "pips.hpp"
 
@@ -80,12 +79,10 @@ struct tapir_ctx {
   float fp8w_s_in = 1.f, fp8w_s_out = 1.f;
   std::vector<float> fp8w_s_dn; std::vector<float*> fp8w_ln2s;
 #endif
-  uint4* fused16_stream = nullptr; long fused16_fpw = 0;         // bf16: sixteen wave streams (mixer_fused_x16.hpp)
-  uint4* fused_half_stream = nullptr; long fused_half_fpw = 0;   // bf16: the 4-wave kernel's packing (mixer_fused_half.hpp)
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
-  int half_skew_div = 0;                          // half-CU kernel: start skew of every other group of this many workgroups (TAPIR_HALF_SKEW_DIV; measured: no gain)
-  int half_min_tracks = 0;                        // auto mode: half-CU kernel from this many tracks on (0: never); TAPIR_HALF_MIN_TRACKS
+  bool cv_tiled = true;                           // row-streamed cost volume, bf16: contraction operand in tile order (TAPIR_CV_TILED=0: row-major, A/B)
+  int cv_form = 0;                                // row-streamed cost volume: maps x waves per workgroup (costvol_rows.hpp; TAPIR_CV_FORM, A/B)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
@@ -93,6 +90,8 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
+  DevBuf grid_tiled;                 // bf16 low-res grid in the cost-volume kernel's operand order (pips.hpp: PoolArgs::tiled)
+  const float* tiled_src = nullptr;  // which grid it holds (valid together with cast_src[1])
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
   int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
@@ -490,113 +489,6 @@ int build_fused_fp8w_weights(tapir_ctx* c) {
 }
 #endif
 
-#ifdef TAPIR_EXPERIMENTS
-// the 8-wave kernel's stream order (U0 U1 D0 U2 D1 ... per block, chunks of 512 hidden units) for SIXTEEN waves:
-// a wave owns 32 output rows (2 row tiles per k-step) and 32 hidden rows per chunk
-int build_fused16_weights(tapir_ctx* c) {
-  typedef bf16_t TA;
-  const int nb = c->cfg.num_mixer_blocks;
-  const long fpw = fused16_frags_per_wave(c->k0_pad, nb);
-  std::vector<uint8_t> host((size_t)FX_WAVES * fpw * 1024, 0);
-  const std::string mx = "torch_pips_mixer.";
-  const HostTensor *w0, *wout;
-  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
-  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
-  constexpr int HC = 512, RAU = HC / FX_WAVES / 16, NC = kHidden4 / HC, QA = FX_QA, RW = kHidden / FX_WAVES;
-  for (int w = 0; w < FX_WAVES; ++w) {
-    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
-    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
-      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
-      q += 1024;
-    };
-    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
-      for (int a = 0; a < QA; ++a) put(w0, kHidden, c->in_dim, RW * w + 16 * a, ks * 32);
-    for (int b = 0; b < nb; ++b) {
-      const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
-      const HostTensor *wup, *wdn;
-      TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup));
-      TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn));
-      auto put_up = [&](int hc) {
-        for (int ks = 0; ks < kHidden / 32; ++ks)
-          for (int a = 0; a < RAU; ++a) put(wup, kHidden4, kHidden, hc * HC + w * (HC / FX_WAVES) + 16 * a, ks * 32);
-      };
-      auto put_dn = [&](int hc) {
-        for (int ks = 0; ks < HC / 32; ++ks)
-          for (int a = 0; a < QA; ++a) put(wdn, kHidden, kHidden4, RW * w + 16 * a, hc * HC + ks * 32);
-      };
-      put_up(0);
-      for (int hc = 1; hc < NC; ++hc) { put_up(hc); put_dn(hc - 1); }
-      put_dn(NC - 1);
-    }
-    for (int ks = 0; ks < kHidden / 32; ++ks)
-      for (int a = 0; a < QA; ++a) put(wout, kMixOut, kHidden, RW * w + 16 * a, ks * 32);
-    if (q + (size_t)FX_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
-      return fail(c, TAPIR_ERR_WEIGHTS, "16-wave fused stream layout mismatch");
-  }
-  void* d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, host.size()));
-  c->owned.push_back(d);
-  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
-  c->fused16_stream = (uint4*)d;
-  c->fused16_fpw = fpw;
-  return TAPIR_OK;
-}
-#endif
-
-#ifdef TAPIR_EXPERIMENTS
-// the same matrices for the half-CU kernel (mixer_fused_half.hpp): FOUR wave streams, a wave owns 128 output rows
-// (8 row tiles per k-step), chunks of 128 hidden units in the pipelined order U0 U1 D0 U2 D1 ... D15
-int build_fused_half_weights(tapir_ctx* c) {
-  typedef bf16_t TA;
-  const int nb = c->cfg.num_mixer_blocks;
-  const long fpw = fused_half_frags_per_wave(c->k0_pad, nb);
-  std::vector<uint8_t> host((size_t)FMH_WAVES * fpw * 1024, 0);
-  const std::string mx = "torch_pips_mixer.";
-  const HostTensor *w0, *wout;
-  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
-  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
-  constexpr int HC = FMH_HC, RAU = FMH_RAU, NC = FMH_NC, QA = FMH_QA, RW = kHidden / FMH_WAVES;
-  for (int w = 0; w < FMH_WAVES; ++w) {
-    uint8_t* q = host.data() + (size_t)w * fpw * 1024;
-    auto put = [&](const HostTensor* t, int rows, int cols, int row0, int k0) {
-      pack_fragment<TA>(q, t->data.data(), rows, cols, row0, k0);
-      q += 1024;
-    };
-    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
-      for (int a = 0; a < QA; ++a) put(w0, kHidden, c->in_dim, RW * w + 16 * a, ks * 32);
-    for (int b = 0; b < nb; ++b) {
-      const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
-      const HostTensor *wup, *wdn;
-      TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup));
-      TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn));
-      auto put_up = [&](int hc) {
-        for (int ks = 0; ks < kHidden / 32; ++ks)
-          for (int a = 0; a < RAU; ++a) put(wup, kHidden4, kHidden, hc * HC + w * (HC / FMH_WAVES) + 16 * a, ks * 32);
-      };
-      auto put_dn = [&](int hc) {
-        for (int ks = 0; ks < HC / 32; ++ks)
-          for (int a = 0; a < QA; ++a) put(wdn, kHidden, kHidden4, RW * w + 16 * a, hc * HC + ks * 32);
-      };
-      put_up(0);
-      for (int hc = 1; hc < NC; ++hc) { put_up(hc); put_dn(hc - 1); }
-      put_dn(NC - 1);
-    }
-    for (int ks = 0; ks < kHidden / 32; ++ks)
-      for (int a = 0; a < QA; ++a) put(wout, kMixOut, kHidden, RW * w + 16 * a, ks * 32);
-    if (q + (size_t)FMH_RING * 1024 != host.data() + (size_t)(w + 1) * fpw * 1024)
-      return fail(c, TAPIR_ERR_WEIGHTS, "half fused stream layout mismatch");
-  }
-  void* d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, host.size()));
-  c->owned.push_back(d);
-  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
-  c->fused_half_stream = (uint4*)d;
-  c->fused_half_fpw = fpw;
-  return TAPIR_OK;
-}
-
-#endif
-
 // ----------------------------------------------------------------------------
 // small helper kernels
 // ----------------------------------------------------------------------------
@@ -632,12 +524,24 @@ __global__ void iter0_kernel(Iter0Args a) {
 // ----------------------------------------------------------------------------
 // stage drivers (templated on the operand type)
 // ----------------------------------------------------------------------------
+// bytes of the tiled bf16 copy of a [frames, h*w, 256] grid
+inline size_t tiled_bytes(long frames, int h, int w) { return (size_t)frames * ((h * w + 15) / 16) * 16 * kLowresDim * 2; }
+
+// grows like ensure(); new memory is zeroed once (cells past the end of a frame's last tile are never written)
+int ensure_zeroed(tapir_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return TAPIR_OK;
+  TRY(ensure(c, b, bytes));
+  HIP_TRY(c, hipMemset(b.p, 0, b.cap));
+  return TAPIR_OK;
+}
+
 template <typename TA>
 int cast_or_pool(tapir_ctx* c, const float* src, long frames, int h, int w, int C, int pool,
-                 DevBuf& dst, hipStream_t s) {
+                 DevBuf& dst, hipStream_t s, DevBuf* tiled = nullptr) {
   const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
   TRY(ensure(c, dst, (size_t)frames * oh * ow * C * sizeof(TA)));
-  PoolArgs pa{src, dst.p, frames, h, w, C, pool};
+  if (tiled != nullptr) TRY(ensure_zeroed(c, *tiled, tiled_bytes(frames, h, w)));
+  PoolArgs pa{src, dst.p, frames, h, w, C, pool, tiled != nullptr ? tiled->p : nullptr};
   const long total = frames * oh * ow * (C / 4);
   const int nb = (int)std::min<long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL((pool_cast_kernel<TA>), dim3(nb), dim3(256), 0, s, pa);
@@ -698,11 +602,15 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   const int C = kLowresDim, hw = h * w;
   const void* qf_op = qfeat;
   const void* grid_op = grid;
+  // row-streamed kernel, bf16: the grid also in the operand order of its contraction (one cast kernel writes both)
+  const bool rows = cv_rows_supported(h, w) && c->cv_mode == 0;
+  const bool tiled = rows && sizeof(TA) == 2 && c->cv_tiled;
   if (sizeof(TA) == 2) {   // stage bf16 copies of both operands
     TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
-    if (c->cast_src[1] != grid) {
-      TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
+    if (c->cast_src[1] != grid || (tiled && c->tiled_src != grid)) {
+      TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s, tiled ? &c->grid_tiled : nullptr));
       c->cast_src[1] = grid;    // the same layout as the low-res pyramid level: prepare_level reuses it
+      if (tiled) c->tiled_src = grid;
     }
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
   }
@@ -710,6 +618,7 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     // one kernel: contraction on the matrix cores into LDS + heads; no volume in HBM
     CvFusedArgs fa{};
     fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = tapnet ? c->tapnet_cvw : c->cvw; fa.qpts = qpts_init;
+    fa.grid_tiled = tiled ? c->grid_tiled.p : nullptr;
     fa.tapnet = tapnet ? 1 : 0;
     fa.points = points; fa.occ = occ; fa.expd = expd;
     fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w;
@@ -717,7 +626,10 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     fa.img_h = (float)c->cfg.initial_h; fa.img_w = (float)c->cfg.initial_w;
     fa.dbg_times = (long long*)c->dbg_times;
     ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
-    launch_cv_fused<TA>(fa, s, tapnet ? c->tapnet_heads : 1);
+    // row-streamed form (every wave owns whole maps, costvol_rows.hpp) for rows of up to 32 cells; the
+    // pixel-tiled form (costvol_fused.hpp) for the other shapes it covers, and on request (cv_mode 2, A/B)
+    if (rows) launch_cv_rows<TA>(fa, s, tapnet ? c->tapnet_heads : 1, c->cv_form);
+    else launch_cv_fused<TA>(fa, s, tapnet ? c->tapnet_heads : 1);
     return TAPIR_OK;
   }
   if (tapnet) return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells");
@@ -789,31 +701,21 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
     bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
                 fused_wide_supported(T, c->k0_pad, causal, has_ctx);
-    // half-CU form (bf16): one track per 4-wave workgroup, two workgroups per CU (17..48 frames)
 #ifdef TAPIR_EXPERIMENTS
-    bool half = sizeof(TA) == 2 && c->fused_half_stream != nullptr && fused_half_supported(T, c->k0_pad, causal, has_ctx);
-    bool x16 = sizeof(TA) == 2 && c->fused16_stream != nullptr && fused16_supported(T, c->k0_pad, causal, has_ctx);
-    if (c->mixer_mode == 6 && !x16)
-      return fail(c, TAPIR_ERR_UNSUPPORTED, "16-wave fused mixer forced, but it does not cover this shape");
     const bool fp8w = c->mixer_mode == 7;
     if (fp8w && !(sizeof(TA) == 2 && c->fp8w_stream != nullptr && fused))
       return fail(c, TAPIR_ERR_UNSUPPORTED, "fp8-weight fused mixer forced, but it does not cover this shape");
 #else
-    bool half = false, x16 = false;
     const bool fp8w = false;
 #endif
-    if (c->mixer_mode == 5 && !half)
-      return fail(c, TAPIR_ERR_UNSUPPORTED, "half-CU fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 2 && !fused)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 3 && !wide)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
-    if (c->mixer_mode == 1) fused = wide = half = false;
-    if (c->mixer_mode == 2) wide = half = false;
-    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = half = false;
-    if (c->mixer_mode == 5) fused = wide = false;
-    if (c->mixer_mode == 6) fused = wide = half = false; else x16 = false;
-    if (fp8w) wide = half = x16 = false;
+    if (c->mixer_mode == 1) fused = wide = false;
+    if (c->mixer_mode == 2) wide = false;
+    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
+    if (fp8w) wide = false;
     if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
@@ -821,24 +723,20 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       // split-K GEMMs on all rows are faster than a mostly idle chip
       if (fused) fused = N >= 128 && R >= 4096;
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
-      // two independent tracks per CU beat two tracks in one workgroup (TAPIR_HALF_MIN_TRACKS; 0 = never)
-      if (half) half = c->half_min_tracks > 0 && N >= c->half_min_tracks && T <= 48;
-      if (half) wide = false;
-      if (wide || half) fused = false;
+      if (wide) fused = false;
     }
-    if (fused || wide || half || x16) {
+    if (fused || wide) {
       TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
       FusedArgs fa{};
       fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
-      fa.stream = x16 ? c->fused16_stream : half ? c->fused_half_stream : wide ? c->fused_wide_stream : c->fused_stream;
-      fa.frags_per_wave = x16 ? c->fused16_fpw : half ? c->fused_half_fpw : wide ? c->fused_wide_fpw : c->fused_fpw;
+      fa.stream = wide ? c->fused_wide_stream : c->fused_stream;
+      fa.frags_per_wave = wide ? c->fused_wide_fpw : c->fused_fpw;
       fa.b0 = c->b0; fa.nblocks = nb;
       for (int i = 0; i < nb; ++i) fa.blocks[i] = c->fused_blocks[i];
       fa.dbg_times = (long long*)c->dbg_times;
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
-      fa.skew_div = half ? c->half_skew_div : 0;
       if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim) {
         fa.fuse_update = 1; fa.upd = *upd; *upd_done = true;
       }
@@ -850,9 +748,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
         qa.s_in = c->fp8w_s_in; qa.s_out = c->fp8w_s_out;
         for (int i = 0; i < nb; ++i) { qa.s_dn[i] = c->fp8w_s_dn[i]; qa.ln2s[i] = c->fp8w_ln2s[i]; }
         launch_mixer_fused_fp8w(qa, s);
-      } else if (x16) launch_mixer_fused16(fa, s);
-      else if (half) launch_mixer_fused_half(fa, s);
-      else
+      } else
 #endif
       if (wide) launch_mixer_fused_wide(fa, s);
       else launch_mixer_fused<TA>(fa, s);
@@ -950,7 +846,7 @@ int do_build_cost_volume(tapir_ctx* c, const float* qfeat, const float* grid, in
   if (sizeof(TA) == 2) {
     TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
     TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s));
-    c->cast_src[1] = nullptr;
+    c->cast_src[1] = nullptr; c->tiled_src = nullptr;
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
   }
   for (int b = 0; b < B; ++b) {
@@ -1061,7 +957,7 @@ int do_refine_pips(tapir_ctx* c, const tapir_pyramid* pyr, int B, int Q, int T, 
     } else {
       DevBuf& dst = (l == 2) ? c->pooled : c->grid_cast[l];
       TRY(cast_or_pool<TA>(c, pyr->grid[l], (long)B * T, pyr->h[l], pyr->w[l], pyr->C[l], 0, dst, s));
-      c->cast_src[l] = nullptr;
+      c->cast_src[l] = nullptr; c->tiled_src = nullptr;
       lg.grid[l] = dst.p;
     }
   }
@@ -1090,6 +986,7 @@ int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
   const int nb = c->cfg.num_mixer_blocks;
   const int ih = c->cfg.initial_h, iw = c->cfg.initial_w;
   for (int l = 0; l < kMaxLevels; ++l) c->cast_src[l] = nullptr;
+  c->tiled_src = nullptr;
   TRY(ensure(c, c->pos, (size_t)R * 2 * 4));
   TRY(ensure(c, c->occ, (size_t)R * 4));
   TRY(ensure(c, c->expd, (size_t)R * 4));
@@ -1177,8 +1074,8 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   // (same-box A/B of builds from outside the process: tools/ab_env.sh)
   if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
-  if (const char* e = getenv("TAPIR_HALF_MIN_TRACKS")) c->half_min_tracks = atoi(e);
-  if (const char* e = getenv("TAPIR_HALF_SKEW_DIV")) c->half_skew_div = atoi(e);
+  if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
+  if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   *out = c;
   return TAPIR_OK;
 }
@@ -1226,8 +1123,6 @@ int tapir_finalize_weights(tapir_ctx* c) {
   c->tapnet_ready = false; c->tapir_ready = false;
   c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
   c->fused_wide_stream = nullptr; c->fused_wide_fpw = 0;
-  c->fused_half_stream = nullptr; c->fused_half_fpw = 0;
-  c->fused16_stream = nullptr; c->fused16_fpw = 0;
 #ifdef TAPIR_EXPERIMENTS
   c->fp8w_stream = nullptr; c->fp8w_ln2s.clear(); c->fp8w_s_dn.clear();
 #endif
@@ -1286,8 +1181,6 @@ static int finalize_tapir(tapir_ctx* c) {
     if (c->cfg.dtype == TAPIR_BF16) {
       TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c));
 #ifdef TAPIR_EXPERIMENTS
-      TRY(build_fused_half_weights(c));
-      TRY(build_fused16_weights(c));
       TRY(build_fused_fp8w_weights(c));
 #endif
     }
@@ -1316,6 +1209,7 @@ int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
     TRY(ensure(c, c->qf_cast, BQ * kLowresDim * es));
     TRY(ensure(c, c->grid_cast[0], frames * 4 * mh * mw * kHiresDim * es));
     TRY(ensure(c, c->grid_cast[1], frames * mh * mw * kLowresDim * es));
+    TRY(ensure_zeroed(c, c->grid_tiled, tiled_bytes((long)frames, (int)mh, (int)mw)));
   }
   if (c->cfg.pyramid_level >= 1) TRY(ensure(c, c->pooled, frames * (mh / 2) * (mw / 2) * kLowresDim * es));
   return TAPIR_OK;
@@ -1345,7 +1239,7 @@ int tapir_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const float*
   REQUIRE_READY(c);
   if (!qfeat || !grid || !points || !occlusion || !expected_dist || B < 1 || Q < 1 || T < 1)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
-  c->cast_src[1] = nullptr;   // (the cast cache is only valid within one API call: the caller may have rewritten the grid)
+  c->cast_src[1] = nullptr; c->tiled_src = nullptr;   // (the cast cache is only valid within one API call: the caller may have rewritten the grid)
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points,
                   occlusion, expected_dist, (hipStream_t)stream);
 }
@@ -1359,7 +1253,7 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (c->cv_mode == 1 || !cv_fused_supported(h, w))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells (fused kernel only)");
-  c->cast_src[1] = nullptr;
+  c->cast_src[1] = nullptr; c->tiled_src = nullptr;
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points, occlusion,
                   nullptr, (hipStream_t)stream, true);
 }
@@ -1786,7 +1680,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
   bool ok = mode >= 0 && mode <= 3;
 #ifdef TAPIR_EXPERIMENTS
-  ok = ok || (mode >= 4 && mode <= 7);   // 4: timing-only pair simulation of the wide kernel; 5: the half-CU kernel; 6: 16 waves; 7: fp8 weights
+  ok = ok || mode == 4 || mode == 7;   // 4: timing-only pair simulation of the wide kernel; 7: fp8 weight stream
 #endif
   if (!c || !ok) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
@@ -1806,7 +1700,7 @@ int tapir_debug_set_update_mode(tapir_ctx* c, int mode) {
 }
 
 int tapir_debug_set_cv_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
   c->cv_mode = mode;
   return TAPIR_OK;
 }

@@ -88,7 +88,6 @@ struct FusedArgs {
   // this iteration's output slices.  fuse_update = 0: plain res output (tapir_pips_mixer).
   int fuse_update;
   UpdateArgs upd;
-  int skew_div;                  // half-CU kernel: workgroups with (blockIdx / skew_div) odd start half a block late (0: none)
 };
 
 // Output of the mixer for token row r, output channels o0 .. o0 + 3 (o0 a multiple of 4, < 388): either stored to

@@ -229,7 +229,14 @@ __global__ __launch_bounds__(128) void query_feature_kernel(SampleArgs a) {
 
 // ---- 2x2 average pool over (h, w) of a channels-last grid (tapir_model.py:995-1000),
 // optionally converting to the operand type; also the plain cast (pool = 0).
-struct PoolArgs { const float* in; void* out; long frames; int h, w, C; int pool; };
+struct PoolArgs {
+  const float* in; void* out; long frames; int h, w, C; int pool;
+  // optional second copy (plain cast of a 256-channel grid to bf16 only) in the cost-volume kernel's A-operand order:
+  // [frame][tile of 16 cells][32 chunks of 8 channels][16 cells][8 bf16] -- the 16 lanes of an MFMA row group read 256
+  // contiguous bytes (costvol_rows.hpp: row-major, the same 16 lanes touch 16 different 512-byte rows and the vector
+  // L1 serves one line per cycle).  Cells past the end of the last tile are never written (the buffer is zeroed once).
+  void* tiled;
+};
 template <typename TO>
 __global__ __launch_bounds__(256) void pool_cast_kernel(PoolArgs a) {
   const int oh = a.pool ? a.h / 2 : a.h, ow = a.pool ? a.w / 2 : a.w;
@@ -256,6 +263,12 @@ __global__ __launch_bounds__(256) void pool_cast_kernel(PoolArgs a) {
     }
     TO* o = reinterpret_cast<TO*>(a.out) + ((f * oh + y) * ow + x) * a.C + c4 * 4;
     Elem<TO>::st(o, v.x); Elem<TO>::st(o + 1, v.y); Elem<TO>::st(o + 2, v.z); Elem<TO>::st(o + 3, v.w);
+    if (sizeof(TO) == 2 && a.tiled != nullptr) {
+      const int cell = y * ow + x, ntile = (oh * ow + 15) >> 4;
+      TO* q = reinterpret_cast<TO*>(a.tiled) +
+              ((((f * ntile + (cell >> 4)) * 32 + (c4 >> 1)) * 16 + (cell & 15)) * 8 + (c4 & 1) * 4);
+      Elem<TO>::st(q, v.x); Elem<TO>::st(q + 1, v.y); Elem<TO>::st(q + 2, v.z); Elem<TO>::st(q + 3, v.w);
+    }
   }
 }
 

@@ -85,47 +85,6 @@ def test_wide_fused_mixer_bf16(T, N):
   e.close()
 
 
-@pytest.mark.parametrize('T,N', [(48, 3), (40, 2), (20, 5), (32, 1)])
-def test_half_cu_fused_mixer_bf16(T, N):
-  """Half-CU form (mixer_fused_half.hpp, mode 5): one track per 4-wave workgroup (a wave owns 128 channels, 8 row
-  tiles per k-step), chunks of 128 hidden units, its own weight-stream packing, LayerNorm summaries inside the
-  activation region.  Same roundings as the 8-wave kernel: the two agree to accumulation order."""
-  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
-  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
-  rng = np.random.default_rng(T + N)
-  x = rng.standard_normal((N, T, 535)).astype(np.float32)
-  half = _mixer(e, x, 5)
-  sep = _mixer(e, x, 1)
-  narrow = _mixer(e, x, 2)
-  assert np.isfinite(half).all()
-  assert np.abs(half - sep).max() < 2e-2, np.abs(half - sep).max()
-  assert np.median(np.abs(half - sep)) < 2e-3
-  assert np.abs(half - narrow).max() < 2e-2
-  ref16, _ = O.pips_mlp_mixer(w, x, num_blocks=2, rnd=O.bf16_round)
-  d = np.abs(half - ref16)
-  assert d.max() < 4e-3 and np.median(d) < 1e-4, (d.max(), np.median(d))     # the rounding oracle
-  # clips of up to 16 frames are the 8-wave kernel's
-  out = np.zeros((1, 16, 388), np.float32)
-  p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, 5) == 0
-  assert e.lib.tapir_pips_mixer(e.ctx, p(x[:1, :16].copy()), 1, 16, p(out), None, None, None, None, None) == _ffi.TAPIR_ERR_UNSUPPORTED
-  e.close()
-
-
-@pytest.mark.parametrize('T,N', [(48, 2), (40, 1)])
-def test_sixteen_wave_fused_mixer_bf16(T, N):
-  """16-wave form (mixer_fused_x16.hpp, mode 6, experiments builds): a wave owns 32 channels, four waves per SIMD,
-  sixteen weight streams with a 4-deep ring, LayerNorm summaries inside the activation region."""
-  w = synthetic.make_weights(9, 1, False, num_mixer_blocks=2, backbone=False)
-  e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=_ffi.TAPIR_BF16)
-  x = np.random.default_rng(T + N).standard_normal((N, T, 535)).astype(np.float32)
-  x16 = _mixer(e, x, 6)
-  ref16, _ = O.pips_mlp_mixer(w, x, num_blocks=2, rnd=O.bf16_round)
-  d = np.abs(x16 - ref16)
-  assert np.isfinite(x16).all() and d.max() < 4e-3 and np.median(d) < 1e-4, (d.max(), np.median(d))
-  e.close()
-
-
 def test_wide_fused_mixer_needs_bf16():
   w = synthetic.make_weights(3, 1, False, num_mixer_blocks=1, backbone=False)
   e = EmuEngine(w, pyramid_level=1, num_mixer_blocks=1, initial_resolution=(64, 64))   # f32 build
@@ -137,8 +96,7 @@ def test_wide_fused_mixer_needs_bf16():
   e.close()
 
 
-@pytest.mark.parametrize('mode,dtype,T,Q', [(2, _ffi.TAPIR_F32, 20, 3), (2, _ffi.TAPIR_BF16, 33, 2), (3, _ffi.TAPIR_BF16, 40, 3),
-                                           (5, _ffi.TAPIR_BF16, 24, 2)])
+@pytest.mark.parametrize('mode,dtype,T,Q', [(2, _ffi.TAPIR_F32, 20, 3), (2, _ffi.TAPIR_BF16, 33, 2), (3, _ffi.TAPIR_BF16, 40, 3)])
 def test_fused_state_update_is_bit_identical(mode, dtype, T, Q):
   """refine_pips's state update (tapir_model.py:613-623, 1026-1039: pos / occ / expd / feats, the per-iteration
   output slices, the reset after a level) applied by the output stage of the track-resident mixer kernels

@@ -323,12 +323,8 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (512, 48), 
       modes.append((2, 'fused'))
     if model.dtype == 'bfloat16' and T > 16:
       modes.append((3, 'fused_wide'))
-    if model.dtype == 'bfloat16' and 16 < T <= 48 and lib.tapir_debug_set_mixer_mode(ctx, 5) == 0:
-      modes.append((5, 'fused_half_cu'))          # (-DTAPIR_EXPERIMENTS builds: mixer_fused_half.hpp)
-    if model.dtype == 'bfloat16' and 16 < T <= 48 and lib.tapir_debug_set_mixer_mode(ctx, 6) == 0:
-      modes.append((6, 'fused_16_waves'))         # (-DTAPIR_EXPERIMENTS builds: mixer_fused_x16.hpp)
     if model.dtype == 'bfloat16' and T <= 48 and lib.tapir_debug_set_mixer_mode(ctx, 7) == 0:
-      modes.append((7, 'fused_fp8_weights'))      # (-DTAPIR_EXPERIMENTS builds: mixer_fused_fp8w.hpp; diff vs separate = quantisation)
+      modes.append((7, 'fused_fp8_weights'))      # (-DTAPIR_EXPERIMENTS builds: experiments/mixer_fused_fp8w.hpp; diff vs separate = quantisation)
     if os.environ.get('KBENCH_PAIRSIM') and model.dtype == 'bfloat16' and T == 48 and N % 2 == 0:
       modes.append((4, 'pair_sim_TIMING_ONLY'))   # (-DTAPIR_EXPERIMENTS builds; meaningless outputs)
     for mode, name in modes:
@@ -356,8 +352,9 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (512, 48), 
 
 def bench_cv(model, reps, results):
   """cost-volume stage (tapir_tracks_from_cost_volume: casts + einsum + heads) at config 2 and at one
-  rank's share of config 3, A/B: mode 1 = einsum GEMM into a workspace + heads kernel, mode 0 = the
-  fused kernel (no volume in HBM)."""
+  rank's share of config 3, A/B: mode 1 = einsum GEMM into a workspace + heads kernel, mode 2 = the
+  fused kernel in its pixel-tiled form (costvol_fused.hpp, no volume in HBM), mode 0 = automatic = the
+  row-streamed fused kernel (costvol_rows.hpp: every wave owns whole maps)."""
   lib, ctx = model._lib, model._ctx
   dev = model.device
   stream = model._stream()
@@ -367,7 +364,7 @@ def bench_cv(model, reps, results):
     qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
     qp = torch.cat([torch.randint(0, T, (1, Q, 1), generator=g).float(), torch.rand(1, Q, 2, generator=g) * 256], -1).to(dev)
     outs = {}
-    for mode, name in ((1, 'workspace'), (0, 'fused')):
+    for mode, name in ((1, 'workspace'), (2, 'fused_tiled'), (0, 'fused')):
       assert lib.tapir_debug_set_cv_mode(ctx, mode) == 0
       pts = torch.empty(1, Q, T, 2, device=dev); occ = torch.empty(1, Q, T, device=dev); expd = torch.empty(1, Q, T, device=dev)
 
@@ -379,17 +376,18 @@ def bench_cv(model, reps, results):
       outs[name] = (pts.clone(), occ.clone())
       row = dict(kernel=f'cost_volume_stage_{name}', Q=Q, T=T, dtype=model.dtype, **t,
                  ns_per_map=round(t['med_us'] * 1e3 / (Q * T), 1))
-      if name == 'fused':
-        d = torch.linalg.norm(outs['fused'][0] - outs['workspace'][0], dim=-1)
+      if name != 'workspace':
+        d = torch.linalg.norm(outs[name][0] - outs['workspace'][0], dim=-1)
         row['tracks_median_diff_px'] = float(d.median()); row['tracks_frac_within_0.05px'] = float((d < 0.05).float().mean())
-        row['occ_max_diff'] = float((outs['fused'][1] - outs['workspace'][1]).abs().max())
+        row['occ_max_diff'] = float((outs[name][1] - outs['workspace'][1]).abs().max())
       results.append(row)
       print(json.dumps(row), flush=True)
     assert lib.tapir_debug_set_cv_mode(ctx, 0) == 0
 
 
 def trace_cv_fused(model):
-  """per-phase shader-cycle totals (wave 0) of the fused cost-volume kernel, TRACE build (-DTAPIR_EXPERIMENTS)"""
+  """per-phase shader-cycle totals of the row-streamed fused cost-volume kernel (costvol_rows.hpp), every wave of every
+  workgroup; TRACE build (tapnet_amd/csrc/build.sh --exp, TAPIR_HIP_LIB=tools/bin/libtapir_hip_exp.so)"""
   lib, ctx = model._lib, model._ctx
   dev = model.device
   Q, T = 256, 48
@@ -397,8 +395,9 @@ def trace_cv_fused(model):
   grid = torch.nn.functional.normalize(torch.randn(1, T, 32, 32, 256, generator=g), dim=-1).to(dev)
   qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
   pts = torch.empty(1, Q, T, 2, device=dev); occ = torch.empty(1, Q, T, device=dev); expd = torch.empty(1, Q, T, device=dev)
-  nwg = T * (Q // 16)
-  buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+  form = int(os.environ.get('TAPIR_CV_FORM', '0'))
+  nwg, nwv = T * (Q // (8 if form == 1 else 16)), (16 if form == 0 else 8)
+  buf = torch.zeros(nwg * nwv * 8, dtype=torch.int64, device=dev)
   for it in range(2):
     assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
     rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), None, 1, Q, T, 32, 32,
@@ -406,13 +405,13 @@ def trace_cv_fused(model):
     assert rc == 0, lib.tapir_last_error(ctx)
     torch.cuda.synchronize()
   lib.tapir_debug_set_trace(ctx, None)
-  t = buf.view(nwg, 8).double().cpu().numpy()
-  names = ['zero fill + einsum + constants', 'barrier (map start)', 'conv1 + conv2P (MFMA f32)', 'barrier', 'logits + argmax + softmax sums',
-           'occlusion conv (MFMA)', 'barrier', 'tail']
+  t = buf.view(nwg * nwv, 8).double().cpu().numpy()
+  names = {0: 'contraction + zero fill + constants', 1: 'barrier (cost maps complete)', 2: 'conv1 + relu + ring + conv2 (MFMA f32)',
+           4: 'logit chain (DPP, bpermute, store)', 5: 'occlusion conv rows (MFMA)', 3: 'soft arg max + head tail'}
   tot = t.sum(-1).mean()
-  print(f'fused cost-volume phase trace ({model.dtype}): wave 0, mean over {nwg} workgroups of 16 maps; total {tot:.0f} cycles')
-  for k, nm in enumerate(names):
-    print(f'  {nm:34s} {t[:, k].mean():10.0f} cycles  {100 * t[:, k].mean() / tot:5.1f} %   per map {t[:, k].mean() / 16:8.0f}')
+  print(f'row-streamed cost-volume phase trace ({model.dtype}): form {form}: mean over {nwg} workgroups x {nwv} waves ({2 if form == 2 else 1} map(s) per wave); total {tot:.0f} cycles per wave')
+  for k in (0, 1, 2, 4, 5, 3):
+    print(f'  {names[k]:42s} {t[:, k].mean():10.0f} cycles  {100 * t[:, k].mean() / tot:5.1f} %   waves min/max {t[:, k].min():.0f}/{t[:, k].max():.0f}')
 
 
 def trace_fused(model):
