@@ -19,9 +19,9 @@ all-gather of the feature grids, query-sharded hot path.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
 ``roofline`` (dominant kernel class -- the track-resident fused mixer kernel at this
 workload -- measured with the dispatch's own timestamps inside the timed region),
-``cpu_baseline`` (numpy oracle + torch-CPU backbone on a bounded sample, timed here;
-plus the reference's own torch CPU path as measured in the build container,
-profiles/r02_reference_torch_cpu_tapir.json) and ``accuracy`` (bf16 build vs the
+``cpu_baseline`` (the reference's own torch CPU path timed here on the full workload, kind "reference": from
+/root/reference in the build container, from the copy oracle/stage_ref.py stages under oracle/_ref on the GPU box;
+the numpy port of the oracle next to it as ``port``) and ``accuracy`` (bf16 build vs the
 oracle-verified f32 build on the same clip, outside the timed region).  With N > 1
 ranks the line also carries ``one_clip_sharded``: the same clip tracked by all ranks
 together (frame-sharded backbone, all-gather of the grids, query-sharded hot path).
@@ -84,15 +84,15 @@ def self_launch(args):
 
 
 def reference_torch_cpu(args, kw, weights, video_np, qpts_np):
-  """The reference's own CPU path (tapnet/torch/tapir_model.py TAPIR.forward; JAX is not installable
-  offline) at the FULL workload on this host's cores: 1 warm-up + 1 timed call (~12 s each on 8 cores).
-  Only where the reference tree exists ($TAPNET_REFERENCE or /root/reference: the build container)."""
-  root = os.environ.get('TAPNET_REFERENCE', '/root/reference')
-  if not os.path.isdir(os.path.join(root, 'tapnet', 'torch')):
-    return None
+  """The reference's own CPU path (tapnet/torch/tapir_model.py TAPIR.forward; JAX is not installable offline) at
+  the FULL workload on this host's cores: 1 warm-up + 1 timed call (~12 s each on 8 cores).  The reference tree is
+  /root/reference in the build container; on the GPU box it is the copy oracle/stage_ref.py staged into the
+  git-ignored oracle/_ref/ (shipped with the push like the built .so files).  None when neither exists."""
   try:
-    from oracle.ref_import import import_reference
-    tm, _, _ = import_reference()
+    from oracle import ref_import
+    if not ref_import.reference_available():
+      return None
+    tm, _, _ = ref_import.import_reference()
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     model = tm.TAPIR(pyramid_level=kw['pyramid_level'], extra_convs=kw['extra_convs'],
@@ -106,16 +106,21 @@ def reference_torch_cpu(args, kw, weights, video_np, qpts_np):
         t0 = time.perf_counter()
         model(v, q)
         times.append(time.perf_counter() - t0)
-    return dict(value=round(qpts_np.shape[1] / times[-1], 3), unit='points/s', cores=cores, kind='reference',
-                seconds=round(times[-1], 2), measured='live on this host (1 warm-up + 1 timed call, full workload)')
+    T, Q = video_np.shape[1], qpts_np.shape[1]
+    return dict(value=round(Q / times[-1], 3), unit='points/s', cores=cores, kind='reference',
+                sample=f'the FULL workload ({args.size}x{args.size}x{T} clip, {Q} queries, {args.model} kwargs): '
+                       'tapnet/torch/tapir_model.py TAPIR.forward of the reference (its torch twin; the JAX path '
+                       'needs jax, not installable offline), f32, torch CPU on all host cores, 1 warm-up + 1 timed call',
+                seconds=round(times[-1], 2), warmup_seconds=round(times[0], 2),
+                source=('oracle/_ref (staged from the reference tree by oracle/stage_ref.py)'
+                        if ref_import.reference_is_staged_copy() else ref_import.REFERENCE_ROOT))
   except Exception as e:   # the reference is not part of the product: never fail the bench over it
     return dict(error=f'{type(e).__name__}: {e}')
 
 
-def cpu_baseline(args, kw, weights, video, qpts):
-  """The oracle (numpy port of the reference hot path) + the backbone restatement on torch-CPU,
-  timed on this host's cores on a bounded sample and extrapolated linearly to the workload:
-  backbone cost is per frame, hot-path cost per query (both are independent units)."""
+def port_cpu(args, kw, weights, video, qpts, sf, sq):
+  """The oracle (numpy port of the reference hot path) + the backbone restatement on torch-CPU, timed on a bounded
+  sample and extrapolated linearly: backbone cost is per frame, hot-path cost per query (independent units)."""
   from oracle import backbone_torch, tapir_oracle as O
   cores = min(os.cpu_count() or 1, 32)   # more threads only add contention for these sizes
   torch.set_num_threads(cores)
@@ -125,7 +130,7 @@ def cpu_baseline(args, kw, weights, video, qpts):
   except Exception:
     pass
   T, Q = video.shape[1], qpts.shape[1]
-  sf, sq = min(args.cpu_sample_frames, T), min(args.cpu_sample_queries, Q)
+  sf, sq = min(sf, T), min(sq, Q)
   bb = backbone_torch.TorchBackbone(weights, kw['extra_convs'])
   frames = torch.as_tensor(video[0, :sf])
   t0 = time.perf_counter()
@@ -143,31 +148,40 @@ def cpu_baseline(args, kw, weights, video, qpts):
                      softmax_temperature=kw['softmax_temperature'])
   t_hot = (time.perf_counter() - t0) / sq * Q
   total = t_bb + t_hot
-  out = dict(value=round(Q / total, 3), unit='points/s', cores=cores, kind='port',
-             sample=f'backbone (torch-CPU restatement) on {sf}/{T} frames + numpy oracle hot path '
-                    f'on {sq}/{Q} queries x {T} frames, extrapolated per-frame / per-query',
-             backbone_s=round(t_bb, 2), hot_path_s=round(t_hot, 2))
-  # the reference's own CPU path (tapnet/torch/tapir_model.py; JAX is not installable offline): timed
-  # live where the reference tree exists; it cannot travel to the GPU box, where the number measured in
-  # the build container (oracle/time_reference_cpu.py) is quoted instead and LABELLED as static
-  live = reference_torch_cpu(args, kw, weights, video, qpts)
-  if live is not None:
-    out['reference_torch'] = live
-  else:
-    ref = os.path.join(ROOT, 'profiles', f'r02_reference_torch_cpu_{args.model}.json')
-    if os.path.exists(ref) and (T, Q, args.size) == (48, 256, 256):
-      try:
-        r = json.load(open(ref))
-        out['reference_torch'] = dict(value=r['points_per_s'], unit='points/s', cores=r['cores'],
-                                      cpu=r['cpu'], median_s=r['median_s'], host=r['host'],
-                                      measured='STATIC: not timed in this run (no reference tree on this host); '
-                                               'quoted from ' + os.path.relpath(ref, ROOT),
-                                      artefact=os.path.relpath(ref, ROOT))
-      except Exception:
-        pass
-  out['note'] = ('kind=port is the numpy oracle, ~3x slower than the reference\'s torch CPU path: no GPU/CPU '
-                 'speed-up should be quoted against it; reference_torch is the comparable CPU number')
-  return out
+  return dict(value=round(Q / total, 3), unit='points/s', cores=cores, kind='port',
+              sample=f'backbone (torch-CPU restatement) on {sf}/{T} frames + numpy oracle hot path '
+                     f'on {sq}/{Q} queries x {T} frames, extrapolated per-frame / per-query',
+              backbone_s=round(t_bb, 2), hot_path_s=round(t_hot, 2))
+
+
+def cpu_baseline(args, kw, weights, video, qpts):
+  """`cpu_baseline` of the JSON line: the REFERENCE's own CPU path timed on this host's cores (kind "reference")
+  wherever the reference's torch twin can be imported -- /root/reference in the build container, the staged copy
+  under oracle/_ref on the GPU box -- with the numpy port of the oracle as a bounded secondary number (`port`); only
+  when neither tree exists is the port the primary value (kind "port", ~3x slower than the reference's torch path:
+  no speed-up should be quoted against it).  The host's torch thread counts are restored afterwards."""
+  threads = torch.get_num_threads()
+  try:
+    ref = reference_torch_cpu(args, kw, weights, video, qpts)
+    if ref is not None and 'error' not in ref:
+      out = dict(ref)
+      # the port next to it, on a small sample (a consistency check of the oracle's cost model, ~10 s)
+      out['port'] = port_cpu(args, kw, weights, video, qpts, min(args.cpu_sample_frames, 6), min(args.cpu_sample_queries, 16))
+      return out
+    out = port_cpu(args, kw, weights, video, qpts, args.cpu_sample_frames, args.cpu_sample_queries)
+    if ref is not None:
+      out['reference_error'] = ref['error']
+    out['note'] = ('kind=port is the numpy oracle, ~3x slower than the reference\'s torch CPU path (12.4 s per clip '
+                   'on 8 cores, profiles/r02_reference_torch_cpu_tapir.json): the reference tree was not available '
+                   'here (run oracle/stage_ref.py in the build container)')
+    return out
+  finally:
+    torch.set_num_threads(threads)
+    try:
+      import threadpoolctl
+      threadpoolctl.threadpool_limits(threads)
+    except Exception:
+      pass
 
 
 def accuracy_vs_f32(kw, weights, dev, video, qpts, out16):

@@ -224,6 +224,20 @@ int tapir_inorm_relu(tapir_ctx* ctx, const void* x, const float* part, const flo
                      const float* beta, float* ss, void* y, void* y_sub, int N, int H, int W, int C,
                      int slabs, int per_s, int out_h, int out_w, void* stream);
 int tapir_l2_normalize(tapir_ctx* ctx, const void* x, float* out, long pixels, int C, void* stream);
+/* The same, and -- bf16 build -- the normalised values once more in the hot path's operand type: row-major
+ * [pixels, C] bf16 (out_op) and, for the 256-channel low-res map, in the cost-volume kernel's tile order (out_tiled:
+ * [frame][tile of 16 cells][32 chunks of 8 channels][16 cells][8], frames of cells_per_frame cells, zero-initialised
+ * by the caller, ((cells + 15) / 16) * 16 * 256 elements per frame).  Either may be NULL.  These are the copies
+ * tapir_estimate_trajectories / tapir_tracks_from_cost_volume otherwise make themselves by re-reading the f32 grids
+ * (151 MB per 48-frame 256 x 256 clip); tapir_set_staged_grid tells the context that they exist. */
+int tapir_l2_normalize_staged(tapir_ctx* ctx, const void* x, float* out, void* out_op, void* out_tiled, long pixels,
+                              int C, int cells_per_frame, void* stream);
+/* Registers operand-type copies of an f32 feature grid (written by tapir_l2_normalize_staged, same stream order) for
+ * the calls that follow: where a call is handed grid_f32 it reads grid_op / grid_tiled instead of casting.  The caller
+ * guarantees that the copies match the f32 grid; tapir_clear_staged_grids forgets all of them (the Python layer
+ * registers the borrowed grids of ONE TAPIR.__call__ and clears them before it returns).  bf16 build only. */
+int tapir_set_staged_grid(tapir_ctx* ctx, const float* grid_f32, const void* grid_op, const void* grid_tiled);
+int tapir_clear_staged_grids(tapir_ctx* ctx);
 
 /* The convolutions of the ResNet blocks (tapnet/models/resnet.py:185-257: self.conv_0 / self.conv_1 /
  * self.proj_conv of BlockV2 with the InstanceNorm + relu in front of them, :241-243 / :248-249, and the

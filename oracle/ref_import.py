@@ -16,10 +16,20 @@ import sys
 import types
 
 REFERENCE_ROOT = os.environ.get("TAPNET_REFERENCE", "/root/reference")
+# the GPU box has no /root/reference: oracle/stage_ref.py (run by __graft_entry__.build() in the build container)
+# stages the reference's torch twin into the git-ignored oracle/_ref/, which travels with the push
+STAGED_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+if not os.path.isdir(os.path.join(REFERENCE_ROOT, "tapnet", "torch")) and \
+    os.path.isfile(os.path.join(STAGED_ROOT, "tapnet", "torch", "tapir_model.py")):
+  REFERENCE_ROOT = STAGED_ROOT
 
 
 def reference_available() -> bool:
   return os.path.isdir(os.path.join(REFERENCE_ROOT, "tapnet", "torch"))
+
+
+def reference_is_staged_copy() -> bool:
+  return REFERENCE_ROOT == STAGED_ROOT
 
 
 def _einshape_adapter():

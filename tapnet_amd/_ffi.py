@@ -88,6 +88,9 @@ PROTOTYPES = {
     'tapir_inorm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'tapir_l2_normalize': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    'tapir_l2_normalize_staged': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    'tapir_set_staged_grid': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tapir_clear_staged_grids': (c_int, [c_void_p]),
     'tapir_conv_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'tapir_conv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     'tapir_conv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -62,6 +62,7 @@ class Backbone:
     """engine: (ctypes library, context) of libtapir_hip.so -- required."""
     self.device = torch.device(device)
     self.engine = engine
+    self.last_staged = None
     if self.device.type != 'cuda' or engine is None:
       raise RuntimeError('tapnet_amd.backbone.Backbone needs a ROCm GPU and the HIP engine '
                          '(libtapir_hip.so); there is no CPU path')
@@ -400,17 +401,36 @@ class Backbone:
     y1 = self._hip_conv(y, p + 'conv_1', 1, 1)
     return y1, self._hip_stats(y1, shortcut)   # y1 += shortcut, fused with the next norm's statistics
 
-  def _hip_l2norm(self, x_nhwc, out=None):
+  def _hip_l2norm(self, x_nhwc, out=None, op=None, tiled=None):
+    """op / tiled (bf16 build): the normalised map once more in the hot path's operand type -- row-major bf16 and
+    (256 channels) the cost-volume kernel's tile order -- so that the hot path does not re-read the f32 grids to cast
+    them (tapir_l2_normalize_staged)."""
     lib, ctx = self.engine
     n, h, w, c = x_nhwc.shape
     if out is None:
       out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
     assert out.shape == (n, h, w, c) and out.is_contiguous() and out.dtype == torch.float32
-    self._check(lib.tapir_l2_normalize(ctx, x_nhwc.data_ptr(), out.data_ptr(), n * h * w, c,
-                                       self._stream()), 'tapir_l2_normalize')
+    if op is None:
+      self._check(lib.tapir_l2_normalize(ctx, x_nhwc.data_ptr(), out.data_ptr(), n * h * w, c,
+                                         self._stream()), 'tapir_l2_normalize')
+    else:
+      assert op.is_contiguous() and op.dtype == torch.bfloat16 and op.numel() == out.numel()
+      assert tiled is None or (tiled.is_contiguous() and tiled.shape[0] == n)
+      self._check(lib.tapir_l2_normalize_staged(ctx, x_nhwc.data_ptr(), out.data_ptr(), op.data_ptr(),
+                                                tiled.data_ptr() if tiled is not None else None, n * h * w, c, h * w,
+                                                self._stream()), 'tapir_l2_normalize_staged')
     return out
 
-  def _features_hip(self, frames_nhwc, out_low=None, out_hi=None):
+  @staticmethod
+  def staged_like(low, hi):
+    """bf16 companions of a pair of f32 grids for _hip_l2norm: (low row-major, low in tile order, hi row-major).  The
+    tile-order buffer is zeroed once: cells past the end of a frame's last tile of 16 are never written."""
+    n, h, w, c = low.shape
+    return (torch.empty_like(low, dtype=torch.bfloat16),
+            torch.zeros((n, ((h * w + 15) // 16) * 16 * c), dtype=torch.bfloat16, device=low.device),
+            torch.empty_like(hi, dtype=torch.bfloat16))
+
+  def _features_hip(self, frames_nhwc, out_low=None, out_hi=None, staged=None):
     st = None
     if self._hip_now and 'stem' in self.hip_convs and self._stem_ws is not None:
       import ctypes
@@ -448,6 +468,8 @@ class Backbone:
       # workgroups per launch; the library's split-K kernels win there)
       xe = self._extra_convs_hip(x) if (self.extra_convs_mode == 'hip' and self._hip_now) else None
       x = xe if xe is not None else self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    if staged is not None and x.shape[-1] == 256:
+      return self._hip_l2norm(x, out_low, staged[0], staged[1]), self._hip_l2norm(unit1, out_hi, staged[2])
     return self._hip_l2norm(x, out_low), self._hip_l2norm(unit1, out_hi)
 
   # -- public ---------------------------------------------------------------
@@ -461,6 +483,7 @@ class Backbone:
     scratch memory, so such calls are launched eagerly (a captured graph keeps full-clip static buffers).
     global_frames: frame count of the whole clip when this call sees one rank's shard of it."""
     n, H, W = frames_nhwc.shape[:3]
+    self.last_staged = None   # borrow=True, bf16 engine: (low16, low_tiled, hi16) written next to the returned f32 grids
     self._hip_now = self._use_hip_convs(max(n, int(global_frames or 0)))
     half = lambda v: -(-v // 2)
     last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
@@ -502,31 +525,40 @@ class Backbone:
       if 'graph' not in ent and not ent.get('failed') and ent['seen'] >= 3:
         ent['in'] = frames_nhwc.contiguous().clone()
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
+        ent['staged'] = self.staged_like(low, hi) if self._stage_ok(low) else None
         torch.cuda.synchronize(self.device)
         try:
           g = torch.cuda.CUDAGraph()
           with torch.cuda.graph(g):   # (the side streams fork from and join the capturing stream)
-            self._run_groups(ent['in'], ent['low'], ent['hi'], bounds, streams)
+            self._run_groups(ent['in'], ent['low'], ent['hi'], bounds, streams, ent['staged'])
           ent['graph'] = g
         except RuntimeError as e:     # e.g. another thread touched the device during the capture
           import warnings
           warnings.warn(f'tapnet_amd.backbone: hipGraph capture failed ({e}); launching eagerly')
           ent['failed'] = True
-          for k in ('in', 'low', 'hi'):
+          for k in ('in', 'low', 'hi', 'staged'):
             ent.pop(k, None)
           torch.cuda.synchronize(self.device)
       if 'graph' in ent:
         ent['in'].copy_(frames_nhwc)
         ent['graph'].replay()
         if borrow:
+          self.last_staged = ent['staged']
           return ent['low'], ent['hi']
         low.copy_(ent['low'])
         hi.copy_(ent['hi'])
         return low, hi
-    self._run_groups(frames_nhwc, low, hi, bounds, streams)
+    staged = self.staged_like(low, hi) if (borrow and self._stage_ok(low)) else None
+    self._run_groups(frames_nhwc, low, hi, bounds, streams, staged)
+    self.last_staged = staged
     return low, hi
 
-  def _run_groups(self, frames_nhwc, low, hi, bounds, streams):
+  def _stage_ok(self, low):
+    """operand-type copies from the L2-normalise kernel: bf16 engine, HIP path, 256-channel low-res map"""
+    return (self.dtype == torch.bfloat16 and self.engine is not None and low.shape[-1] == 256
+            and os.environ.get('TAPIR_STAGE_GRIDS', '1') != '0')
+
+  def _run_groups(self, frames_nhwc, low, hi, bounds, streams, staged=None):
     cur = torch.cuda.current_stream(self.device)
     while len(self._side_streams) < streams - 1:
       self._side_streams.append(torch.cuda.Stream(self.device))
@@ -542,7 +574,8 @@ class Backbone:
           st.wait_event(fork)
         self._lane = lane
         with torch.cuda.stream(st):
-          self._features_hip(frames_nhwc[s:e], low[s:e], hi[s:e])
+          self._features_hip(frames_nhwc[s:e], low[s:e], hi[s:e],
+                             None if staged is None else tuple(t[s:e] for t in staged))
       for st in self._side_streams[:streams - 1]:
         cur.wait_stream(st)
     finally:

@@ -306,7 +306,13 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_relu_kernel(NormApplyArgs 
   }
 }
 
-struct L2Args { const void* x; float* out; long pixels; int C; };
+struct L2Args {
+  const void* x; float* out; long pixels; int C;
+  // bf16 build, optional: the same values rounded to bf16 row-major [pixels, C] (the hot path's pyramid level) and,
+  // for the 256-channel map, in the cost-volume kernel's tile order (pips.hpp PoolArgs::tiled) -- what
+  // pool_cast_kernel would otherwise produce by re-reading the f32 grids (151 MB per 48-frame clip)
+  void* out_op; void* out_tiled; int cells;   // cells = h * w of one frame (tile order is per frame)
+};
 
 // x / sqrt(max(sum_c x^2, 1e-12)) per pixel (tapir_model.py:709-720), f32 out.
 template <typename T>
@@ -325,8 +331,21 @@ __global__ __launch_bounds__(NORM_THREADS) void l2norm_kernel(L2Args a) {
     const float r = 1.0f / sqrtf(fmaxf(s, 1e-12f));
     float* o = a.out + p * a.C + cg * EPT;
 #pragma unroll
+    for (int e = 0; e < EPT; ++e) v[e] *= r;
+#pragma unroll
     for (int e = 0; e < EPT; e += 4)
-      *reinterpret_cast<float4*>(o + e) = make_float4(v[e] * r, v[e + 1] * r, v[e + 2] * r, v[e + 3] * r);
+      *reinterpret_cast<float4*>(o + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+    if (sizeof(T) == 2 && a.out_op != nullptr) {       // EPT = 8: one 16-byte chunk per lane
+      uint4 q;
+      q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]);
+      q.z = pack_bf16x2(v[4 % EPT], v[5 % EPT]); q.w = pack_bf16x2(v[6 % EPT], v[7 % EPT]);
+      reinterpret_cast<uint4*>(a.out_op)[p * G + cg] = q;
+      if (a.out_tiled != nullptr) {                    // C = 256: chunk cg of cell (p % cells) of frame p / cells
+        const long f = p / a.cells;
+        const int cell = (int)(p - f * a.cells), ntile = (a.cells + 15) >> 4;
+        reinterpret_cast<uint4*>(a.out_tiled)[((f * ntile + (cell >> 4)) * 32 + cg) * 16 + (cell & 15)] = q;
+      }
+    }
   }
 }
 

@@ -601,11 +601,13 @@ inline bool cv_rows_supported(int h, int w) {
   return (h + rps - 1) / rps <= CVR_ZREG;
 }
 
-// Forms of the row-streamed kernel (bf16 build; the f32 parity build always runs 8 maps on 8 waves):
-//   0: 16 maps, 16 waves (one map per wave; ONE workgroup per CU, four waves per SIMD)
-//   1: 8 maps, 8 waves   (one map per wave; two workgroups per CU: the contraction of one under the rows of the other,
-//                         at twice the grid reads)
-//   2: 16 maps, 8 waves  (two maps per wave; one workgroup per CU, two waves per SIMD)
+// Forms of the row-streamed kernel (bf16 build; the f32 parity build always runs 8 maps on 8 waves), measured at
+// 256 / 1024 queries x 48 frames (cost-volume stage, profiles/r04_kbench_cv_forms.txt):
+//   1 (default): 8 maps, 8 waves   one map per wave; two workgroups per CU: the contraction of one runs under the rows
+//                                   of the other, at twice the grid reads                            210 / 652 us
+//   0: 16 maps, 16 waves            one map per wave; ONE workgroup per CU, four waves per SIMD      225 / 752 us
+//   2: 16 maps, 8 waves             two maps per wave; one workgroup per CU, two waves per SIMD       234 / 785 us
+// (the pixel-tiled kernel of costvol_fused.hpp: 365 / 1343 us)
 template <typename TA, int QPW, int WAVES>
 inline void launch_cv_rows_q(const CvFusedArgs& a, hipStream_t s, int heads) {
   const int qpt = QPW / heads;
@@ -631,7 +633,7 @@ inline void launch_cv_rows_q(const CvFusedArgs& a, hipStream_t s, int heads) {
 }
 
 template <typename TA>
-inline void launch_cv_rows(const CvFusedArgs& a, hipStream_t s, int heads = 1, int form = 0) {
+inline void launch_cv_rows(const CvFusedArgs& a, hipStream_t s, int heads = 1, int form = 1) {
   if constexpr (sizeof(TA) == 2) {
     if (heads == 1 && form == 0) { launch_cv_rows_q<TA, 16, 16>(a, s, heads); return; }
     if (form == 2) { launch_cv_rows_q<TA, 16, 8>(a, s, heads); return; }

@@ -82,7 +82,7 @@ struct tapir_ctx {
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   bool cv_tiled = true;                           // row-streamed cost volume, bf16: contraction operand in tile order (TAPIR_CV_TILED=0: row-major, A/B)
-  int cv_form = 0;                                // row-streamed cost volume: maps x waves per workgroup (costvol_rows.hpp; TAPIR_CV_FORM, A/B)
+  int cv_form = 1;                                // row-streamed cost volume: maps x waves per workgroup (costvol_rows.hpp; TAPIR_CV_FORM, A/B)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
@@ -90,6 +90,8 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
+  struct Staged { const float* f32; const void* op; const void* tiled; };
+  std::vector<Staged> staged;       // operand-type copies the caller's backbone wrote next to its f32 grids (tapir_set_staged_grid)
   DevBuf grid_tiled;                 // bf16 low-res grid in the cost-volume kernel's operand order (pips.hpp: PoolArgs::tiled)
   const float* tiled_src = nullptr;  // which grid it holds (valid together with cast_src[1])
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
@@ -524,6 +526,12 @@ __global__ void iter0_kernel(Iter0Args a) {
 // ----------------------------------------------------------------------------
 // stage drivers (templated on the operand type)
 // ----------------------------------------------------------------------------
+// operand-type copy registered for this f32 grid (tapir_set_staged_grid), or null
+inline const tapir_ctx::Staged* find_staged(const tapir_ctx* c, const float* grid) {
+  for (const auto& st : c->staged) if (st.f32 == grid) return &st;
+  return nullptr;
+}
+
 // bytes of the tiled bf16 copy of a [frames, h*w, 256] grid
 inline size_t tiled_bytes(long frames, int h, int w) { return (size_t)frames * ((h * w + 15) / 16) * 16 * kLowresDim * 2; }
 
@@ -605,7 +613,13 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   // row-streamed kernel, bf16: the grid also in the operand order of its contraction (one cast kernel writes both)
   const bool rows = cv_rows_supported(h, w) && c->cv_mode == 0;
   const bool tiled = rows && sizeof(TA) == 2 && c->cv_tiled;
-  if (sizeof(TA) == 2) {   // stage bf16 copies of both operands
+  const void* tiled_op = nullptr;
+  const tapir_ctx::Staged* stg = sizeof(TA) == 2 ? find_staged(c, grid) : nullptr;
+  if (stg != nullptr && (!tiled || stg->tiled != nullptr)) {
+    // the backbone's L2-normalise kernel already wrote the bf16 copies (row-major and, for this kernel, tile order)
+    TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
+    qf_op = c->qf_cast.p; grid_op = stg->op; tiled_op = stg->tiled;
+  } else if (sizeof(TA) == 2) {   // stage bf16 copies of both operands
     TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
     if (c->cast_src[1] != grid || (tiled && c->tiled_src != grid)) {
       TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s, tiled ? &c->grid_tiled : nullptr));
@@ -613,12 +627,13 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
       if (tiled) c->tiled_src = grid;
     }
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
+    if (tiled) tiled_op = c->grid_tiled.p;
   }
   if (cv_fused_supported(h, w) && c->cv_mode != 1) {
     // one kernel: contraction on the matrix cores into LDS + heads; no volume in HBM
     CvFusedArgs fa{};
     fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = tapnet ? c->tapnet_cvw : c->cvw; fa.qpts = qpts_init;
-    fa.grid_tiled = tiled ? c->grid_tiled.p : nullptr;
+    fa.grid_tiled = tiled ? tiled_op : nullptr;
     fa.tapnet = tapnet ? 1 : 0;
     fa.points = points; fa.occ = occ; fa.expd = expd;
     fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w;
@@ -891,15 +906,18 @@ int prepare_level(tapir_ctx* c, const float* hires, int hh, int hw_, const float
   if (sizeof(TA) == 4) {
     lg->grid[0] = hires; lg->grid[1] = lowres;
   } else {
-    if (c->cast_src[0] != hires) {
+    const tapir_ctx::Staged* sh = find_staged(c, hires);
+    const tapir_ctx::Staged* sl = find_staged(c, lowres);
+    if (sh == nullptr && c->cast_src[0] != hires) {
       TRY(cast_or_pool<TA>(c, hires, frames, hh, hw_, kHiresDim, 0, c->grid_cast[0], s));
       c->cast_src[0] = hires;
     }
-    if (c->cast_src[1] != lowres) {
+    if (sl == nullptr && c->cast_src[1] != lowres) {
       TRY(cast_or_pool<TA>(c, lowres, frames, lh, lw, kLowresDim, 0, c->grid_cast[1], s));
       c->cast_src[1] = lowres;
     }
-    lg->grid[0] = c->grid_cast[0].p; lg->grid[1] = c->grid_cast[1].p;
+    lg->grid[0] = sh != nullptr ? sh->op : c->grid_cast[0].p;
+    lg->grid[1] = sl != nullptr ? sl->op : c->grid_cast[1].p;
   }
   if (c->cfg.pyramid_level >= 1) {
     if (c->cast_src[2] != lowres) {
@@ -1368,13 +1386,35 @@ int tapir_inorm_relu(tapir_ctx* c, const void* x, const float* part, const float
 }
 
 int tapir_l2_normalize(tapir_ctx* c, const void* x, float* out, long pixels, int C, void* stream) {
+  return tapir_l2_normalize_staged(c, x, out, nullptr, nullptr, pixels, C, 0, stream);
+}
+
+int tapir_set_staged_grid(tapir_ctx* c, const float* grid_f32, const void* grid_op, const void* grid_tiled) {
+  if (!c || !grid_f32 || !grid_op) return TAPIR_ERR_INVALID;
+  if (c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "staged grids: bf16 build only");
+  for (auto& st : c->staged) if (st.f32 == grid_f32) { st.op = grid_op; st.tiled = grid_tiled; return TAPIR_OK; }
+  c->staged.push_back({grid_f32, grid_op, grid_tiled});
+  return TAPIR_OK;
+}
+
+int tapir_clear_staged_grids(tapir_ctx* c) {
+  if (!c) return TAPIR_ERR_INVALID;
+  c->staged.clear();
+  return TAPIR_OK;
+}
+
+int tapir_l2_normalize_staged(tapir_ctx* c, const void* x, float* out, void* out_op, void* out_tiled, long pixels, int C,
+                              int cells_per_frame, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!x || !out || pixels < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (!norm_channels_ok(c, C, 64)) return fail(c, TAPIR_ERR_UNSUPPORTED, "channel count");
+  if ((out_op || out_tiled) && c->cfg.dtype != TAPIR_BF16) return fail(c, TAPIR_ERR_UNSUPPORTED, "operand-type copies: bf16 build only");
+  if (out_tiled && (!out_op || C != kLowresDim || cells_per_frame < 1 || pixels % cells_per_frame != 0))
+    return fail(c, TAPIR_ERR_INVALID, "tile-order copy: 256 channels, whole frames, together with the row-major copy");
   const int ept = c->cfg.dtype == TAPIR_BF16 ? 8 : 4;
   const int PP = NORM_THREADS / (C / ept);
-  L2Args la{x, out, pixels, C};
+  L2Args la{x, out, pixels, C, out_op, out_tiled, cells_per_frame};
   const unsigned grid = (unsigned)std::min<long>((pixels + PP - 1) / PP, 8192);
   if (c->cfg.dtype == TAPIR_BF16)
     hipLaunchKernelGGL((l2norm_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);

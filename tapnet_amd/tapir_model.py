@@ -166,6 +166,7 @@ class TAPIR:
       self.device = torch.device('cuda', torch.cuda.current_device())
 
     self._lib = _ffi.load_library()
+    self._staged = []   # (f32 grid, bf16 copy, tile-order copy) of the grids borrowed by the running __call__
     self._ctx = ctypes.c_void_p()
     cfg = _ffi.TapirCfg(pyramid_level, num_pips_iter, num_mixer_blocks, int(use_causal_conv),
                         self.softmax_temperature, self.initial_resolution[0],
@@ -318,6 +319,11 @@ class TAPIR:
         low, hi = self._backbone.features(video_resize.reshape(b * t, h, w, c),
                                           self.feature_extractor_chunk_size, borrow=_borrow,
                                           global_frames=None if _global_frames is None else b * _global_frames)
+        if _borrow and self._backbone.last_staged is not None:
+          # bf16 engine: the backbone's L2-normalise kernel also wrote the hot path's operand-type copies
+          low16, low_tiled, hi16 = self._backbone.last_staged
+          self._staged.append((low, low16, low_tiled))
+          self._staged.append((hi, hi16, None))
         latent = low.reshape(b, t, *low.shape[1:])
         hires = hi.reshape(b, t, *hi.shape[1:])
       feature_grid.append(latent)
@@ -536,14 +542,26 @@ class TAPIR:
     if get_query_feats:
       raise ValueError('Get query feats not supported in TAPIR.')
     numpy_out = _is_numpy(video)
+    self._staged = []
     if feature_grids is None:
       feature_grids = self.get_feature_grids(video, is_training, refinement_resolutions, _borrow=True)
     query_features = self.get_query_features(video, is_training, query_points, feature_grids,
                                              refinement_resolutions)
     fg = FeatureGrids(tuple(self._dev(x) for x in feature_grids.lowres),
                       tuple(self._dev(x) for x in feature_grids.hires), feature_grids.resolutions)
-    traj = self.estimate_trajectories(tuple(video.shape[-3:-1]), is_training, fg, query_features,
-                                      self._dev(query_points), query_chunk_size)
+    try:
+      # the borrowed grids' operand-type copies (written by the backbone next to them) stand in for the casts of
+      # the hot path for exactly this call
+      for f32, op, tiled in self._staged:
+        self._check(self._lib.tapir_set_staged_grid(self._ctx, f32.data_ptr(), op.data_ptr(),
+                                                    tiled.data_ptr() if tiled is not None else None),
+                    'tapir_set_staged_grid')
+      traj = self.estimate_trajectories(tuple(video.shape[-3:-1]), is_training, fg, query_features,
+                                        self._dev(query_points), query_chunk_size)
+    finally:
+      if self._staged:
+        self._lib.tapir_clear_staged_grids(self._ctx)
+        self._staged = []
     p = self.num_pips_iter
     conv = (lambda t: t.cpu().numpy()) if numpy_out else (lambda t: t)
 

@@ -218,3 +218,28 @@ def test_config5_shape_vs_oracle():
   idx = np.random.default_rng(5).choice(Q, 8, replace=False)
   ref, clear = _oracle_subset(w, kw, video.shape, _np_grids(fg), qp, idx)
   _check_against(out, ref, idx, clear, 1e-3)
+
+
+def test_staged_grids_equal_the_cast_path():
+  """bf16 build: inside TAPIR.__call__ the backbone's L2-normalise kernel writes the hot path's bf16 copies of the
+  feature grids (row-major + the cost-volume kernel's tile order, tapir_l2_normalize_staged) and the hot path reads
+  them (tapir_set_staged_grid) instead of casting the f32 grids itself.  Same values, same roundings: every output is
+  bit-identical to the call that is handed the f32 grids -- eagerly (first calls) and from the replayed hipGraph,
+  for TAPIR and BootsTAPIR kwargs (pooled pyramid level, ExtraConvs)."""
+  from tapnet_amd import tapir_model
+  for name in ('tapir', 'bootstapir'):
+    kw = KW[name]
+    w = synthetic.make_weights(5, kw['pyramid_level'], kw['extra_convs'])
+    video = torch.as_tensor(_clip()).cuda()
+    qp = torch.as_tensor(synthetic.make_queries(3, 64, T, S, S)).cuda()
+    m = tapir_model.TAPIR(**kw, weights=w, device='cuda:0', dtype='bfloat16')
+    fg = m.get_feature_grids(video)                       # f32 grids only: the hot path casts
+    ref = m(video, False, qp, feature_grids=fg)
+    for call in range(4):                                 # calls 0-1 eager, 2 captures, 3 replays the hipGraph
+      out = m(video, False, qp)
+      assert m._backbone.last_staged is not None, 'the backbone did not stage the operand copies'
+      for k in ('tracks', 'occlusion', 'expected_dist'):
+        assert torch.equal(out[k], ref[k]), (name, call, k)
+      for a, b in zip(out['unrefined_tracks'], ref['unrefined_tracks']):
+        assert torch.equal(a, b), (name, call)
+    del m
