@@ -191,17 +191,89 @@ def make_backbone_case(tm):
   print('backbone', f'{os.path.getsize(path) / 1e6:.2f} MB')
 
 
+# The BENCHMARKED shape (BASELINE.json configs[1]: 256x256x48 clip, 256 queries), both checkpoint kwarg sets: the
+# reference's torch twin end to end, video -> tracks.  OUTPUTS ONLY (the clip, the queries and the weights are
+# seeds): < 0.5 MB per case.  A pin at the headline shape that does not pass through oracle/hk_numpy_shim.py.
+HEADLINE = {
+    'headline_tapir': dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, causal=False,
+                           res=256, video=256, T=48, Q=256, wseed=31),
+    'headline_bootstapir': dict(pyramid_level=1, extra_convs=True, softmax_temperature=10.0, causal=False,
+                                res=256, video=256, T=48, Q=256, wseed=32),
+}
+
+
+def headline_inputs(cfg):
+  """(weights, video, query_points) of a headline case from its seeds (shared with tests/golden_util.py)."""
+  weights = synthetic.make_weights(cfg['wseed'], cfg['pyramid_level'], cfg['extra_convs'])
+  video = synthetic.make_video(cfg['wseed'] + 100, cfg['T'], cfg['video'], cfg['video'])
+  qpts = synthetic.make_queries(cfg['wseed'] + 200, cfg['Q'], cfg['T'], cfg['video'], cfg['video'])
+  return weights, video, qpts
+
+
+def run_headline_case(tm, cfg):
+  weights, video, qpts = headline_inputs(cfg)
+  model = build_reference(tm, cfg, weights)
+  with torch.no_grad():
+    out = model(torch.from_numpy(video), torch.from_numpy(qpts))   # torch twin defaults: query_chunk_size=64
+  res = dict(tracks=np_(out['tracks']), occlusion=np_(out['occlusion']), expected_dist=np_(out['expected_dist']))
+  for i, t in enumerate(out['unrefined_tracks']):
+    res[f'unrefined_tracks_{i}'] = np_(t)
+  return res
+
+
+def make_headline_case(tm, name, cfg, check=False):
+  res = run_headline_case(tm, cfg)
+  path = os.path.join(GOLDEN_DIR, name + '.npz')
+  if check:
+    old = np.load(path)
+    worst = max(float(np.abs(old[k] - v).max()) for k, v in res.items())
+    print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e}')
+    assert set(old.files) == set(res) and worst == 0.0, name
+    return
+  np.savez_compressed(path, **res)
+  print(name, {k: v.shape for k, v in res.items() if k == 'tracks'}, f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
+def check_case(tm, name, cfg):
+  """--check: the committed stage-boundary fixture against a fresh run of the reference (bit for bit)."""
+  global GOLDEN_DIR
+  keep = GOLDEN_DIR
+  old = {k: v for k, v in np.load(os.path.join(keep, name + '.npz')).items()}
+  try:
+    GOLDEN_DIR = os.path.join(keep, '_regen')
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    make_case(tm, name, cfg)
+    new = {k: v for k, v in np.load(os.path.join(GOLDEN_DIR, name + '.npz')).items()}
+  finally:
+    import shutil
+    shutil.rmtree(os.path.join(keep, '_regen'), ignore_errors=True)
+    GOLDEN_DIR = keep
+  assert set(old) == set(new), (name, set(old) ^ set(new))
+  worst = max(float(np.abs(old[k].astype(np.float64) - new[k].astype(np.float64)).max()) for k in old)
+  print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e}')
+  assert worst == 0.0, name
+
+
 def main():
   os.makedirs(GOLDEN_DIR, exist_ok=True)
   torch.manual_seed(0)
   torch.set_num_threads(os.cpu_count() or 1)
   tm, _, _ = import_reference()
-  only = sys.argv[1:]
+  args = sys.argv[1:]
+  check = '--check' in args
+  only = [a for a in args if not a.startswith('--')]
   for name, cfg in CASES.items():
     if only and name not in only:
       continue
-    make_case(tm, name, cfg)
-  if not only or 'backbone' in only:
+    if check:
+      check_case(tm, name, cfg)
+    else:
+      make_case(tm, name, cfg)
+  for name, cfg in HEADLINE.items():
+    if (only and name not in only) or (not only and check):   # (--check without names: the small cases only)
+      continue
+    make_headline_case(tm, name, cfg, check)
+  if (not only or 'backbone' in only) and not check:
     make_backbone_case(tm)
 
 

@@ -41,3 +41,22 @@ def oracle_kwargs(cfg):
               softmax_temperature=cfg['softmax_temperature'],
               initial_resolution=(cfg['res'], cfg['res']),
               use_causal_conv=cfg['causal'])
+
+
+# must match oracle/make_golden.py:HEADLINE -- the benchmarked shape (BASELINE.json configs[1]), the reference's
+# torch twin end to end; the fixtures hold OUTPUTS only, inputs and weights are regenerated from the seeds
+HEADLINE = {
+    'headline_tapir': dict(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, causal=False,
+                           res=256, video=256, T=48, Q=256, wseed=31),
+    'headline_bootstapir': dict(pyramid_level=1, extra_convs=True, softmax_temperature=10.0, causal=False,
+                                res=256, video=256, T=48, Q=256, wseed=32),
+}
+
+
+def load_headline(name):
+  cfg = HEADLINE[name]
+  g = dict(np.load(os.path.join(GOLDEN_DIR, name + '.npz')))
+  weights = synthetic.make_weights(cfg['wseed'], cfg['pyramid_level'], cfg['extra_convs'])
+  video = synthetic.make_video(cfg['wseed'] + 100, cfg['T'], cfg['video'], cfg['video'])
+  qpts = synthetic.make_queries(cfg['wseed'] + 200, cfg['Q'], cfg['T'], cfg['video'], cfg['video'])
+  return cfg, g, weights, video, qpts

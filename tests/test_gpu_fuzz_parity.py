@@ -1,0 +1,102 @@
+"""Seeded random-shape parity sweep (round 3's tools/fuzz_parity.py runs, now a test): the f32 engine, video -> tracks,
+against the oracle (plain-PyTorch backbone restatement + numpy hot path) on random configurations -- frame counts,
+query counts, NON-SQUARE initial resolutions, frames at 1x / 1.5x / 2x of it (2 or 3 feature levels), TAPIR / BootsTAPIR
+kwargs, ragged query chunks.  Sweep A: small shapes (separate-launch kernels); sweep B: up to 50 frames x 96 queries
+(the track-resident mixer kernels engage).
+
+What is asserted, per sweep:
+  * the margin mask is REPORTED and small: a query is set aside only when one of its frames has a relative gap below
+    1e-4 between the two largest soft-max cells of the oracle's heat map (a near-tie arg max may legitimately flip
+    between two f32 evaluation orders, and the temporal convolutions spread the flip over the query's frames);
+    at least 90 % of the queries must remain;
+  * on the remaining queries every point, every frame: tracks within 1e-3 px IN INITIAL-RESOLUTION PIXELS, logits within
+    1e-3.  The engine's tracks are in video pixels (tapir_model.py:906-912 rescales by video / initial resolution), so
+    on a frame at twice the initial resolution a deviation of 5.7e-4 px of the 256-coordinate estimate reads 1.14e-3 px
+    -- the one value above 1e-3 in round 3's sweep (profiles/r03_fuzz_parity.txt); north_star's tolerance is stated
+    for video = initial resolution.  Both numbers are recorded (gpurun_out/fuzz_parity.json).
+Reference arithmetic: tapnet/models/tapir_model.py:626-729, 858-1154; tapnet/utils/model_utils.py:209-314."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_torch, tapir_oracle as O   # checker only
+from tapnet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SWEEPS = {'A_small': dict(seed=1, cases=10, tmax=20, qmax=24), 'B_fused_mixer': dict(seed=7, cases=2, tmax=50, qmax=96)}
+
+
+def _case(rng, tmax, qmax):
+  pyr, extra = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+  T, Q = int(rng.integers(1, tmax + 1)), int(rng.integers(1, qmax + 1))
+  ih, iw = 8 * int(rng.integers(6, 13)), 8 * int(rng.integers(6, 13))          # initial_resolution 48..96
+  scale = float(rng.choice([1.0, 1.0, 1.5, 2.0]))
+  H, W = 8 * int(round(ih * scale / 8)), 8 * int(round(iw * scale / 8))
+  chunk = int(rng.choice([Q, max(1, Q // 2), 7]))
+  seed = int(rng.integers(0, 1 << 30))
+  return dict(pyr=pyr, extra=extra, T=T, Q=Q, init=(ih, iw), video=(H, W), chunk=chunk, seed=seed)
+
+
+@pytest.mark.parametrize('sweep', list(SWEEPS))
+def test_random_shapes_against_the_oracle(sweep):
+  from tapnet_amd import tapir_model
+  cfg = SWEEPS[sweep]
+  rng = np.random.default_rng(cfg['seed'])
+  rows, n_q, n_clear = [], 0, 0
+  for i in range(cfg['cases']):
+    c = _case(rng, cfg['tmax'], cfg['qmax'])
+    (ih, iw), (H, W), T, Q = c['init'], c['video'], c['T'], c['Q']
+    w = synthetic.make_weights(c['seed'] % 1000, c['pyr'], c['extra'])
+    video = synthetic.make_video(c['seed'], T, H, W).astype(np.float32)
+    qp = synthetic.make_queries(c['seed'] + 1, Q, T, H, W).astype(np.float32)
+    m = tapir_model.TAPIR(pyramid_level=c['pyr'], extra_convs=c['extra'], initial_resolution=(ih, iw), weights=w,
+                          device='cuda:0')
+    out = m(video, False, qp, query_chunk_size=c['chunk'])
+    res = [(ih, iw)] + [tuple(r) for r in O.generate_default_resolutions((H, W), (ih, iw))]
+    bb = backbone_torch.TorchBackbone(w, c['extra'])
+    lows, his, cur, lo, hi = [], [], None, None, None
+    for r in res:
+      if r != cur:
+        v = torch.as_tensor(video)
+        if r != (H, W):   # the torch twin's resize (no antialias): what the engine does for torch-named weights
+          v = torch.nn.functional.interpolate(v[0].permute(0, 3, 1, 2), size=r, mode='bilinear', align_corners=False
+                                              ).permute(0, 2, 3, 1)[None]
+        l, h = bb.features(v.reshape(-1, r[0], r[1], 3))
+        lo, hi, cur = l.numpy()[None], h.numpy()[None], r
+      lows.append(lo); his.append(hi)
+    ref = O.tapir_from_grids(w, video.shape, lows, his, res, qp, pyramid_level=c['pyr'], softmax_temperature=20.0,
+                             initial_resolution=(ih, iw))
+    ql, _ = O.get_query_features(lows, his, res, qp, video.shape)
+    _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], None, (ih, iw), 20.0, return_stages=True)
+    clear = (st['top2_rel_gap'] > 1e-4).all(axis=-1)[0]          # [Q]: no near-tie arg max in any frame of the query
+    d = np.linalg.norm(np.asarray(out['tracks']) - ref['tracks'], axis=-1)[0]                    # [Q, T] video px
+    dl = np.maximum(np.abs(np.asarray(out['occlusion']) - ref['occlusion']),
+                    np.abs(np.asarray(out['expected_dist']) - ref['expected_dist']))[0]
+    scale = max(H / ih, W / iw)
+    row = dict(case=i, **{k: c[k] for k in ('pyr', 'extra', 'T', 'Q', 'init', 'video', 'chunk')}, levels=len(res),
+               queries_masked=int((~clear).sum()),
+               tracks_video_px_max=float(d[clear].max()) if clear.any() else 0.0,
+               tracks_initial_px_max=float(d[clear].max() / scale) if clear.any() else 0.0,
+               logits_max=float(dl[clear].max()) if clear.any() else 0.0,
+               masked_tracks_video_px_max=float(d[~clear].max()) if (~clear).any() else 0.0,
+               min_top2_rel_gap=float(st['top2_rel_gap'].min()))
+    rows.append(row)
+    n_q += Q; n_clear += int(clear.sum())
+    del m
+  frac = n_clear / n_q
+  summary = dict(sweep=sweep, **cfg, queries=n_q, fraction_compared=round(frac, 4),
+                 tracks_initial_px_max=max(r['tracks_initial_px_max'] for r in rows),
+                 tracks_video_px_max=max(r['tracks_video_px_max'] for r in rows),
+                 logits_max=max(r['logits_max'] for r in rows), cases=rows)
+  os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+  path = os.path.join(ROOT, 'gpurun_out', 'fuzz_parity.json')
+  allr = json.load(open(path)) if os.path.exists(path) else {}
+  allr[sweep] = summary
+  json.dump(allr, open(path, 'w'), indent=1)
+  print(json.dumps({k: v for k, v in summary.items() if k != 'cases'}))
+  assert frac >= 0.9, f'margin mask hides {100 * (1 - frac):.1f} % of the queries'
+  assert summary['tracks_initial_px_max'] < 1e-3 and summary['logits_max'] < 1e-3, summary
