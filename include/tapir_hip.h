@@ -112,6 +112,19 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, con
                                          const float* query_points, int B, int Q, int T, int h, int w,
                                          float* points, float* occlusion, void* stream);
 
+/* TAP-Net's forward-backward cycle-consistency tracker -- tapnet/training/supervised_point_prediction.py:443-546, the
+ * evaluation path of prediction_algo != 'cost_volume_regressor' (SURVEY.md 8 f4): no learned head.  Forward: soft arg max
+ * of softmax(temperature * einsum('bnc,bthwc->bnthw')) per frame, the query's own frame overridden by the query point
+ * (:453-469); the grid is sampled bilinearly at the tracked point of every frame (:473-496); backward: each sampled
+ * vector against the grid of the frame its query came from (:501-531); a point whose backward track lands more than
+ * dist_threshold (48) pixels from the query is occluded: logit +10, else -10 (:533-539; the intended indexing of :537).
+ * Both passes are the row-streamed cost-volume kernel without heads -- no [B,N,T,h,w] tensor exists.
+ * query_feats [B,Q,256], feature_grid [B,T,h,w,256] (w <= 32), query_points [B,Q,3] (t,y,x) in img_h x img_w pixels;
+ * tracks [B,Q,T,2] (x,y), occlusion [B,Q,T], inverse_tracks [B,Q,T,2] or NULL.  No weights needed. */
+int tapir_cycle_consistency_tracks(tapir_ctx* ctx, const float* query_feats, const float* feature_grid,
+                                   const float* query_points, int B, int Q, int T, int h, int w, int img_h, int img_w,
+                                   float softmax_temperature, float dist_threshold, float* tracks, float* occlusion,
+                                   float* inverse_tracks, void* stream);
 /* One grid of TAPIR.get_query_features (tapir_model.py:781-849;
  * model_utils.interp mode='nearest' :177-206): trilinear sample of
  * grid [B,T,h,w,C] at query_points [B,Q,3] (t,y,x) given in video pixels

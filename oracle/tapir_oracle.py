@@ -338,6 +338,55 @@ def tapnet_tracks_from_cost_volume(weights: Dict[str, np.ndarray], interp_featur
   return points, occlusion
 
 
+def cycle_consistency_tracks(query_feats, feature_grid, query_points, im_hw, softmax_temperature=10.0,
+                             dist_threshold=48.0, rnd=None, return_stages=False):
+  """The forward-backward cycle-consistency tracker of the TAP-Net evaluation path
+  (tapnet/training/supervised_point_prediction.py:443-546): no learned head at all --
+    forward : tracks = heatmaps_to_points(softmax(temperature * einsum('bnc,bthwc->bnthw')), query_points)  :453-469
+    features: bilinear samples of the grid at the tracked point of every frame (model_utils.interp,
+              (t, y, x) -> grid coordinates, t an exact frame)                                                 :473-496
+    backward: the sampled vector of (query n, frame t) against the grid of the QUERY's frame
+              (round(t_query)), einsum('bntc,bnhwc->bnthw'), the same soft arg max without the override       :501-531
+    occluded: the backward point lands more than 48 px from the query -> logit +10, else -10                  :533-539
+  Line :537 of the reference indexes the query points as `query_points[jnp.newaxis, 2:0:-1]`, which slices the
+  BATCH axis (and cannot broadcast against [b,n,t,2]); the evident intent -- the query's (x, y), i.e.
+  query_points[:, :, None, 2:0:-1] -- is what is restated here.  Everything before that line is pinned to the
+  reference's own lines executed over numpy stand-ins (oracle/make_cycle_golden.py).
+
+  query_feats [B,N,C], feature_grid [B,T,h,w,C], query_points [B,N,3] (t,y,x) in im_hw pixels.
+  Returns tracks [B,N,T,2] (x,y) px, occlusion logits [B,N,T] (and the inverse tracks)."""
+  rnd = rnd or _id
+  dt = feature_grid.dtype
+  b, t, h, w, c = feature_grid.shape
+  n = query_feats.shape[1]
+
+  def soft_points(dots, qp):
+    z = dots * dt.type(softmax_temperature)
+    z = z - z.max(axis=(-2, -1), keepdims=True)
+    e = np.exp(z)
+    return heatmaps_to_points((e / e.sum(axis=(-2, -1), keepdims=True)).astype(dt), im_hw, qp)
+
+  fg = rnd(feature_grid)
+  dots = np.einsum('bnc,bthwc->bnthw', rnd(query_feats), fg, optimize=True).astype(dt)
+  tracks = soft_points(dots, query_points)
+  # position_in_grid = (frame, y, x) * grid_shape / im_shape (transforms.py:75-76); interp: t as is, y / x - 0.5
+  interp_features = np.zeros((b, n, t, c), dt)
+  for bi in range(b):
+    for ti in range(t):
+      pts = np.stack([np.full(n, ti, dt), tracks[bi, :, ti, 1] * dt.type(h / im_hw[0]),
+                      tracks[bi, :, ti, 0] * dt.type(w / im_hw[1])], -1)
+      interp_features[bi, :, ti] = interp_nearest_3d(feature_grid[bi], pts)
+  query_frame = np.round(query_points[..., 0].astype(dt)).astype(np.int32)     # grid frames = video frames
+  target = np.stack([fg[bi][np.clip(query_frame[bi], 0, t - 1)] for bi in range(b)])   # [B,N,h,w,C]
+  dots2 = np.einsum('bntc,bnhwc->bnthw', rnd(interp_features), target, optimize=True).astype(dt)
+  inverse = soft_points(dots2, None)
+  dist = ((inverse - query_points[:, :, None, 2:0:-1].astype(dt)) ** 2).sum(-1)
+  occlusion = (dist > dt.type(dist_threshold) ** 2).astype(dt) * dt.type(20.0) - dt.type(10.0)
+  if return_stages:
+    return tracks, occlusion, dict(inverse_tracks=inverse, interp_features=interp_features, dist=dist)
+  return tracks, occlusion
+
+
 # ---------------------------------------------------------------------------
 # R3: PIPs patch correlation (front half of refine_pips)
 # ---------------------------------------------------------------------------

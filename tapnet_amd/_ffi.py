@@ -89,6 +89,8 @@ PROTOTYPES = {
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'tapir_l2_normalize': (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     'tapir_l2_normalize_staged': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    'tapir_cycle_consistency_tracks': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tapir_set_staged_grid': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'tapir_clear_staged_grids': (c_int, [c_void_p]),
     'tapir_conv_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

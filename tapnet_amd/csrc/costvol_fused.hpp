@@ -55,6 +55,9 @@ struct CvFusedArgs {
   int tapnet;             // 1: TAP-Net head (tapnet_model.py:157-166): no ReLU after the stride-2
                           // convolution, ONE output logit (occlusion; expd is not written)
   long long* dbg_times;   // TRACE build: [workgroups][8] shader-cycle totals per phase (wave 0)
+  // costvol_rows.hpp only:
+  int raw;                // 1: no heads -- points = soft arg max of softmax(temperature * cost map) (occ / expd not written)
+  const int* frame_map;   // null, or [B*T]: unit frame -> index of the grid frame it correlates with
 };
 
 template <typename TA> struct CvFusedCfg;

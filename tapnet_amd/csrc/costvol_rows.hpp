@@ -177,18 +177,27 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   //   conv 2: A2[row c][k-slot g] of MFMA j = W2[ch 4 g + j][tap 3 (c >> 2) + (c & 3)]   (rows with c >> 2 == 3 or c & 3 == 3: 0)
   float a1[HEADS][3], a2[4];     // W1 is [16][HEADS][3][3]
   int off1[3];                   // LDS offset (floats) of tap 4 j + g relative to the pixel's halo index
+  f32x4 b1v = f32x4{0.f, 0.f, 0.f, 0.f};
+  float b2 = 0.f, b3a = 0.f, b3b = 0.f;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int tap = 4 * j + g;
-    const int tc = min(tap, 8);
-#pragma unroll
-    for (int hd = 0; hd < HEADS; ++hd) {
-      const float v = a.wt.w1[(c * HEADS + hd) * 9 + tc];   // unconditional load, masked on use
-      a1[hd][j] = tap < 9 ? v : 0.f;
-    }
+    const int tc = min(4 * j + g, 8);
     off1[j] = (tc / 3 - 1) * pw + (tc % 3 - 1);
+#pragma unroll
+    for (int hd = 0; hd < HEADS; ++hd) a1[hd][j] = 0.f;
   }
-  {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a2[j] = 0.f;
+  if (!a.raw) {                  // (raw mode has no heads: the weight pointers may be null)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tap = 4 * j + g;
+#pragma unroll
+      for (int hd = 0; hd < HEADS; ++hd) {
+        const float v = a.wt.w1[(c * HEADS + hd) * 9 + min(tap, 8)];   // unconditional load, masked on use
+        a1[hd][j] = tap < 9 ? v : 0.f;
+      }
+    }
     const int dy = c >> 2, dx = c & 3;
     const bool live = dy < 3 && dx < 3;
 #pragma unroll
@@ -196,10 +205,10 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       const float v = a.wt.w2[(4 * g + j) * 9 + min(3 * min(dy, 2) + min(dx, 2), 8)];
       a2[j] = live ? v : 0.f;
     }
+    b1v = *reinterpret_cast<const f32x4*>(a.wt.b1 + 4 * g);
+    b2 = a.wt.b2[0];
+    b3a = a.wt.b3[c]; b3b = a.wt.b3[16 + c];
   }
-  const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.wt.b1 + 4 * g);
-  const float b2 = a.wt.b2[0];
-  const float b3a = a.wt.b3[c], b3b = a.wt.b3[16 + c];
   // ---- G: cost maps.  B operand: lane (query c, chunk group g) holds chunks 4 s + g of its row.
   {
     const int qrow = min(q0 + (c < QPW ? c / HEADS : 0), a.Q - 1);
@@ -208,12 +217,13 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     uint4 fq[KCH];
 #pragma unroll
     for (int s = 0; s < KCH; ++s) fq[s] = keep_head<TA, HEADS>(qsrc[4 * s + g], c % HEADS);
-    const TA* gbase = reinterpret_cast<const TA*>(a.grid) + frame * (long)hw * kLowresDim;
+    const long gframe = a.frame_map != nullptr ? (long)a.frame_map[frame] : frame;   // which grid this unit's frame is
+    const TA* gbase = reinterpret_cast<const TA*>(a.grid) + gframe * (long)hw * kLowresDim;
     const int ntile = (hw + 15) / 16;
     // tile order (bf16 build; pips.hpp PoolArgs::tiled): chunk 4 s + g of cell c of tile `it` is 16-byte piece
     // (it * 32 + 4 s + g) * 16 + c of the frame: the 16 lanes of a lane group read 256 contiguous bytes, the wave 1 KiB
     const bool tiled = BF && a.grid_tiled != nullptr;
-    const uint4* tbase = reinterpret_cast<const uint4*>(a.grid_tiled) + (frame * ntile * 32 + g) * 16 + c;
+    const uint4* tbase = reinterpret_cast<const uint4*>(a.grid_tiled) + (gframe * ntile * 32 + g) * 16 + c;
     auto load_tile = [&](int it, uint4 (&f)[KCH]) {
       if (tiled) {
         const uint4* csrc = tbase + (long)it * 512;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   }
   // head tail (Linear 32 -> 16, Linear 16 -> 2): 562 floats through LDS, both loads in flight together
   static_assert(THREADS >= 512, "head staging assumes >= 512 threads");
-  {
+  if (!a.raw) {
     const int n5 = a.tapnet ? 16 : 32, nb5 = a.tapnet ? 1 : 2;
     float hv0 = 0.f, hv1 = 0.f;
     if (tid < 512) hv0 = a.wt.w4[tid];
@@ -289,7 +299,9 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   const int oh = (h + 1) / 2, ow = (w + 1) / 2, opix = oh * ow;
   const int ply = max((oh - 1) * 2 + 3 - h, 0) / 2, plx = max((ow - 1) * 2 + 3 - w, 0) / 2;
   uint4 wb[BF ? 5 : 1][2];
-  if (BF) {
+#pragma unroll
+  for (int s = 0; s < (BF ? 5 : 1); ++s) wb[s][0] = wb[s][1] = make_uint4(0u, 0u, 0u, 0u);
+  if (BF && !a.raw) {
 #pragma unroll
     for (int s = 0; s < 5; ++s)
 #pragma unroll
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   const int zx = lane & (wq - 1), zy = lane / wq;
   const bool zcol = zx < w;
   const float zcx = (float)zx + 0.5f;
+  const float zscale = a.raw ? a.temperature : 1.0f;   // raw: the cost map itself is the logit map (x temperature)
   // this lane's pixel column in tile tx, its ring / map offsets
   int px[NTX];
   bool pin[NTX];
@@ -339,6 +352,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     float osum[2] = {0.f, 0.f};                      // sum over this lane's output pixels of relu(conv + b3), channels c, 16 + c
 #pragma unroll
     for (int tx = 0; tx < NTX; ++tx) pend[tx] = 0.f;
+    if (!a.raw) {   // (raw: the soft arg max of the cost map itself, no heads -- TAP-Net's cycle-consistency tracker)
     // ring row of image row -1 (read by the stride-2 window when ply = 1) is all zero
     for (int i = lane; i < RING_ROW; i += 64) ring[((-1) & (CVR_RING - 1)) * RING_ROW + i] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
@@ -520,6 +534,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       if (oc_pending) { occl_sum(); oc_pending = false; }
     }
 
+    }
     // ---- M2: arg max (FIRST maximum: jnp.argmax, model_utils.py:232), softmax window sums
     wave_sync();
     float z[CVR_ZREG];
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     for (int k = 0; k < CVR_ZREG; ++k) {
       const int yk = k * rps + zy;
       const bool in = zcol && yk < h;
-      z[k] = in ? cm[(min(yk, h - 1) + 1) * pw + min(zx, w - 1) + 1] : -3.0e38f;
+      z[k] = in ? cm[(min(yk, h - 1) + 1) * pw + min(zx, w - 1) + 1] * zscale : -3.0e38f;
       best = fmaxf(best, z[k]);
     }
     best = wave_max(best);
@@ -551,25 +566,27 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       }
     }
     wave_sum_n<4>(red);
-    // occlusion head tail: mean over the output pixels, Linear 32 -> 16 + ReLU, Linear 16 -> 2 (:462-470)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      osum[k] += __shfl_xor(osum[k], 16);
-      osum[k] += __shfl_xor(osum[k], 32);
-    }
-    if (lane < 16) { vec[lane] = osum[0] / (float)opix; vec[16 + lane] = osum[1] / (float)opix; }
-    wave_sync();
-    if (lane < 16) {
-      float acc = s_head[512 + lane];
-      for (int k = 0; k < 32; ++k) acc = fmaf(s_head[lane * 32 + k], vec[k], acc);
-      vec[32 + lane] = fmaxf(acc, 0.f);
-    }
-    wave_sync();
     const long map = (b * a.Q + q0 + m) * a.T + t;
-    if (lane < (a.tapnet ? 1 : 2)) {
-      float acc = s_head[560 + lane];
-      for (int k = 0; k < 16; ++k) acc = fmaf(s_head[528 + lane * 16 + k], vec[32 + k], acc);
-      if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;
+    if (!a.raw) {
+      // occlusion head tail: mean over the output pixels, Linear 32 -> 16 + ReLU, Linear 16 -> 2 (:462-470)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        osum[k] += __shfl_xor(osum[k], 16);
+        osum[k] += __shfl_xor(osum[k], 32);
+      }
+      if (lane < 16) { vec[lane] = osum[0] / (float)opix; vec[16 + lane] = osum[1] / (float)opix; }
+      wave_sync();
+      if (lane < 16) {
+        float acc = s_head[512 + lane];
+        for (int k = 0; k < 32; ++k) acc = fmaf(s_head[lane * 32 + k], vec[k], acc);
+        vec[32 + lane] = fmaxf(acc, 0.f);
+      }
+      wave_sync();
+      if (lane < (a.tapnet ? 1 : 2)) {
+        float acc = s_head[560 + lane];
+        for (int k = 0; k < 16; ++k) acc = fmaf(s_head[528 + lane * 16 + k], vec[32 + k], acc);
+        if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;
+      }
     }
     if (lane == 0) {
       const float tot = red[0];

@@ -90,6 +90,7 @@ struct tapir_ctx {
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
   DevBuf qf_cast, grid_cast[kMaxLevels], pooled;
+  DevBuf cyc_pts, cyc_feat, cyc_map, cyc_inv;   // cycle-consistency tracker (tapir_cycle_consistency_tracks)
   struct Staged { const float* f32; const void* op; const void* tiled; };
   std::vector<Staged> staged;       // operand-type copies the caller's backbone wrote next to its f32 grids (tapir_set_staged_grid)
   DevBuf grid_tiled;                 // bf16 low-res grid in the cost-volume kernel's operand order (pips.hpp: PoolArgs::tiled)
@@ -666,6 +667,85 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
                           expd + bq * T, s));
     }
   }
+  return TAPIR_OK;
+}
+
+// ---- forward-backward cycle-consistency tracker (tapnet/training/supervised_point_prediction.py:443-546) ----------
+struct CycPtsArgs { const float* tracks; const float* qpts; float* pts3; int* frame_map; long BQ; int Q, T; };
+// (t, y, x) of the tracked point of every (query, frame), and the grid frame each query came from (:489-507)
+__global__ void cycle_points_kernel(CycPtsArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.BQ * a.T) return;
+  const long bq = i / a.T;
+  const int t = (int)(i - bq * a.T);
+  a.pts3[i * 3 + 0] = (float)t;
+  a.pts3[i * 3 + 1] = a.tracks[i * 2 + 1];
+  a.pts3[i * 3 + 2] = a.tracks[i * 2 + 0];
+  if (t == 0) {   // round-half-even like jnp.round; frame b * T + round(t_query) of the [B*T] grid frames
+    const int qf = min(max((int)rintf(a.qpts[bq * 3 + 0]), 0), a.T - 1);
+    a.frame_map[bq] = (int)(bq / a.Q) * a.T + qf;
+  }
+}
+struct CycOccArgs { const float* inv; const float* qpts; float* occ; long BQ; int T; float thr2; };
+// occluded when the backward point misses the query by more than the threshold: logit +10 / -10 (:533-539)
+__global__ void cycle_occlusion_kernel(CycOccArgs a) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.BQ * a.T) return;
+  const long bq = i / a.T;
+  const float dx = a.inv[i * 2 + 0] - a.qpts[bq * 3 + 2], dy = a.inv[i * 2 + 1] - a.qpts[bq * 3 + 1];
+  a.occ[i] = (dx * dx + dy * dy > a.thr2) ? 10.0f : -10.0f;
+}
+
+// one raw pass: points = soft arg max of softmax(temperature * <qfeat, grid cell>) per (query, frame)
+template <typename TA>
+void cycle_pass(tapir_ctx* c, const void* qf_op, const void* grid_op, const void* tiled_op, const float* qpts,
+                const int* frame_map, int B, int Q, int T, int h, int w, float img_h, float img_w, float temperature,
+                float* points, hipStream_t s) {
+  CvFusedArgs fa{};   // (the head weights stay null: raw mode does not read them)
+  fa.qfeat = qf_op; fa.grid = grid_op; fa.grid_tiled = tiled_op; fa.qpts = qpts;
+  fa.points = points;
+  fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w;
+  fa.temperature = temperature; fa.img_h = img_h; fa.img_w = img_w;
+  fa.raw = 1; fa.frame_map = frame_map;
+  launch_cv_rows<TA>(fa, s, 1, c->cv_form);
+}
+
+template <typename TA>
+int do_cycle_consistency(tapir_ctx* c, const float* qfeat, const float* grid, const float* qpts, int B, int Q, int T,
+                         int h, int w, int img_h, int img_w, float temperature, float threshold, float* tracks,
+                         float* occlusion, float* inverse_tracks, hipStream_t s) {
+  const int C = kLowresDim;
+  if (!cv_rows_supported(h, w))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "cycle-consistency tracker: grids of up to 32 cells per row");
+  const long BQ = (long)B * Q, R = BQ * T;
+  TRY(ensure(c, c->cyc_pts, (size_t)R * 12)); TRY(ensure(c, c->cyc_feat, (size_t)R * C * 4));
+  TRY(ensure(c, c->cyc_map, (size_t)BQ * 4));
+  if (inverse_tracks == nullptr) { TRY(ensure(c, c->cyc_inv, (size_t)R * 8)); inverse_tracks = (float*)c->cyc_inv.p; }
+  const void* qf_op = qfeat; const void* grid_op = grid; const void* tiled_op = nullptr;
+  if (sizeof(TA) == 2) {
+    TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
+    TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s, c->cv_tiled ? &c->grid_tiled : nullptr));
+    c->cast_src[1] = nullptr; c->tiled_src = nullptr;
+    qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p; tiled_op = c->cv_tiled ? c->grid_tiled.p : nullptr;
+  }
+  // forward (:453-469): every query against every frame, the query's own frame overridden by the query point
+  cycle_pass<TA>(c, qf_op, grid_op, tiled_op, qpts, nullptr, B, Q, T, h, w, (float)img_h, (float)img_w, temperature, tracks, s);
+  // features at the tracked points (:473-496) and the frames the queries came from (:501-514)
+  CycPtsArgs pa{tracks, qpts, (float*)c->cyc_pts.p, (int*)c->cyc_map.p, BQ, Q, T};
+  hipLaunchKernelGGL(cycle_points_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, pa);
+  SampleArgs sa{grid, (const float*)c->cyc_pts.p, (float*)c->cyc_feat.p, B, Q * T, T, h, w, C, (float)img_h, (float)img_w};
+  hipLaunchKernelGGL(query_feature_kernel, dim3((unsigned)R), dim3(128), 0, s, sa);
+  // backward (:516-531): the T sampled vectors of a query against the ONE frame the query came from -- B * Q "clips"
+  // of one frame with T "queries" each; frame_map picks the grid frame
+  const void* f_op = c->cyc_feat.p;
+  if (sizeof(TA) == 2) {
+    TRY(cast_or_pool<TA>(c, (const float*)c->cyc_feat.p, 1, 1, (int)R, C, 0, c->qf_cast, s));
+    f_op = c->qf_cast.p;
+  }
+  cycle_pass<TA>(c, f_op, grid_op, tiled_op, nullptr, (const int*)c->cyc_map.p, (int)BQ, T, 1, h, w, (float)img_h,
+                 (float)img_w, temperature, inverse_tracks, s);
+  CycOccArgs oa{inverse_tracks, qpts, occlusion, BQ, T, threshold * threshold};
+  hipLaunchKernelGGL(cycle_occlusion_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, oa);
   return TAPIR_OK;
 }
 
@@ -1274,6 +1354,19 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const
   c->cast_src[1] = nullptr; c->tiled_src = nullptr;
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points, occlusion,
                   nullptr, (hipStream_t)stream, true);
+}
+
+int tapir_cycle_consistency_tracks(tapir_ctx* c, const float* query_feats, const float* feature_grid,
+                                    const float* query_points, int B, int Q, int T, int h, int w, int img_h, int img_w,
+                                    float softmax_temperature, float dist_threshold, float* tracks, float* occlusion,
+                                    float* inverse_tracks, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!query_feats || !feature_grid || !query_points || !tracks || !occlusion || B < 1 || Q < 1 || T < 1 || h < 1 ||
+      w < 1 || img_h < 1 || img_w < 1)
+    return fail(c, TAPIR_ERR_INVALID, "bad argument");
+  return DISPATCH(c, do_cycle_consistency, c, query_feats, feature_grid, query_points, B, Q, T, h, w, img_h, img_w,
+                  softmax_temperature, dist_threshold, tracks, occlusion, inverse_tracks, (hipStream_t)stream);
 }
 
 int tapir_get_query_features(tapir_ctx* c, const float* grid, const float* query_points, int B,

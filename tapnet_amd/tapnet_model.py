@@ -150,6 +150,31 @@ class TAPNet:
       return pts.cpu().numpy(), occ.cpu().numpy()
     return pts, occ
 
+  def cycle_consistency_tracks(self, query_feats, feature_grid, query_points, im_shp,
+                               softmax_temperature: Optional[float] = None, dist_threshold: float = 48.0,
+                               return_inverse_tracks: bool = False):
+    """The forward-backward cycle-consistency tracker of TAP-Net's evaluation path
+    (tapnet/training/supervised_point_prediction.py:443-546; prediction_algo other than 'cost_volume_regressor'): no
+    learned head.  query_feats [B,N,C] and feature_grid [B,T,h,w,C] as returned by __call__(get_query_feats=True)
+    (out['query_feats'], out['feature_grid']), query_points [B,N,3] (t,y,x) in im_shp pixels, im_shp [B,T,H,W,3].
+    Returns (tracks [B,N,T,2] (x,y) px, occlusion logits [B,N,T] = +10 / -10)."""
+    numpy_out = isinstance(query_feats, np.ndarray)
+    qf, g, qp = self._dev(query_feats), self._dev(feature_grid), self._dev(query_points)
+    B, Q, C = qf.shape
+    _, T, h, w, _ = g.shape
+    if C != 256:
+      raise ValueError('feature dimension must be 256 (tsm_resnet_unit_2 of TSM-ResNet-18)')
+    H, W = int(im_shp[2]), int(im_shp[3])
+    temp = float(self.softmax_temperature if softmax_temperature is None else softmax_temperature)
+    pts = torch.empty((B, Q, T, 2), device=self.device, dtype=torch.float32)
+    occ = torch.empty((B, Q, T), device=self.device, dtype=torch.float32)
+    inv = torch.empty((B, Q, T, 2), device=self.device, dtype=torch.float32)
+    self._check(self._lib.tapir_cycle_consistency_tracks(
+        self._ctx, qf.data_ptr(), g.data_ptr(), qp.data_ptr(), B, Q, T, h, w, H, W, temp, float(dist_threshold),
+        pts.data_ptr(), occ.data_ptr(), inv.data_ptr(), self._stream()), 'tapir_cycle_consistency_tracks')
+    outs = (pts, occ, inv) if return_inverse_tracks else (pts, occ)
+    return tuple(t.cpu().numpy() for t in outs) if numpy_out else outs
+
   def __call__(self, video, is_training: bool = False, query_points=None, compute_regression: bool = True,
                query_chunk_size: Optional[int] = None, get_query_feats: bool = False, feature_grid=None):
     """tapnet_model.py:173-290 from a precomputed feature grid.  ``video`` is used for its shape only

@@ -101,6 +101,16 @@ class EmuEngine:
                                                             _p(pts), _p(occ), None), 'tapnet head')
     return pts, occ
 
+  def cycle_consistency_tracks(self, qfeat, grid, qpts, im_hw, temperature=10.0, threshold=48.0):
+    qfeat, grid, qpts = f32(qfeat), f32(grid), f32(qpts)
+    B, Q, _ = qfeat.shape
+    _, T, h, w, _ = grid.shape
+    pts = np.zeros((B, Q, T, 2), np.float32); occ = np.zeros((B, Q, T), np.float32); inv = np.zeros((B, Q, T, 2), np.float32)
+    self._chk(self.lib.tapir_cycle_consistency_tracks(self.ctx, _p(qfeat), _p(grid), _p(qpts), B, Q, T, h, w, int(im_hw[0]),
+                                                      int(im_hw[1]), temperature, threshold, _p(pts), _p(occ), _p(inv), None),
+              'cycle consistency')
+    return pts, occ, inv
+
   def get_query_features(self, grid, qpts, video_hw):
     grid, qpts = f32(grid), f32(qpts)
     B, T, h, w, C = grid.shape

@@ -91,12 +91,12 @@ def test_random_shapes_against_the_oracle(sweep):
   summary = dict(sweep=sweep, **cfg, queries=n_q, fraction_compared=round(frac, 4),
                  tracks_initial_px_max=max(r['tracks_initial_px_max'] for r in rows),
                  tracks_video_px_max=max(r['tracks_video_px_max'] for r in rows),
-                 logits_max=max(r['logits_max'] for r in rows), cases=rows)
+                 logits_max=max(r['logits_max'] for r in rows), case_rows=rows)
   os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
   path = os.path.join(ROOT, 'gpurun_out', 'fuzz_parity.json')
   allr = json.load(open(path)) if os.path.exists(path) else {}
   allr[sweep] = summary
   json.dump(allr, open(path, 'w'), indent=1)
-  print(json.dumps({k: v for k, v in summary.items() if k != 'cases'}))
+  print(json.dumps({k: v for k, v in summary.items() if k != 'case_rows'}))
   assert frac >= 0.9, f'margin mask hides {100 * (1 - frac):.1f} % of the queries'
   assert summary['tracks_initial_px_max'] < 1e-3 and summary['logits_max'] < 1e-3, summary
