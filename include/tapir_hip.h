@@ -378,6 +378,10 @@ int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
  * workgroup) also where automatic picks the row-streamed form (costvol_rows.hpp: every wave owns whole
  * maps; rows of up to 32 cells). */
 int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
+/* tools/kbench.py --what contraction: the contraction phase of the row-streamed cost-volume kernel alone (cost maps into
+ * LDS, no heads); scratch = B*T*ceil(Q/8) floats. */
+int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* grid, int B, int Q, int T, int h, int w,
+                            float* scratch, void* stream);
 /* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
  * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);

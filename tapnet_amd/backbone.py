@@ -270,6 +270,12 @@ class Backbone:
 
   def _check(self, rc, what):
     from tapnet_amd import _ffi
+    if rc != 0:
+      # a launch sequence that stops half way may leave arrival counters of the in-launch InstanceNorm merge
+      # (csrc/conv_fused.hpp) non-zero, and every later merge of that buffer would then fire early: start clean
+      for k, t in self._bufs.items():
+        if len(k) > 1 and k[1] == 'arrive':
+          t.zero_()
     _ffi.check(self.engine[0], self.engine[1], rc, what)
 
   def _stream(self):
@@ -495,7 +501,9 @@ class Backbone:
     hi = torch.empty((n, half(half(H)), half(half(W)), c_hi), dtype=torch.float32, device=self.device)
     if n == 0:
       return low, hi
-    streams = max(1, min(int(self.streams), n // 8))
+    # chunked calls exist to BOUND the scratch (feature_extractor_chunk_size, tapir_model.py:689-703): one stream,
+    # one chunk's scratch alive at a time (every stream lane keeps its own buffers)
+    streams = 1 if chunk else max(1, min(int(self.streams), n // 8))
     # hipGraph replay: a clip's backbone is ~60 launches of 10-100 us kernels, which one Python thread
     # cannot issue as fast as the GPU retires them (2.04 ms wall against 1.7 ms of kernels for 48 frames).
     # From the third call with the same shape on, the launches are replayed from a captured graph.
@@ -516,8 +524,8 @@ class Backbone:
       ent['seen'] += 1
       # a few captured shapes at most (their static buffers are large): evict the least recently used
       # CAPTURED entry; entries that were only counted cost nothing and are trimmed separately
-      captured = [k for k, e in self._graphs.items() if 'graph' in e]
-      if len(captured) > 4:
+      captured = [k for k, e in self._graphs.items() if 'graph' in e and k != key]
+      if len(captured) >= 4 and 'graph' not in ent:      # at most four captured graphs resident, this one included
         self._graphs.pop(captured[0])
       if len(self._graphs) > 64:
         for k in [k for k, e in self._graphs.items() if 'graph' not in e][:32]:

@@ -56,7 +56,8 @@ struct CvFusedArgs {
                           // convolution, ONE output logit (occlusion; expd is not written)
   long long* dbg_times;   // TRACE build: [workgroups][8] shader-cycle totals per phase (wave 0)
   // costvol_rows.hpp only:
-  int raw;                // 1: no heads -- points = soft arg max of softmax(temperature * cost map) (occ / expd not written)
+  int raw;                // 1: no heads -- points = soft arg max of softmax(temperature * cost map) (occ / expd not written);
+                          // 2: stop after the contraction (tools: tapir_debug_contraction)
   const int* frame_map;   // null, or [B*T]: unit frame -> index of the grid frame it correlates with
 };
 

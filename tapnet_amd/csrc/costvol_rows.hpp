@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     // tile order (bf16 build; pips.hpp PoolArgs::tiled): chunk 4 s + g of cell c of tile `it` is 16-byte piece
     // (it * 32 + 4 s + g) * 16 + c of the frame: the 16 lanes of a lane group read 256 contiguous bytes, the wave 1 KiB
     const bool tiled = BF && a.grid_tiled != nullptr;
-    const uint4* tbase = reinterpret_cast<const uint4*>(a.grid_tiled) + (gframe * ntile * 32 + g) * 16 + c;
+    const uint4* tbase = tiled ? reinterpret_cast<const uint4*>(a.grid_tiled) + (gframe * ntile * 32 + g) * 16 + c : nullptr;
     auto load_tile = [&](int it, uint4 (&f)[KCH]) {
       if (tiled) {
         const uint4* csrc = tbase + (long)it * 512;
@@ -345,6 +345,10 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   tick(0);
   lds_barrier();   // cost maps complete; the waves part here
   tick(1);
+  if (a.raw == 2) {   // tools/kbench.py --what contraction: time the contraction alone (keep one store so that it is not dead code)
+    if (tid == 0 && a.points != nullptr) a.points[unit] = s_cm[0][pw + 1];
+    return;
+  }
 
   for (int m = wave; m < nq; m += WAVES) {
     float* const cm = s_cm[m * HEADS];               // head hd of this query: cm + hd * CVF_PAD

@@ -749,6 +749,28 @@ int do_cycle_consistency(tapir_ctx* c, const float* qfeat, const float* grid, co
   return TAPIR_OK;
 }
 
+template <typename TA>
+int do_debug_contraction(tapir_ctx* c, const float* qfeat, const float* grid, int B, int Q, int T, int h, int w,
+                         float* scratch, hipStream_t s) {
+  const int C = kLowresDim;
+  const void* qf_op = qfeat; const void* grid_op = grid; const void* tiled_op = nullptr;
+  if (sizeof(TA) == 2) {
+    TRY(cast_or_pool<TA>(c, qfeat, 1, 1, B * Q, C, 0, c->qf_cast, s));
+    if (c->cast_src[1] != grid || c->tiled_src != grid) {
+      TRY(cast_or_pool<TA>(c, grid, (long)B * T, h, w, C, 0, c->grid_cast[1], s, &c->grid_tiled));
+      c->cast_src[1] = grid; c->tiled_src = grid;
+    }
+    qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p; tiled_op = c->cv_tiled ? c->grid_tiled.p : nullptr;
+  }
+  CvFusedArgs fa{};
+  fa.qfeat = qf_op; fa.grid = grid_op; fa.grid_tiled = tiled_op; fa.points = scratch;
+  fa.B = B; fa.Q = Q; fa.T = T; fa.h = h; fa.w = w; fa.temperature = 1.f; fa.img_h = 8.f * h; fa.img_w = 8.f * w;
+  fa.raw = 2;
+  ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
+  launch_cv_rows<TA>(fa, s, 1, c->cv_form);
+  return TAPIR_OK;
+}
+
 int pick_time_chunk(int N, int T) {
   // enough workgroups to fill 256 CUs x 4, chunks of at most MIX_MAX_TC frames, at least ~6
   // frames per chunk so the halo recompute stays small
@@ -832,7 +854,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
-      if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim) {
+      if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim && !fp8w) {   // (fp8w: separate update kernel)
         fa.fuse_update = 1; fa.upd = *upd; *upd_done = true;
       }
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
@@ -1830,6 +1852,16 @@ int tapir_debug_set_update_mode(tapir_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
   c->fuse_update = mode;
   return TAPIR_OK;
+}
+
+// tools/kbench.py --what contraction: the einsum('bnc,bthwc->tbnhw') phase of the row-streamed cost-volume kernel alone
+// (cost maps into LDS, nothing else); scratch: B*T*ceil(Q/8) floats.  The cast of the grid is done once per grid pointer.
+int tapir_debug_contraction(tapir_ctx* c, const float* qfeat, const float* grid, int B, int Q, int T, int h, int w,
+                            float* scratch, void* stream) {
+  if (!c || !qfeat || !grid || !scratch) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!cv_rows_supported(h, w)) return fail(c, TAPIR_ERR_UNSUPPORTED, "rows of up to 32 cells");
+  return DISPATCH(c, do_debug_contraction, c, qfeat, grid, B, Q, T, h, w, scratch, (hipStream_t)stream);
 }
 
 int tapir_debug_set_cv_mode(tapir_ctx* c, int mode) {

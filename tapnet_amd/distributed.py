@@ -119,8 +119,11 @@ def gather_feature_grids(model, video_local, num_frames: int, group=None,
     # (the convolution implementation is chosen from the WHOLE clip's frame count, so a small shard runs
     # the kernels the unsharded call runs: bit-identical sharding, tapnet_amd/backbone.py)
     # (an engine-internal keyword: any other object with the reference's get_feature_grids works unchanged)
-    kw = {'_global_frames': num_frames} if hasattr(model, '_backbone') else {}
-    fg = model.get_feature_grids(video_local, **kw)
+    # (ParameterizedTAPIR forwards get_feature_grids of the TAPIR it wraps: look through the wrapper, or a small
+    # shard of a wrapped model would pick the per-shard convolution path and lose bit-identical sharding)
+    inner = getattr(model, '_model', model)
+    kw = {'_global_frames': num_frames} if hasattr(inner, '_backbone') else {}
+    fg = (inner if kw else model).get_feature_grids(video_local, **kw)
     res = tuple(fg.resolutions)
     levels = list(zip(fg.lowres, fg.hires))
   else:   # empty frame shard: contribute zero-length tensors of the right trailing shape

@@ -12,7 +12,7 @@ from tapnet_amd import _ffi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, 'hipemu')
-EMU_LIB = os.path.join(EMU_DIR, 'libtapir_emu.so')
+EMU_LIB = os.environ.get('TAPIR_EMU_LIB') or os.path.join(EMU_DIR, 'libtapir_emu.so')   # (tests/hipemu/run_asan.sh: the sanitizer build)
 CSRC = os.path.join(os.path.dirname(HERE), 'tapnet_amd', 'csrc')
 
 

@@ -105,6 +105,18 @@ namespace hipemu {
 
 extern "C" void hipemu_switch(void** from_sp, void* to_sp);
 
+// AddressSanitizer builds (build_emu.sh --asan): the fibers run on heap-allocated stacks, which the sanitizer has to be
+// told about at every switch (it keeps the current stack's bounds per thread); no-ops otherwise.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#endif
+#endif
+#ifdef HIPEMU_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+
 struct Block;
 struct Fiber {
   void* sp = nullptr;
@@ -114,6 +126,7 @@ struct Fiber {
   long wait_gen = 0;
   unsigned tid = 0;
   Block* block = nullptr;
+  void* fake = nullptr;                  // (ASAN fake-stack handle of this fiber)
 };
 
 struct WaveBuf {           // one rendezvous buffer (two per wave, alternating)
@@ -135,6 +148,9 @@ struct Block {
   long bar_gen = 0;
   unsigned live = 0;
   void* sched_sp = nullptr;
+  void* sched_fake = nullptr;            // (ASAN: fake-stack handle / bounds of the scheduler's own stack)
+  const void* sched_bottom = nullptr;
+  size_t sched_size = 0;
   Fiber* cur = nullptr;
   const std::function<void()>* body = nullptr;
 };
@@ -146,11 +162,34 @@ inline thread_local Idx3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 
 inline void yield() {
   Block* b = g_block;
+#ifdef HIPEMU_ASAN
+  Fiber* me = b->cur;
+  __sanitizer_start_switch_fiber(me->done ? nullptr : &me->fake, b->sched_bottom, b->sched_size);
+#endif
   hipemu_switch(&b->cur->sp, b->sched_sp);
+#ifdef HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(me->fake, nullptr, nullptr);
+#endif
+}
+
+// scheduler -> fiber f and back
+inline void enter_fiber(Block& b, Fiber& f, char* stack_lo, size_t stack_size) {
+#ifdef HIPEMU_ASAN
+  __sanitizer_start_switch_fiber(&b.sched_fake, stack_lo, stack_size);
+#else
+  (void)stack_lo; (void)stack_size;
+#endif
+  hipemu_switch(&b.sched_sp, f.sp);
+#ifdef HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(b.sched_fake, nullptr, nullptr);
+#endif
 }
 
 inline void fiber_entry() {
   Block* b = g_block;
+#ifdef HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &b->sched_bottom, &b->sched_size);
+#endif
   (*b->body)();
   b->cur->done = true;
   b->live--;
@@ -189,7 +228,7 @@ inline void run_block(Block& b, const std::function<void()>& body) {
     threadIdx_.x = t % b.bdim.x;
     threadIdx_.y = (t / b.bdim.x) % b.bdim.y;
     threadIdx_.z = t / (b.bdim.x * b.bdim.y);
-    hipemu_switch(&b.sched_sp, f.sp);
+    enter_fiber(b, f, f.stack, kStack);
   };
   bool skew = (b.bidx.x & 1u) != 0;
   if (const char* e = getenv("HIPEMU_SKEW")) skew = e[0] == '1';
@@ -242,7 +281,7 @@ inline void run_block(Block& b, const std::function<void()>& body) {
       threadIdx_.x = t % b.bdim.x;
       threadIdx_.y = (t / b.bdim.x) % b.bdim.y;
       threadIdx_.z = t / (b.bdim.x * b.bdim.y);
-      hipemu_switch(&b.sched_sp, f.sp);
+      enter_fiber(b, f, f.stack, kStack);
     }
   }
   free(stacks);

@@ -23,7 +23,7 @@ torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, T, Q, q):
+def _worker(rank, world, port, T, Q, q, wrap=False):
   try:
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -37,12 +37,20 @@ def _worker(rank, world, port, T, Q, q):
     dist.init_process_group(backend, rank=rank, world_size=world)
     S = 64
     w = synthetic.make_weights(17, pyramid_level=1, extra_convs=False)
-    m = tapir_model.TAPIR(pyramid_level=1, weights=w, device=dev, initial_resolution=(S, S))
+    if wrap:   # the reference's entry point: the whole-clip convolution choice has to look through the wrapper
+      m = tapir_model.ParameterizedTAPIR(w, None, dict(pyramid_level=1, initial_resolution=(S, S)), device=dev)
+    else:
+      m = tapir_model.TAPIR(pyramid_level=1, weights=w, device=dev, initial_resolution=(S, S))
     video = torch.as_tensor(synthetic.make_video(3, T, S, S), device=dev)
     qp = torch.as_tensor(synthetic.make_queries(4, Q, T, S, S), device=dev)
     out, fg = tdist.sharded_call(m, video, qp, return_grids=True)
     same = m(tdist.ShapeOnly(video.shape), False, qp, feature_grids=fg)
     bitwise = all(torch.equal(out[k], same[k]) for k in ('tracks', 'occlusion', 'expected_dist'))
+    if not bitwise and os.environ.get('TAPIR_TEST_SHARD_TOL'):
+      # a query shard may select another GEMM algorithm than the whole batch (few-row kernel below 512 token rows,
+      # tiled GEMM above; the track-resident mixer from 128 tracks on): same arithmetic, another summation order
+      tol = float(os.environ['TAPIR_TEST_SHARD_TOL'])
+      bitwise = all(float((out[k] - same[k]).abs().max()) < tol for k in ('tracks', 'occlusion', 'expected_dist'))
     solo = m(video, False, qp)
     d = torch.linalg.norm(out['tracks'] - solo['tracks'], dim=-1)
     shapes_ok = tuple(out['tracks'].shape) == (1, Q, T, 2) and tuple(fg.lowres[0].shape[:2]) == (1, T)
@@ -62,6 +70,30 @@ def test_sharded_call_two_ranks_real_model(T, Q):
   procs = [ctx.Process(target=_worker, args=(r, 2, port, T, Q, q)) for r in range(2)]
   for p in procs: p.start()
   res = [q.get(timeout=600) for _ in range(2)]
+  for p in procs: p.join(60)
+  for rank, backend, bitwise, shapes_ok, med, mx, err in res:
+    assert not err, err
+    assert shapes_ok
+    assert bitwise, f'rank {rank} ({backend}): sharded != unsharded on the same grids'
+    assert med < 1e-3 and mx < 0.05, (med, mx)
+
+
+@pytest.mark.parametrize('T,Q,wrap', [(6, 3, False), (9, 10, True), (48, 13, False)])
+def test_sharded_call_four_ranks_real_model(T, Q, wrap, monkeypatch):
+  """World size 4 (the ranks share the one visible device -> gloo; with >= 4 devices RCCL): ragged frame shards
+  (6 = 2+2+1+1, 9 = 3+2+2+2, 48 = 4 x 12), ragged and EMPTY query shards (3 queries on 4 ranks), and the
+  ParameterizedTAPIR wrapper: frame shards below the HIP convolutions' minimum (4 frames) must run the kernels
+  the whole clip runs, or the sharded result is not bit-equal to the unsharded call on the gathered grids."""
+  import torch.multiprocessing as mp
+  world = 4
+  if T * Q > 512:   # 13 queries x 48 frames = 624 token rows (tiled GEMMs) against shards of 3-4 queries (few-row kernel):
+    monkeypatch.setenv('TAPIR_TEST_SHARD_TOL', '1e-3')   # not bit-equal; within 1e-3 px / logit
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, T, Q, q, wrap)) for r in range(world)]
+  for p in procs: p.start()
+  res = [q.get(timeout=900) for _ in range(world)]
   for p in procs: p.join(60)
   for rank, backend, bitwise, shapes_ok, med, mx, err in res:
     assert not err, err

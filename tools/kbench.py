@@ -385,6 +385,55 @@ def bench_cv(model, reps, results):
     assert lib.tapir_debug_set_cv_mode(ctx, 0) == 0
 
 
+def bench_contraction(model, reps, results):
+  """north_star's explicit kernel target -- the MFMA fraction of einsum('bnc,bthwc->tbnhw') (tapir_model.py:433) -- at
+  the shapes where SURVEY.md 8d says it is meaningful: config 5's cost volume (M = 4096 queries, K = 256, N = 96 frames x
+  32 x 32 cells = 98304: 206 GFLOP) and config 2 (M = 256, N = 49152: 6.4 GFLOP).  Two forms:
+    fused    : the contraction phase of the row-streamed kernel alone (cost maps into LDS, nothing leaves the CU),
+               forms 1 (8 maps per workgroup) and 2 (16 maps), TAPIR_CV_FORM;
+    workspace: the tiled GEMM of the separate-launch path writing the f32 volume to HBM (gemm.hpp), chunks of <= 256 MiB."""
+  lib, ctx = model._lib, model._ctx
+  dev = model.device
+  stream = model._stream()
+  g = torch.Generator(device='cpu').manual_seed(0)
+  for Q, T in ((256, 48), (4096, 96)):
+    grid = torch.nn.functional.normalize(torch.randn(1, T, 32, 32, 256, generator=g), dim=-1).to(dev)
+    qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
+    flops = 2.0 * Q * 256 * T * 1024
+    scratch = torch.zeros(T * ((Q + 7) // 8) + 8, device=dev)
+
+    def run(i):
+      rc = lib.tapir_debug_contraction(ctx, qf.data_ptr(), grid.data_ptr(), 1, Q, T, 32, 32, scratch.data_ptr(), stream)
+      assert rc == 0, lib.tapir_last_error(ctx)
+    run(0)   # (casts the grid once)
+    t = timeit(run, max(5, reps // 2), warm=2)
+    form = int(os.environ.get('TAPIR_CV_FORM', '1'))
+    row = dict(kernel='contraction_fused_phase', form=form, M=Q, K=256, N=T * 1024, dtype=model.dtype, **t,
+               gflop=round(flops / 1e9, 1), tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
+               frac_of_bf16_mfma_peak=round(flops / (t['med_us'] * 1e-6) / 2.5e15, 4),
+               note='includes the cast of the 256 query vectors and the zero fill of the cost maps; the 16-column B port '
+                    'holds 8 (form 1) or 16 (forms 0, 2) queries')
+    results.append(row)
+    print(json.dumps(row), flush=True)
+    # the separate-launch GEMM into a workspace (build_cost_volume), query chunks bounded by the 256-MiB volume
+    qc = max(1, min(Q, (256 << 20) // (T * 1024 * 4)))
+    vol = torch.empty(1, qc, T, 32, 32, device=dev)
+    qsub = qf[:, :qc].contiguous()
+
+    def run2(i):
+      rc = lib.tapir_build_cost_volume(ctx, qsub.data_ptr(), grid.data_ptr(), 1, qc, T, 32, 32, 256, vol.data_ptr(), stream)
+      assert rc == 0, lib.tapir_last_error(ctx)
+    t2 = timeit(run2, max(5, reps // 2), warm=2)
+    f2 = 2.0 * qc * 256 * T * 1024
+    row = dict(kernel='contraction_gemm_to_workspace', M=qc, K=256, N=T * 1024, dtype=model.dtype, **t2,
+               gflop=round(f2 / 1e9, 1), tflops=round(f2 / (t2['med_us'] * 1e-6) / 1e12, 1),
+               frac_of_bf16_mfma_peak=round(f2 / (t2['med_us'] * 1e-6) / 2.5e15, 4),
+               hbm_write_GBps=round(qc * T * 1024 * 4 / (t2['med_us'] * 1e-6) / 1e9, 1),
+               note='writes the f32 volume: M*N*4 bytes; includes the operand casts')
+    results.append(row)
+    print(json.dumps(row), flush=True)
+
+
 def trace_cv_fused(model):
   """per-phase shader-cycle totals of the row-streamed fused cost-volume kernel (costvol_rows.hpp), every wave of every
   workgroup; TRACE build (tapnet_amd/csrc/build.sh --exp, TAPIR_HIP_LIB=tools/bin/libtapir_hip_exp.so)"""
@@ -628,6 +677,8 @@ def main():
       trace_conv(model)
     if 'cvfusedtrace' in what:
       trace_cv_fused(model)
+    if 'contraction' in what:
+      bench_contraction(model, args.reps, results)
     if 'fusedtrace' in what:
       trace_fused(model)
     if 'widetrace' in what:
