@@ -388,6 +388,10 @@ int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
 /* refine_pips's state update (tapir_model.py:613-623): 1 (default) = applied by the output stage of the track-resident
  * mixer kernels, 0 = always the separate update kernel on the mixer's [R,388] output (A/B, tests; bit-identical). */
 int tapir_debug_set_update_mode(tapir_ctx* ctx, int mode);
+/* refine_pips's front half (patch correlation + mixer input rows, tapir_model.py:496-594): 0 (default) = the separate
+ * patch_corr_kernel launch writing mlp_in to HBM; 1 = built by the track-resident mixer kernel in its prologue, straight
+ * into LDS, where that kernel runs (bit-identical; measured equal in time: profiles/r04_ab_fuse_patch.txt). */
+int tapir_debug_set_patch_mode(tapir_ctx* ctx, int mode);
 int tapir_debug_mix(tapir_ctx* ctx, int block, const float* x_in, float* x_out, void* xn,
                     int N, int T, int tc, void* stream);
 

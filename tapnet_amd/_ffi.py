@@ -118,6 +118,7 @@ PROTOTYPES = {
     'tapir_debug_set_trace': (c_int, [c_void_p, c_void_p]),
     'tapir_debug_set_mixer_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_set_cv_mode': (c_int, [c_void_p, c_int]),
+    'tapir_debug_set_patch_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_contraction': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tapir_debug_set_gemm_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_set_update_mode': (c_int, [c_void_p, c_int]),

@@ -80,6 +80,8 @@ class Backbone:
     # With BootsTAPIR's ExtraConvs (large, MFMA-bound launches that fill the chip on their own) two groups are 3.5 %
     # faster than four (3.49-3.54 against 3.64-3.69 ms per clip, tools/exp_streams.py, same box).
     self.streams = (2 if extra_convs else 4) if dtype == torch.bfloat16 else 1
+    if os.environ.get('TAPIR_BACKBONE_STREAMS'):   # (A/B measurements, tools/bench_backbone.py)
+      self.streams = int(os.environ['TAPIR_BACKBONE_STREAMS'])
     self._side_streams = []
     self._lane = 0
     # 'auto': the convolutions of the ResNet blocks (3x3 and 1x1, stride 1 and 2: everything but the 7x7

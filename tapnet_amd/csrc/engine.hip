@@ -82,6 +82,8 @@ struct tapir_ctx {
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   bool cv_tiled = true;                           // row-streamed cost volume, bf16: contraction operand in tile order (TAPIR_CV_TILED=0: row-major, A/B)
+  bool fuse_patch = false;                        // refine_pips's front half in the track-resident mixer's prologue (TAPIR_FUSE_PATCH=1; measured: the
+                                                  // prologue costs what the separate launch costs, profiles/r04_ab_fuse_patch.txt -- opt-in)
   int cv_form = 1;                                // row-streamed cost volume: maps x waves per workgroup (costvol_rows.hpp; TAPIR_CV_FORM, A/B)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
@@ -803,9 +805,14 @@ int mixer_gemm(tapir_ctx* c, const GemmArgs& g, hipStream_t s) {
 // upd (nullable): the state update that follows the mixer in refine_pips; the track-resident kernels apply it in
 // their output stage and set *upd_done (the caller then skips update_kernel)
 template <typename TA>
+void launch_patch_args(tapir_ctx* c, const PatchArgs& pa, hipStream_t s);
+
+template <typename TA>
 int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
               float* ctx1_out, float* ctx2_out, hipStream_t s, const UpdateArgs* upd = nullptr,
-              bool* upd_done = nullptr) {
+              bool* upd_done = nullptr, const PatchArgs* patch = nullptr) {
+  // patch != null: the mixer input rows are still to be built (refine_pips's front half).  The track-resident kernel
+  // builds them in its prologue (fuse_patch); every other form gets them from patch_corr_kernel, launched here.
   const long R = (long)N * T;
   const int nb = c->cfg.num_mixer_blocks;
   // track-resident fused kernel (mixer_fused.hpp) for whole non-causal clips; separate launches for
@@ -842,9 +849,13 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
       if (wide) fused = false;
     }
+    const bool in_prologue = patch != nullptr && fused && !wide && !fp8w && c->fuse_patch && c->mixer_mode != 4;
+    if (patch != nullptr && !in_prologue) launch_patch_args<TA>(c, *patch, s);
+    patch = in_prologue ? patch : nullptr;
     if (fused || wide) {
       TRY(ensure(c, c->res, (size_t)R * kMixOut * 4));
       FusedArgs fa{};
+      if (patch != nullptr) { fa.fuse_patch = 1; fa.patch = *patch; }
       fa.mlp_in = c->mlp_in.p; fa.ld_in = c->k0_pad;
       fa.stream = wide ? c->fused_wide_stream : c->fused_stream;
       fa.frags_per_wave = wide ? c->fused_wide_fpw : c->fused_fpw;
@@ -926,9 +937,9 @@ struct LevelGrids {   // operand-type pyramid of one feature level
 };
 
 template <typename TA>
-int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const float* pos,
-                 const float* occ, const float* expd, const float* feats, int orig_h, int orig_w,
-                 hipStream_t s) {
+int make_patch_args(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const float* pos,
+                    const float* occ, const float* expd, const float* feats, int orig_h, int orig_w,
+                    PatchArgs* out) {
   const long R = (long)B * Q * T;
   TRY(ensure(c, c->mlp_in, (size_t)R * c->k0_pad * sizeof(TA)));
   PatchArgs pa{};
@@ -942,8 +953,23 @@ int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const 
   pa.mlp_in = c->mlp_in.p; pa.ld = c->k0_pad;
   pa.B = B; pa.Q = Q; pa.T = T;
   pa.orig_h = (float)orig_h; pa.orig_w = (float)orig_w;
-  { ProfScope ps(c, TAPIR_PROF_PATCH, s);
-    TAPIR_LAUNCH((patch_corr_kernel<TA, TA>), dim3(patch_corr_grid(B, Q, T)), dim3(256), s, pa); }
+  *out = pa;
+  return TAPIR_OK;
+}
+
+template <typename TA>
+void launch_patch_args(tapir_ctx* c, const PatchArgs& pa, hipStream_t s) {
+  ProfScope ps(c, TAPIR_PROF_PATCH, s);
+  TAPIR_LAUNCH((patch_corr_kernel<TA, TA>), dim3(patch_corr_grid(pa.B, pa.Q, pa.T)), dim3(256), s, pa);
+}
+
+template <typename TA>
+int launch_patch(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, const float* pos,
+                 const float* occ, const float* expd, const float* feats, int orig_h, int orig_w,
+                 hipStream_t s) {
+  PatchArgs pa{};
+  TRY(make_patch_args<TA>(c, lg, B, Q, T, pos, occ, expd, feats, orig_h, orig_w, &pa));
+  launch_patch_args<TA>(c, pa, s);
   return TAPIR_OK;
 }
 
@@ -1040,8 +1066,8 @@ int refine_iter(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, float* 
                 float vx, float vy, float* out_tracks, float* out_occ, float* out_expd,
                 const float* c1i, const float* c2i, float* c1o, float* c2o, hipStream_t s) {
   const long R = (long)B * Q * T;
-  TRY(launch_patch<TA>(c, lg, B, Q, T, pos, occ, expd, first_of_level ? nullptr : feats, orig_h,
-                       orig_w, s));
+  PatchArgs pa{};
+  TRY(make_patch_args<TA>(c, lg, B, Q, T, pos, occ, expd, first_of_level ? nullptr : feats, orig_h, orig_w, &pa));
   UpdateArgs u{};
   u.pos = pos; u.occ = occ; u.expd = expd; u.feats = feats;
   u.q_hires = lg.query[0]; u.q_lowres = lg.query[1];
@@ -1052,7 +1078,7 @@ int refine_iter(tapir_ctx* c, const LevelGrids& lg, int B, int Q, int T, float* 
   u.first_of_level = first_of_level ? 1 : 0;
   u.last_of_level = last_of_level ? 1 : 0;
   bool upd_done = false;
-  TRY(run_mixer<TA>(c, B * Q, T, c1i, c2i, c1o, c2o, s, &u, &upd_done));
+  TRY(run_mixer<TA>(c, B * Q, T, c1i, c2i, c1o, c2o, s, &u, &upd_done, &pa));
   if (!upd_done) {   // separate-launch mixer: res [R,388] in the workspace
     u.res = (const float*)c->res.p;
     hipLaunchKernelGGL(update_kernel, dim3((unsigned)R), dim3(128), 0, s, u);
@@ -1195,6 +1221,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
+  if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   *out = c;
   return TAPIR_OK;
@@ -1845,6 +1872,12 @@ int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
 int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
   c->small_gemm = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_patch_mode(tapir_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  c->fuse_patch = mode != 0;
   return TAPIR_OK;
 }
 

@@ -37,6 +37,7 @@
 #include "common.hpp"
 #include "gemm.hpp"    // MfmaStep
 #include "mixer.hpp"   // kLnEps
+#include "pips.hpp"    // PatchArgs, patch_row (fuse_patch)
 
 namespace tapir {
 
@@ -88,6 +89,11 @@ struct FusedArgs {
   // this iteration's output slices.  fuse_update = 0: plain res output (tapir_pips_mixer).
   int fuse_update;
   UpdateArgs upd;
+  // refine_pips's front half (tapir_model.py:496-594; pips.hpp) inside the prologue: every wave builds the input rows of
+  // its share of the track's frames -- header, features, 7x7 correlations -- straight into the LDS input image, instead
+  // of a separate launch writing mlp_in [R, ld] to HBM for this kernel to read back.  fuse_patch = 0: rows from mlp_in.
+  int fuse_patch;
+  PatchArgs patch;
 };
 
 // Output of the mixer for token row r, output channels o0 .. o0 + 3 (o0 a multiple of 4, < 388): either stored to
@@ -322,7 +328,23 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 
   // ---- stage the mixer-input rows of this track: [ROWS][ld_in], rows >= T zero
   const int in_stride = a.ld_in * (int)sizeof(TA);
-  {
+  if (a.fuse_patch) {
+    // built here (pips.hpp::patch_row): wave w takes frames w, w + 8, ...; LDS row 16 i + c holds token NT c + i, the
+    // 16-byte chunks of a row are XOR-swizzled by the row's low 4 bits (as below)
+    char* const img = reinterpret_cast<char*>(s_act);
+    for (int tok = wave; tok < ROWS; tok += FM_WAVES) {
+      const int row = 16 * (tok % NT) + tok / NT;
+      char* const rp = img + row * in_stride;
+      auto put = [&](int ccol, float v) {
+        Elem<TA>::st(reinterpret_cast<TA*>(rp + (((ccol / EPC) ^ (row & 15)) << 4)) + (ccol % EPC), v);
+      };
+      if (tok < T) {
+        patch_row<TA>(a.patch, (long)n * T + tok, lane, put);
+      } else {
+        for (int ccol = lane; ccol < a.ld_in; ccol += 64) put(ccol, 0.f);
+      }
+    }
+  } else {
     const int cpr = in_stride >> 4;   // 16-byte chunks per row (a multiple of 16)
     const uint4* src = reinterpret_cast<const uint4*>(
         reinterpret_cast<const char*>(a.mlp_in) + (long)n * T * in_stride);

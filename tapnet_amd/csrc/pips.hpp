@@ -132,6 +132,45 @@ inline unsigned patch_corr_grid(long B, long Q, long T) {
   return (unsigned)((B * Q * T + PATCH_TOKENS_PER_WG - 1) / PATCH_TOKENS_PER_WG);
 }
 
+// The mixer-input row of token r = (b * Q + q) * T + t: header, features, zero tail and the 7x7 correlations of
+// every pyramid level, handed element by element to st(c, v) (c = column of the row) by ONE wave.  Used by
+// patch_corr_kernel (stores to HBM) and by the track-resident mixer's prologue (stores into its LDS input image:
+// mixer_fused.hpp, fuse_patch).
+template <typename TG, typename St>
+__device__ __forceinline__ void patch_row(const PatchArgs& a, long r, int lane, St&& st) {
+  const int t = (int)(r % a.T);
+  const long bq = r / a.T;
+  const int b = (int)(bq / a.Q);
+  // header + features + zero padding of the K tail
+  const int ncorr0 = kMixOut;
+  for (int c = lane; c < a.ld; c += 64) {
+    float v;
+    if (c < 2) v = 0.f;                       // position channels are always zero (:583)
+    else if (c == 2) v = a.occ[r];
+    else if (c == 3) v = a.expd[r];
+    else if (c < ncorr0) {
+      const int f = c - 4;
+      if (a.feats != nullptr) v = a.feats[r * kFeatDim + f];
+      else v = (f < kHiresDim) ? a.lvl[0].query[bq * kHiresDim + f]
+                               : a.lvl[1].query[bq * kLowresDim + (f - kHiresDim)];
+    } else if (c >= ncorr0 + kPatch * a.n_levels) v = 0.f;
+    else continue;                            // correlation slots: written below
+    st(c, v);
+  }
+  const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
+  const long frame = (long)b * a.T + t;
+  const int i = lane >> 3, j = lane & 7;
+  for (int l = 0; l < a.n_levels; ++l) {
+    const PyrLevel& L = a.lvl[l];
+    // the query vector of this level: the refined per-token feature, or the (tiled) query feature
+    const float* qsrc = (a.feats != nullptr) ? a.feats + r * kFeatDim + L.feat_off : L.query + bq * L.C;
+    float corr;
+    if (L.C == 256) corr = level_corr<256, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
+    else corr = level_corr<128, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
+    if (i < 7 && j < 7) st(ncorr0 + kPatch * l + i * 7 + j, corr);
+  }
+}
+
 template <typename TG, typename TO>
 __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
   const int tid = threadIdx.x;
@@ -148,40 +187,8 @@ __global__ __launch_bounds__(256) void patch_corr_kernel(PatchArgs a) {
     r = (long)blockIdx.x * PATCH_TOKENS_PER_WG + wave;
     if (r >= frames * a.Q) return;
   }
-  const int t = (int)(r % a.T);
-  const long bq = r / a.T;
-  const int b = (int)(bq / a.Q);
   TO* out = reinterpret_cast<TO*>(a.mlp_in) + r * a.ld;
-
-  // header + features + zero padding of the K tail
-  const int ncorr0 = kMixOut;
-  for (int c = lane; c < a.ld; c += 64) {
-    float v;
-    if (c < 2) v = 0.f;                       // position channels are always zero (:583)
-    else if (c == 2) v = a.occ[r];
-    else if (c == 3) v = a.expd[r];
-    else if (c < ncorr0) {
-      const int f = c - 4;
-      if (a.feats != nullptr) v = a.feats[r * kFeatDim + f];
-      else v = (f < kHiresDim) ? a.lvl[0].query[bq * kHiresDim + f]
-                               : a.lvl[1].query[bq * kLowresDim + (f - kHiresDim)];
-    } else if (c >= ncorr0 + kPatch * a.n_levels) v = 0.f;
-    else continue;                            // correlation slots: written below
-    Elem<TO>::st(out + c, v);
-  }
-
-  const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
-  const long frame = (long)b * a.T + t;
-  const int i = lane >> 3, j = lane & 7;
-  for (int l = 0; l < a.n_levels; ++l) {
-    const PyrLevel& L = a.lvl[l];
-    // the query vector of this level: the refined per-token feature, or the (tiled) query feature
-    const float* qsrc = (a.feats != nullptr) ? a.feats + r * kFeatDim + L.feat_off : L.query + bq * L.C;
-    float corr;
-    if (L.C == 256) corr = level_corr<256, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
-    else corr = level_corr<128, TG>(L, qsrc, frame, px, py, a.orig_w, a.orig_h, lane);
-    if (i < 7 && j < 7) Elem<TO>::st(out + ncorr0 + kPatch * l + i * 7 + j, corr);
-  }
+  patch_row<TG>(a, r, lane, [&](int c, float v) { Elem<TO>::st(out + c, v); });
 }
 
 // ---- query features: trilinear sample with index clamping

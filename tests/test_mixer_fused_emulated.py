@@ -127,6 +127,35 @@ def test_fused_state_update_is_bit_identical(mode, dtype, T, Q):
   e.close()
 
 
+@pytest.mark.parametrize('dtype,T,Q,pyr', [(_ffi.TAPIR_F32, 20, 3, 1), (_ffi.TAPIR_BF16, 33, 2, 1), (_ffi.TAPIR_BF16, 48, 2, 0)])
+def test_patch_rows_built_in_the_mixer_prologue_are_bit_identical(dtype, T, Q, pyr):
+  """refine_pips's front half (tapir_model.py:496-594: header, features, 7x7 patch correlations per pyramid level)
+  built by the track-resident mixer kernel in its prologue, straight into the swizzled LDS input image
+  (mixer_fused.hpp fuse_patch, pips.hpp patch_row), against the separate patch_corr_kernel launch through HBM: the
+  same device function, the same rounding to the operand type -- every output of estimate_trajectories over two
+  refinement levels (first / later iterations: query features, then refined features) is bit-identical; ragged
+  clips (20, 33 frames: zero rows past the clip end) and both pyramid depths."""
+  w = synthetic.make_weights(6, pyr, False, num_mixer_blocks=2, backbone=False)
+  e = EmuEngine(w, pyramid_level=pyr, num_pips_iter=2, num_mixer_blocks=2, initial_resolution=(64, 64), dtype=dtype)
+  rng = np.random.default_rng(T + pyr)
+  S = 64
+  lows = [O.l2_normalize(rng.standard_normal((1, T, 8, 8, 256)).astype(np.float32)) for _ in range(2)]
+  his = [O.l2_normalize(rng.standard_normal((1, T, 16, 16, 128)).astype(np.float32)) for _ in range(2)]
+  lows, his, res = [lows[0], lows[0], lows[1]], [his[0], his[0], his[1]], [(S, S)] * 3
+  qp = synthetic.make_queries(7, Q, T, S, S)
+  qp[0, 0, 1:] = [1.0, S - 0.5]        # a patch that leaves the grid
+  ql, qh = O.get_query_features(lows, his, res, qp, (1, T, S, S, 3))
+  assert e.lib.tapir_debug_set_mixer_mode(e.ctx, 2) == 0
+  outs = {}
+  for mode in (0, 1):
+    assert e.lib.tapir_debug_set_patch_mode(e.ctx, mode) == 0
+    outs[mode] = e.estimate_trajectories((S, S), lows, his, res, ql, qh, qp)
+  for k in ('tracks', 'occlusion', 'expected_dist'):
+    np.testing.assert_array_equal(outs[0][k], outs[1][k])
+  assert np.isfinite(outs[1]['tracks']).all()
+  e.close()
+
+
 def _fp8_e4m3(x):
   """nearest OCP e4m3 value (round to nearest even, saturating at 448, subnormals down to 2^-9)"""
   x = np.asarray(x, np.float64)

@@ -35,6 +35,10 @@ KERNELS = {
     'xconv_256_1024_gelu': ('xconv_kernel<unsigned short, 256, true, false', ''),
     'xconv_1024_256_skip': ('xconv_kernel<unsigned short, 256, false, true', ''),
     'ln_affine': ('ln_affine_kernel<unsigned short', ''),
+    # round 4
+    'cv_rows': ('cv_rows_kernel<unsigned short', ''),
+    'l2norm': ('l2norm_kernel<unsigned short', ''),
+    'pool_cast': ('pool_cast_kernel<unsigned short', ''),
 }
 
 
