@@ -88,6 +88,13 @@ __device__ __forceinline__ float rol1(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12F, 0xf, 0xf, false));   // row_ror:15
 #endif
 }
+// value the optimiser cannot see through (keeps a splat from being hoisted as a live vector)
+__device__ __forceinline__ float opaque_f32(float v) {
+#ifndef TAPIR_HIPEMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 // lane l <- v[l - 16] (the same column of the previous lane group); lane group 0 <- 0
 __device__ __forceinline__ float group_up(float v, int lane) {
 #ifdef TAPIR_HIPEMU
@@ -418,7 +425,10 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     // F: output row oy of the stride-2 convolution from ring rows 2 oy - ply .. + 2
     auto occl_row = [&](int oy) {
       wave_sync();
-      oc0 = f32x4{b3a, b3a, b3a, b3a}; oc1 = f32x4{b3b, b3b, b3b, b3b};
+      // (the bias splats are rebuilt from ONE register each: hoisted out of the row loop as two 4-register vectors they
+      // were spilled under the 128-VGPR cap and reloaded from scratch, with a vmcnt(0), in front of every occlusion row)
+      const float ba = opaque_f32(b3a), bb = opaque_f32(b3b);
+      oc0 = f32x4{ba, ba, ba, ba}; oc1 = f32x4{bb, bb, bb, bb};
       const int r0 = 2 * oy - ply;
       if (BF) {
         // k = tap * 16 + ci (padded to 160): lane group g of k-step s reads channels 8 (g & 1) .. +7 of
