@@ -372,7 +372,7 @@ int tapir_debug_set_trace(tapir_ctx* ctx, void* device_buffer);
 int tapir_debug_set_mixer_mode(tapir_ctx* ctx, int mode);
 /* Cost-volume stage (tapir_tracks_from_cost_volume and the first stage of
  * tapir_estimate_trajectories): 0 = automatic (ONE kernel -- einsum on the matrix cores into LDS +
- * heads, no volume in HBM -- for grids of up to 32 x 32 cells; larger grids take the path below),
+ * heads, no volume in HBM -- for grids of up to 64 x 64 cells; other shapes take the path below, up to 1600 cells),
  * 1 = einsum GEMM into a workspace followed by the heads kernel (round-1 path; tools A/B it),
  * 2 = the fused kernel in its pixel-tiled form (costvol_fused.hpp: one map at a time over the whole
  * workgroup) also where automatic picks the row-streamed form (costvol_rows.hpp: every wave owns whole

@@ -36,7 +36,8 @@
 // Everything that feeds the soft arg max is exact f32 in both builds.
 // LDS (bf16 build): 16 cost maps 72 KiB + 8 rings 34 KiB = 107 KiB; f32 build: 8 maps 36 KiB + rings 68 KiB.
 //
-// Grids wider than 32 cells (or taller than 16 register rows allow) stay on costvol_fused.hpp.
+// Rows of 33 .. 64 cells run the wide instantiation (PW = 66, below); rows of <= 32 cells taller than 16 register rows
+// allow stay on costvol_fused.hpp.
 #pragma once
 #include "common.hpp"
 #include "costvol.hpp"         // CvHeadWeights
@@ -133,16 +134,24 @@ __device__ __forceinline__ float relu_f32(float x) {
 // RAGW = false: w is exactly 16 NTX (the selects that zero the pixels past the row end are compiled out).
 // WAVES = 8 or 16 waves per workgroup (16: one map per wave at QPW = 16, four waves per SIMD from ONE workgroup at
 // half the grid reads of two QPW = 8 workgroups; needs <= 128 VGPRs).
-template <typename TA, int QPW, int NTX, bool TRACE = false, int HEADS = 1, bool RAGW = true, int WAVES = CVR_WAVES>
-__global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void cv_rows_kernel(CvFusedArgs a) {
+// PW = padded row length of the LDS images: 34 (rows of <= 32 cells, NTX <= 2) or 66 (rows of <= 64 cells, NTX = 3 / 4:
+// `initial_resolution` up to 512 x 512 -- 6 maps on 6 waves (4 on 4 in the f32 build) fill the 160 KiB of LDS, the
+// logits of the soft-arg-max pass are streamed from LDS twice instead of held in registers, an occlusion row is two tiles).
+template <typename TA, int QPW, int NTX, bool TRACE = false, int HEADS = 1, bool RAGW = true, int WAVES = CVR_WAVES,
+          int PW = CVR_PW>
+__global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES == 8) ? 2 : 4) void cv_rows_kernel(CvFusedArgs a) {
   constexpr int THREADS = WAVES * 64;
+  constexpr int PAD = PW == CVR_PW ? CVF_PAD : PW * PW;   // floats per cost map incl. the halo
+  constexpr bool ZSTREAM = PW > CVR_PW;                     // soft arg max: two passes over the in-place logits
+  constexpr int NOT = NTX > 2 ? 2 : 1;                      // 16-pixel tiles of an occlusion-convolution output row
+  static_assert(NTX * 16 <= PW - 2, "tiles per row");
   constexpr int QPT = QPW / HEADS;                   // queries per tile
   static_assert(QPW % HEADS == 0 && (16 / (int)sizeof(TA)) % HEADS == 0, "heads");
   constexpr int EPC = 16 / (int)sizeof(TA);          // elements per 16-byte chunk
   constexpr int KCH = kLowresDim / EPC / 4;          // chunk-steps over K = 256 (4 chunks per step)
   constexpr bool BF = sizeof(TA) == 2;
-  constexpr int RING_ROW = CVR_PW * 16 * (int)sizeof(TA) / 16;   // uint4 per ring row
-  __shared__ __attribute__((aligned(16))) float s_cm[QPW][CVF_PAD];            // cost maps (zero halo), then logits in place
+  constexpr int RING_ROW = PW * 16 * (int)sizeof(TA) / 16;   // uint4 per ring row
+  __shared__ __attribute__((aligned(16))) float s_cm[QPW][PAD];                // cost maps (zero halo), then logits in place
   __shared__ uint4 s_ring[WAVES][CVR_RING * RING_ROW];                     // relu(hid1) [row & 3][pixel][16 ch], zero halo
   __shared__ __attribute__((aligned(16))) float s_head[512 + 16 + 32 + 2 + 2];  // w4 [16][32], b4, w5 [2][16], b5
   __shared__ float s_vec[WAVES][32 + 16];
@@ -248,8 +257,8 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     if (it < ntile) load_tile(it, fa0);              // the first two tiles fly while the halos are zeroed
     if (it + WAVES < ntile) load_tile(it + WAVES, fa1);
     // zero: cost maps (halo cells are never written), rings (halo columns / out-of-image rows)
-    static_assert((QPW * CVF_PAD) % 4 == 0, "16-byte zero fill");
-    for (int i = tid; i < QPW * CVF_PAD / 4; i += THREADS) reinterpret_cast<uint4*>(&s_cm[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+    static_assert((QPW * PAD) % 4 == 0, "16-byte zero fill");
+    for (int i = tid; i < QPW * PAD / 4; i += THREADS) reinterpret_cast<uint4*>(&s_cm[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = lane; i < CVR_RING * RING_ROW; i += 64) s_ring[wave][i] = make_uint4(0u, 0u, 0u, 0u);
     lds_barrier();   // zero fill done before the first cost values land
     // D: lane holds cells itile*16 + 4 g + r of map c (= query c / HEADS, head c % HEADS).  The cell -> (row, column)
@@ -290,16 +299,18 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       it += WAVES;
     }
   }
-  // head tail (Linear 32 -> 16, Linear 16 -> 2): 562 floats through LDS, both loads in flight together
-  static_assert(THREADS >= 512, "head staging assumes >= 512 threads");
+  // head tail (Linear 32 -> 16, Linear 16 -> 2): 562 floats through LDS, all loads of a thread in flight together
   if (!a.raw) {
     const int n5 = a.tapnet ? 16 : 32, nb5 = a.tapnet ? 1 : 2;
-    float hv0 = 0.f, hv1 = 0.f;
-    if (tid < 512) hv0 = a.wt.w4[tid];
+    constexpr int PER = (512 + THREADS - 1) / THREADS;
+    float hv[PER], hv1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) hv[k] = tid + k * THREADS < 512 ? a.wt.w4[tid + k * THREADS] : 0.f;
     if (tid < 16) hv1 = a.wt.b4[tid];                  // 16 + n5 + nb5 <= 50 further values
     else if (tid < 16 + n5) hv1 = a.wt.w5[tid - 16];
     else if (tid < 16 + n5 + nb5) hv1 = a.wt.b5[tid - 16 - n5];
-    if (tid < 512) s_head[tid] = hv0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) if (tid + k * THREADS < 512) s_head[tid + k * THREADS] = hv[k];
     if (tid < 16 + n5 + nb5) s_head[512 + (tid < 16 + n5 ? tid : 48 + (tid - 16 - n5))] = hv1;
   }
   // occlusion convolution: stride 2, XLA SAME (pad_lo = total / 2)
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       for (int n = 0; n < 2; ++n) wb[s][n] = a.wt.w3b[(s * 2 + n) * 64 + lane];
   }
   // soft-arg-max pass: lane <-> (row within a group of RPS rows, column): cells of CVR_ZREG row groups
-  const int wq = w <= 16 ? 16 : 32, rps = 64 / wq;      // rows per step
+  const int wq = w <= 16 ? 16 : w <= 32 ? 32 : 64, rps = 64 / wq;      // rows per step
   const int zx = lane & (wq - 1), zy = lane / wq;
   const bool zcol = zx < w;
   const float zcx = (float)zx + 0.5f;
@@ -326,9 +337,11 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
 #pragma unroll
   for (int tx = 0; tx < NTX; ++tx) { px[tx] = 16 * tx + c; pin[tx] = px[tx] < w; }
   constexpr bool ragw = RAGW;
-  bool ovalid[4];                // output pixels 4 g + r of an occlusion row that exist (ow <= 16: one tile)
+  bool ovalid[NOT][4];           // output pixels 16 ot + 4 g + r of an occlusion row that exist
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ovalid[r] = 4 * g + r < ow;
+  for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ovalid[ot][r] = 16 * ot + 4 * g + r < ow;
   constexpr bool full_ow = NTX == 2 && !RAGW;      // w = 32: all 16 output pixels of an occlusion row exist
   const float floor3 = a.tapnet ? -3.0e38f : 0.f;   // TAPIR: ReLU (tapir_model.py:461); TAP-Net: none
   const float b2t = b2 * a.temperature;
@@ -338,14 +351,18 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int tx = 0; tx < NTX; ++tx) cbase[j][tx] = pw + min(16 * tx + c, w - 1) + 1 + off1[j];
-  // occlusion convolution: this lane's A row = output pixel min(c, ow - 1); ring column of tap column 0
-  const int ocol = 2 * min(c, ow - 1) - plx + 1;
-  int otap_row[5], otap_off[5];   // k-step s: ring row (relative to 2 oy - ply) and uint4 offset inside the row
+  // occlusion convolution: this lane's A row of tile ot = output pixel min(16 ot + c, ow - 1); ring column of tap column 0
+  int ocol[NOT];
+  int otap_row[5], otap_off[NOT][5];   // k-step s: ring row (relative to 2 oy - ply) and uint4 offset inside the row
 #pragma unroll
-  for (int s5 = 0; s5 < 5; ++s5) {
-    const int tap = min(2 * s5 + (g >> 1), 8);       // tap 9 has zero weights
-    otap_row[s5] = tap / 3;
-    otap_off[s5] = (ocol + tap % 3) * 2 + (g & 1);
+  for (int ot = 0; ot < NOT; ++ot) {
+    ocol[ot] = 2 * min(16 * ot + c, ow - 1) - plx + 1;
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int tap = min(2 * s5 + (g >> 1), 8);       // tap 9 has zero weights
+      otap_row[s5] = tap / 3;
+      otap_off[ot][s5] = (ocol[ot] + tap % 3) * 2 + (g & 1);
+    }
   }
   uint4* const ring = s_ring[wave];
   float* const vec = s_vec[wave];
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   }
 
   for (int m = wave; m < nq; m += WAVES) {
-    float* const cm = s_cm[m * HEADS];               // head hd of this query: cm + hd * CVF_PAD
+    float* const cm = s_cm[m * HEADS];               // head hd of this query: cm + hd * PAD
     float pend[NTX];                                 // pending logit sums (lane group g: row y + 1 - g)
     float osum[2] = {0.f, 0.f};                      // sum over this lane's output pixels of relu(conv + b3), channels c, 16 + c
 #pragma unroll
@@ -390,10 +407,10 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int tx = 0; tx < NTX; ++tx)   // pixels past the row end read the halo / the next row: zeroed in C
-            cmv[hd][j][tx] = row[hd * CVF_PAD + cbase[j][tx]];
+            cmv[hd][j][tx] = row[hd * PAD + cbase[j][tx]];
     };
     f32x4 d2p[NTX];                                  // conv 2 of the previous row
-    f32x4 oc0, oc1;                                  // occlusion row multiplied in the previous iteration (bias inside)
+    f32x4 oc0[NOT], oc1[NOT];                        // occlusion row multiplied in the previous iteration (bias inside)
     bool oc_pending = false;
     // E: s = P[g,0][x-1] + P[g,1][x] + P[g,2][x+1], then the lane-group chain; lane group 2 ends up with the logits of
     // row yl, stored in place of the cost map's row yl (yl = -1: the dead top halo row)
@@ -414,13 +431,15 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
           if (!ragw || pin[tx]) zrow[px[tx]] = zv[tx];
       }
     };
-    auto occl_sum = [&]() {   // D of the occlusion row: lane holds channel c (and 16 + c), output pixels 4 g + r
+    auto occl_sum = [&]() {   // D of the occlusion row: lane holds channel c (and 16 + c), output pixels 16 ot + 4 g + r
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v0 = max1_f32(oc0[r], floor3), v1 = max1_f32(oc1[r], floor3);
-        osum[0] += (full_ow || ovalid[r]) ? v0 : 0.f;
-        osum[1] += (full_ow || ovalid[r]) ? v1 : 0.f;
-      }
+      for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = max1_f32(oc0[ot][r], floor3), v1 = max1_f32(oc1[ot][r], floor3);
+          osum[0] += (full_ow || ovalid[ot][r]) ? v0 : 0.f;
+          osum[1] += (full_ow || ovalid[ot][r]) ? v1 : 0.f;
+        }
     };
     // F: output row oy of the stride-2 convolution from ring rows 2 oy - ply .. + 2
     auto occl_row = [&](int oy) {
@@ -428,33 +447,37 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
       // (the bias splats are rebuilt from ONE register each: hoisted out of the row loop as two 4-register vectors they
       // were spilled under the 128-VGPR cap and reloaded from scratch, with a vmcnt(0), in front of every occlusion row)
       const float ba = opaque_f32(b3a), bb = opaque_f32(b3b);
-      oc0 = f32x4{ba, ba, ba, ba}; oc1 = f32x4{bb, bb, bb, bb};
       const int r0 = 2 * oy - ply;
-      if (BF) {
-        // k = tap * 16 + ci (padded to 160): lane group g of k-step s reads channels 8 (g & 1) .. +7 of
-        // tap 2 s + (g >> 1): one 16-byte read of the pixel-major bf16 ring
 #pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) {
-          const int rr = (r0 + otap_row[s5]) & (CVR_RING - 1);
-          const uint4 af = ring[rr * RING_ROW + otap_off[s5]];
-          oc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
-                                                        __builtin_bit_cast(bf16x8, wb[s5][0]), oc0, 0, 0, 0);
-          oc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
-                                                        __builtin_bit_cast(bf16x8, wb[s5][1]), oc1, 0, 0, 0);
-        }
-      } else {
-        // exact f32: 36 k-slices of 4: slice j = (tap = j / 4, channels 4 (j % 4) + g)
-        const float* h1 = reinterpret_cast<const float*>(ring);
-        for (int tap = 0; tap < 9; ++tap) {
-          const int rr = (r0 + tap / 3) & (CVR_RING - 1);
-          const int pp = rr * CVR_PW + ocol + tap % 3;
+      for (int ot = 0; ot < NOT; ++ot) {
+        if (ot * 16 >= ow) { oc0[ot] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}; oc1[ot] = oc0[ot]; continue; }
+        oc0[ot] = f32x4{ba, ba, ba, ba}; oc1[ot] = f32x4{bb, bb, bb, bb};
+        if (BF) {
+          // k = tap * 16 + ci (padded to 160): lane group g of k-step s reads channels 8 (g & 1) .. +7 of
+          // tap 2 s + (g >> 1): one 16-byte read of the pixel-major bf16 ring
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int ci = 4 * jj + g;
-            const float av = h1[pp * 16 + ci];
-            const float* wr = a.wt.w3 + (ci * 9 + tap) * 32;
-            oc0 = mfma_f32(av, wr[c], oc0);
-            oc1 = mfma_f32(av, wr[16 + c], oc1);
+          for (int s5 = 0; s5 < 5; ++s5) {
+            const int rr = (r0 + otap_row[s5]) & (CVR_RING - 1);
+            const uint4 af = ring[rr * RING_ROW + otap_off[ot][s5]];
+            oc0[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                              __builtin_bit_cast(bf16x8, wb[s5][0]), oc0[ot], 0, 0, 0);
+            oc1[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                              __builtin_bit_cast(bf16x8, wb[s5][1]), oc1[ot], 0, 0, 0);
+          }
+        } else {
+          // exact f32: 36 k-slices of 4: slice j = (tap = j / 4, channels 4 (j % 4) + g)
+          const float* h1 = reinterpret_cast<const float*>(ring);
+          for (int tap = 0; tap < 9; ++tap) {
+            const int rr = (r0 + tap / 3) & (CVR_RING - 1);
+            const int pp = rr * PW + ocol[ot] + tap % 3;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int ci = 4 * jj + g;
+              const float av = h1[pp * 16 + ci];
+              const float* wr = a.wt.w3 + (ci * 9 + tap) * 32;
+              oc0[ot] = mfma_f32(av, wr[c], oc0[ot]);
+              oc1[ot] = mfma_f32(av, wr[16 + c], oc1[ot]);
+            }
           }
         }
       }
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     };
     // hid1 -> ring: lane holds channels 4 g .. 4 g + 3 of pixel px
     auto ring_store = [&](int y, const f32x4 (&d1)[NTX]) {
-      const int rrow = (y & (CVR_RING - 1)) * CVR_PW + 1;
+      const int rrow = (y & (CVR_RING - 1)) * PW + 1;
 #pragma unroll
       for (int tx = 0; tx < NTX; ++tx) {
         if (!ragw || pin[tx]) {
@@ -551,33 +574,48 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
     }
     // ---- M2: arg max (FIRST maximum: jnp.argmax, model_utils.py:232), softmax window sums
     wave_sync();
-    float z[CVR_ZREG];
-    float best = -3.0e38f;
+    float best = -3.0e38f, bestf = 3.0e9f;   // cell indices are < 2^24: exact as floats
+    float red[4] = {0.f, 0.f, 0.f, 0.f};     // sum e, sum x e, sum y e, sum e inside the window
+    auto accumulate = [&](float zv, int yk, float ax, float ay, float zmax) {
+      const float e = fast_exp(zv - zmax);
+      const float ccy = (float)yk + 0.5f;
+      red[0] += e;
+      const float dd = (zcx - ax) * (zcx - ax) + (ccy - ay) * (ccy - ay);
+      if (dd < 25.0f) { red[1] += zcx * e; red[2] += ccy * e; red[3] += e; }   // radius 5, strict (model_utils.py:236)
+    };
+    if constexpr (!ZSTREAM) {
+      float z[CVR_ZREG];
 #pragma unroll
-    for (int k = 0; k < CVR_ZREG; ++k) {
-      const int yk = k * rps + zy;
-      const bool in = zcol && yk < h;
-      z[k] = in ? cm[(min(yk, h - 1) + 1) * pw + min(zx, w - 1) + 1] * zscale : -3.0e38f;
-      best = fmaxf(best, z[k]);
-    }
-    best = wave_max(best);
-    float bestf = 3.0e9f;   // cell indices are < 2^24: exact as floats
-#pragma unroll
-    for (int k = CVR_ZREG - 1; k >= 0; --k)
-      if (z[k] == best) bestf = (float)((k * rps + zy) * w + zx);
-    const int besti = (int)(-wave_max(-bestf));
-    const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
-    float red[4] = {0.f, 0.f, 0.f, 0.f};   // sum e, sum x e, sum y e, sum e inside the window
-#pragma unroll
-    for (int k = 0; k < CVR_ZREG; ++k) {
-      const int yk = k * rps + zy;
-      if (zcol && yk < h) {
-        const float e = fast_exp(z[k] - best);
-        const float ccy = (float)yk + 0.5f;
-        red[0] += e;
-        const float dd = (zcx - ax) * (zcx - ax) + (ccy - ay) * (ccy - ay);
-        if (dd < 25.0f) { red[1] += zcx * e; red[2] += ccy * e; red[3] += e; }   // radius 5, strict (model_utils.py:236)
+      for (int k = 0; k < CVR_ZREG; ++k) {
+        const int yk = k * rps + zy;
+        const bool in = zcol && yk < h;
+        z[k] = in ? cm[(min(yk, h - 1) + 1) * pw + min(zx, w - 1) + 1] * zscale : -3.0e38f;
+        best = fmaxf(best, z[k]);
       }
+      best = wave_max(best);
+#pragma unroll
+      for (int k = CVR_ZREG - 1; k >= 0; --k)
+        if (z[k] == best) bestf = (float)((k * rps + zy) * w + zx);
+      const int besti = (int)(-wave_max(-bestf));
+      const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
+#pragma unroll
+      for (int k = 0; k < CVR_ZREG; ++k) {
+        const int yk = k * rps + zy;
+        if (zcol && yk < h) accumulate(z[k], yk, ax, ay, best);
+      }
+    } else {
+      // rows of up to 64 cells: the logits do not fit the registers -- two passes over the in-place logits
+      const float* zrow = cm + pw + min(zx, w - 1) + 1;
+      for (int yk = zy; yk < h; yk += rps) {
+        const float v = zcol ? zrow[yk * pw] * zscale : -3.0e38f;
+        if (v > best) { best = v; bestf = (float)(yk * w + zx); }     // (increasing index: the lane's FIRST maximum)
+      }
+      const float bw = wave_max(best);
+      const int besti = (int)(-wave_max(-(best == bw ? bestf : 3.0e9f)));
+      best = bw;
+      const float ax = (float)(besti % w) + 0.5f, ay = (float)(besti / w) + 0.5f;
+      for (int yk = zy; yk < h; yk += rps)
+        if (zcol) accumulate(zrow[yk * pw] * zscale, yk, ax, ay, best);
     }
     wave_sum_n<4>(red);
     const long map = (b * a.Q + q0 + m) * a.T + t;
@@ -625,11 +663,26 @@ __global__ __launch_bounds__(WAVES * 64, (QPW == 16 && WAVES == 8) ? 2 : 4) void
   }
 }
 
-// grids of up to 32 cells per row whose logits fit CVR_ZREG registers per lane in the soft-arg-max pass
+// rows of up to 32 cells whose logits fit CVR_ZREG registers per lane in the soft-arg-max pass (the narrow instantiations),
+// or rows of 33 .. 64 cells on up to 64 rows (the wide ones, PW = 66)
+inline bool cv_rows_wide(int h, int w) { return w > 32 && w <= 64 && h >= 1 && h <= 64; }
 inline bool cv_rows_supported(int h, int w) {
+  if (cv_rows_wide(h, w)) return true;
   if (h < 1 || w < 1 || w > 32 || !cv_fused_supported(h, w)) return false;
   const int rps = w <= 16 ? 4 : 2;
   return (h + rps - 1) / rps <= CVR_ZREG;
+}
+
+constexpr int CVR_PW_WIDE = 66;
+
+// rows of 33 .. 64 cells: 6 maps x 6 waves (bf16; 159 KiB of LDS) or 4 x 4 (f32), one map per wave, one workgroup per CU
+template <typename TA>
+inline void launch_cv_rows_wide(const CvFusedArgs& a, hipStream_t s) {
+  constexpr int QW = sizeof(TA) == 2 ? 6 : 4;
+  const int qtiles = (a.Q + QW - 1) / QW;
+  const dim3 grid((unsigned)(8 * (((long)a.B * a.T * qtiles + 7) / 8))), block(QW * 64);
+  if (a.w > 48) TAPIR_LAUNCH((cv_rows_kernel<TA, QW, 4, false, 1, true, QW, CVR_PW_WIDE>), grid, block, s, a);
+  else TAPIR_LAUNCH((cv_rows_kernel<TA, QW, 3, false, 1, true, QW, CVR_PW_WIDE>), grid, block, s, a);
 }
 
 // Forms of the row-streamed kernel (bf16 build; the f32 parity build always runs 8 maps on 8 waves), measured at
@@ -665,6 +718,7 @@ inline void launch_cv_rows_q(const CvFusedArgs& a, hipStream_t s, int heads) {
 
 template <typename TA>
 inline void launch_cv_rows(const CvFusedArgs& a, hipStream_t s, int heads = 1, int form = 1) {
+  if (cv_rows_wide(a.h, a.w) && heads == 1) { launch_cv_rows_wide<TA>(a, s); return; }
   if constexpr (sizeof(TA) == 2) {
     if (heads == 1 && form == 0) { launch_cv_rows_q<TA, 16, 16>(a, s, heads); return; }
     if (form == 2) { launch_cv_rows_q<TA, 16, 8>(a, s, heads); return; }

@@ -614,7 +614,8 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
   const void* qf_op = qfeat;
   const void* grid_op = grid;
   // row-streamed kernel, bf16: the grid also in the operand order of its contraction (one cast kernel writes both)
-  const bool rows = cv_rows_supported(h, w) && c->cv_mode == 0;
+  const bool rows = cv_rows_supported(h, w) && c->cv_mode == 0 &&
+                    !(cv_rows_wide(h, w) && tapnet && c->tapnet_heads != 1);   // (rows of > 32 cells: one head only)
   const bool tiled = rows && sizeof(TA) == 2 && c->cv_tiled;
   const void* tiled_op = nullptr;
   const tapir_ctx::Staged* stg = sizeof(TA) == 2 ? find_staged(c, grid) : nullptr;
@@ -632,7 +633,7 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     qf_op = c->qf_cast.p; grid_op = c->grid_cast[1].p;
     if (tiled) tiled_op = c->grid_tiled.p;
   }
-  if (cv_fused_supported(h, w) && c->cv_mode != 1) {
+  if ((rows || cv_fused_supported(h, w)) && c->cv_mode != 1) {
     // one kernel: contraction on the matrix cores into LDS + heads; no volume in HBM
     CvFusedArgs fa{};
     fa.qfeat = qf_op; fa.grid = grid_op; fa.wt = tapnet ? c->tapnet_cvw : c->cvw; fa.qpts = qpts_init;
@@ -718,7 +719,7 @@ int do_cycle_consistency(tapir_ctx* c, const float* qfeat, const float* grid, co
                          float* occlusion, float* inverse_tracks, hipStream_t s) {
   const int C = kLowresDim;
   if (!cv_rows_supported(h, w))
-    return fail(c, TAPIR_ERR_UNSUPPORTED, "cycle-consistency tracker: grids of up to 32 cells per row");
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "cycle-consistency tracker: grids of up to 64 x 64 cells");
   const long BQ = (long)B * Q, R = BQ * T;
   TRY(ensure(c, c->cyc_pts, (size_t)R * 12)); TRY(ensure(c, c->cyc_feat, (size_t)R * C * 4));
   TRY(ensure(c, c->cyc_map, (size_t)BQ * 4));
@@ -1398,8 +1399,8 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* c, const float* qfeat, const
   if (!c->tapnet_ready) return fail(c, TAPIR_ERR_WEIGHTS, "TAP-Net head weights (tapnet_cost_volume_track_mods.*) not set");
   if (!qfeat || !grid || !points || !occlusion || B < 1 || Q < 1 || T < 1)
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
-  if (c->cv_mode == 1 || !cv_fused_supported(h, w))
-    return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells (fused kernel only)");
+  if (c->cv_mode == 1 || !(cv_fused_supported(h, w) || (c->tapnet_heads == 1 && c->cv_mode == 0 && cv_rows_supported(h, w))))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "TAP-Net head: grids of up to 32 x 32 cells (64 x 64 with one head), fused kernels only");
   c->cast_src[1] = nullptr; c->tiled_src = nullptr;
   return DISPATCH(c, cost_volume_stage, c, qfeat, grid, query_points, B, Q, T, h, w, points, occlusion,
                   nullptr, (hipStream_t)stream, true);
@@ -1893,7 +1894,7 @@ int tapir_debug_contraction(tapir_ctx* c, const float* qfeat, const float* grid,
                             float* scratch, void* stream) {
   if (!c || !qfeat || !grid || !scratch) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!cv_rows_supported(h, w)) return fail(c, TAPIR_ERR_UNSUPPORTED, "rows of up to 32 cells");
+  if (!cv_rows_supported(h, w)) return fail(c, TAPIR_ERR_UNSUPPORTED, "rows of up to 64 cells");
   return DISPATCH(c, do_debug_contraction, c, qfeat, grid, B, Q, T, h, w, scratch, (hipStream_t)stream);
 }
 

@@ -586,3 +586,61 @@ def test_odd_grids_times_odd_frame_counts(hw, T):
   np.testing.assert_allclose(out['tracks'], ref['tracks'], atol=2e-3)
   np.testing.assert_allclose(out['occlusion'], ref['occlusion'], atol=1e-3)
   np.testing.assert_allclose(out['expected_dist'], ref['expected_dist'], atol=1e-3)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('hw', [(64, 64), (40, 56), (64, 33)])
+def test_cost_volume_rows_of_up_to_64_cells(hw, dtype):
+  """Round 4: grids wider than 32 cells (`initial_resolution` up to 512 x 512) run the row-streamed cost-volume kernel
+  in its wide instantiation (costvol_rows.hpp: padded rows of 66, 6 maps x 6 waves / 4 x 4 in the f32 build, streaming
+  soft arg max) -- before, such grids took the workspace path up to 1600 cells and failed beyond.  Stage against the
+  oracle: f32 at 1e-3 px / 1e-4 (logits), bf16 against the oracle on bf16-rounded operands."""
+  from tapnet_amd import tapir_model
+  h, wd = hw
+  w = synthetic.make_weights(29, 1, False)
+  m = tapir_model.TAPIR(pyramid_level=1, weights=w, device='cuda:0', initial_resolution=(8 * h, 8 * wd), dtype=dtype)
+  rng = np.random.default_rng(h * wd)
+  Q, T = 23, 3
+  grid = O.l2_normalize(rng.standard_normal((1, T, h, wd, 256)).astype(np.float32))
+  qf = O.l2_normalize(rng.standard_normal((1, Q, 256)).astype(np.float32))
+  qp = np.stack([rng.integers(0, T, (1, Q)), rng.uniform(0, 8 * h, (1, Q)), rng.uniform(0, 8 * wd, (1, Q))], -1).astype(np.float32)
+  pts, occ, expd = m.tracks_from_cost_volume(qf, grid, qp)
+  if dtype == 'float32':
+    rp, ro, re, st = O.tracks_from_cost_volume(w, qf, grid, qp, (8 * h, 8 * wd), 20.0, return_stages=True)
+    ok = st['top2_rel_gap'] > 1e-4
+    np.testing.assert_allclose(occ, ro, atol=1e-4)
+    np.testing.assert_allclose(expd, re, atol=1e-4)
+    assert ok.mean() > 0.8
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3)
+  else:
+    rb = O.bf16_round
+    rp, ro, re, st = O.tracks_from_cost_volume(w, rb(qf), rb(grid), qp, (8 * h, 8 * wd), 20.0, return_stages=True)
+    np.testing.assert_allclose(occ, ro, atol=3e-2)
+    np.testing.assert_allclose(expd, re, atol=3e-2)
+    ok = st['top2_rel_gap'] > 1e-3
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=2e-3)
+
+
+def test_initial_resolution_512_end_to_end():
+  """A 512 x 512 model (`initial_resolution=(512, 512)`: 64 x 64 / 128 x 128 cell grids) video -> tracks: the whole path
+  runs on HIP kernels (wide cost-volume instantiation, patch correlation and mixer are size-agnostic) and agrees with
+  the oracle fed with the engine's own grids on a query subset."""
+  from tapnet_amd import tapir_model
+  S, T, Q = 512, 4, 12
+  w = synthetic.make_weights(31, 0, False)
+  m = tapir_model.TAPIR(pyramid_level=0, weights=w, device='cuda:0', initial_resolution=(S, S))
+  video = synthetic.make_video(5, T, S, S)
+  qp = synthetic.make_queries(6, Q, T, S, S)
+  fg = m.get_feature_grids(video)
+  assert tuple(fg.lowres[0].shape) == (1, T, 64, 64, 256)
+  out = m(video, False, qp, feature_grids=fg)
+  lows = [x.cpu().numpy() for x in fg.lowres]; his = [x.cpu().numpy() for x in fg.hires]
+  res = [tuple(int(v) for v in r) for r in fg.resolutions]
+  ref = O.tapir_from_grids(w, video.shape, lows, his, res, qp, pyramid_level=0, softmax_temperature=20.0,
+                           initial_resolution=(S, S))
+  ql, _ = O.get_query_features(lows, his, res, qp, video.shape)
+  _, _, _, st = O.tracks_from_cost_volume(w, ql[0], lows[0], qp, (S, S), 20.0, return_stages=True)
+  clear = (st['top2_rel_gap'] > 1e-4).all(axis=-1)[0]
+  assert clear.mean() >= 0.75
+  np.testing.assert_allclose(np.asarray(out['tracks'])[0][clear], ref['tracks'][0][clear], atol=2e-3)
+  np.testing.assert_allclose(np.asarray(out['occlusion'])[0][clear], ref['occlusion'][0][clear], atol=1e-3)

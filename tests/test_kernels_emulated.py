@@ -336,3 +336,37 @@ def test_cost_volume_stage_when_frames_x_cells_is_not_a_multiple_of_four(dtype):
     outs.append(pts)
   np.testing.assert_allclose(outs[0][ok], outs[1][ok], atol=1e-3 if dtype == _ffi.TAPIR_F32 else 5e-3)
   e.close()
+
+
+@pytest.mark.parametrize('dtype,hw,Q', [(_ffi.TAPIR_F32, (40, 48), 5), (_ffi.TAPIR_F32, (64, 64), 3), (_ffi.TAPIR_BF16, (35, 64), 7),
+                                        (_ffi.TAPIR_BF16, (64, 33), 2)])
+def test_cost_volume_rows_of_up_to_64_cells(dtype, hw, Q):
+  """Round 4: the row-streamed cost-volume kernel on grids wider than 32 cells (`initial_resolution` up to 512 x 512;
+  before: pixel-tiled kernel up to 34 x 34 padded cells, workspace path up to 1600 cells, nothing beyond): padded rows
+  of 66, 6 maps x 6 waves (4 x 4 in the f32 build), three or four 16-pixel tiles per row, two tiles per
+  occlusion-convolution row, the soft arg max streamed twice from the in-place logits.  Ragged everything: 40 x 48 and
+  35 x 64 cells (odd height: pad_lo = 1 of the stride-2 window), 33 cells per row (a third tile with one pixel), query
+  counts that fill no tile.  f32 against the oracle; bf16 against the oracle on bf16-rounded operands."""
+  h, wd = hw
+  w = synthetic.make_weights(23, 1, False, num_mixer_blocks=1, backbone=False)
+  e = EmuEngine(w, num_mixer_blocks=1, initial_resolution=(8 * h, 8 * wd), dtype=dtype)
+  rng = np.random.default_rng(h + wd)
+  T = 2 if h * wd < 3000 else 1
+  grid = O.l2_normalize(rng.standard_normal((1, T, h, wd, 256)).astype(np.float32))
+  qf = O.l2_normalize(rng.standard_normal((1, Q, 256)).astype(np.float32))
+  qp = np.stack([rng.integers(0, T, (1, Q)), rng.uniform(0, 8 * h, (1, Q)), rng.uniform(0, 8 * wd, (1, Q))], -1).astype(np.float32)
+  pts, occ, expd = e.tracks_from_cost_volume(qf, grid, qp)
+  if dtype == _ffi.TAPIR_F32:
+    rp, ro, re, st = O.tracks_from_cost_volume(w, qf, grid, qp, (8 * h, 8 * wd), 20.0, return_stages=True)
+    ok = st['top2_rel_gap'] > 1e-4
+    np.testing.assert_allclose(occ, ro, atol=1e-4)
+    np.testing.assert_allclose(expd, re, atol=1e-4)
+    assert ok.mean() > 0.7
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=1e-3)
+  else:
+    rp, ro, re, st = O.tracks_from_cost_volume(w, bf16_round(qf), bf16_round(grid), qp, (8 * h, 8 * wd), 20.0, return_stages=True)
+    np.testing.assert_allclose(occ, ro, atol=3e-2)     # hid1 / conv-3 weights rounded to bf16
+    np.testing.assert_allclose(expd, re, atol=3e-2)
+    ok = st['top2_rel_gap'] > 1e-3
+    np.testing.assert_allclose(pts[ok], rp[ok], atol=2e-3)   # the soft-arg-max path stays f32
+  e.close()
