@@ -34,12 +34,21 @@ template <> struct Vec16<float> {
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[4]) {
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+  }
   static __device__ __forceinline__ float round(float x) { return x; }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int EPT = 8;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void unpack(const uint4& t, float (&v)[8]) {
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
     v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);

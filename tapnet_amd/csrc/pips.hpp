@@ -75,22 +75,44 @@ __device__ __forceinline__ float level_corr(const PyrLevel& L, const float* __re
   const bool vy = (y >= 0) && (y < L.h);
   const int yc = min(max(y, 0), L.h - 1);
   const TG* rowp = reinterpret_cast<const TG*>(L.grid) + (frame * L.h + yc) * ((long)L.w * C) + cs * EPL;
+  // All loads of a batch of cells are issued back to back, UNCONDITIONALLY, from clamped addresses, and masked on use:
+  // under a lane condition hipcc waits for every load on the spot (the 128-channel level ran as sixteen dependent
+  // L2 round trips per token: profiles/r04_patch_corr.txt).  <= 16 loads of 16 bytes in flight per lane.
+  constexpr int NL = SL / EPL;                      // 16-byte loads per cell and lane
+  constexpr int CB = NL <= 2 ? 8 : 16 / NL;         // cells per batch
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) u32x4_t* gptr16;
   float part[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int x = x0 + j;
-    const bool v = vy && (x >= 0) && (x < L.w);
-    const int xc = min(max(x, 0), L.w - 1);
-    const TG* p = rowp + (long)xc * C;
-    float d = 0.f;
+  for (int j0 = 0; j0 < 8; j0 += CB) {
+    uint4 raw[CB][NL];
 #pragma unroll
-    for (int k = 0; k < SL; k += EPL) {
-      float e[EPL];
-      Vec16<TG>::load(p + k * 8, e);   // chunk m = k / EPL sits (m * 8 + cs) * EPL channels in
+    for (int jj = 0; jj < CB; ++jj) {
+      const int xc = min(max(x0 + j0 + jj, 0), L.w - 1);
+      const TG* p = rowp + (long)xc * C;
 #pragma unroll
-      for (int u = 0; u < EPL; ++u) d = fmaf(e[u], qv[k + u], d);
+      for (int m = 0; m < NL; ++m) {
+#ifdef TAPIR_HIPEMU
+        raw[jj][m] = *reinterpret_cast<const uint4*>(p + m * 8 * EPL);
+#else
+        raw[jj][m] = __builtin_bit_cast(uint4, *(gptr16)(uintptr_t)(p + m * 8 * EPL));   // chunk m sits (m * 8 + cs) * EPL channels in
+#endif
+      }
     }
-    part[j] = v ? d : 0.f;
+#pragma unroll
+    for (int jj = 0; jj < CB; ++jj) {
+      const int x = x0 + j0 + jj;
+      const bool v = vy && (x >= 0) && (x < L.w);
+      float d = 0.f;
+#pragma unroll
+      for (int m = 0; m < NL; ++m) {
+        float e[EPL];
+        Vec16<TG>::unpack(raw[jj][m], e);
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) d = fmaf(e[u], qv[m * EPL + u], d);
+      }
+      part[j0 + jj] = v ? d : 0.f;
+    }
   }
   // transposed butterfly over lane bits 2..0: after the step with offset `off`, a lane keeps
   // the half of its values whose cell index j has bit `off` equal to the lane's
@@ -141,23 +163,40 @@ __device__ __forceinline__ void patch_row(const PatchArgs& a, long r, int lane, 
   const int t = (int)(r % a.T);
   const long bq = r / a.T;
   const int b = (int)(bq / a.Q);
-  // header + features + zero padding of the K tail
-  const int ncorr0 = kMixOut;
-  for (int c = lane; c < a.ld; c += 64) {
-    float v;
-    if (c < 2) v = 0.f;                       // position channels are always zero (:583)
-    else if (c == 2) v = a.occ[r];
-    else if (c == 3) v = a.expd[r];
-    else if (c < ncorr0) {
-      const int f = c - 4;
-      if (a.feats != nullptr) v = a.feats[r * kFeatDim + f];
-      else v = (f < kHiresDim) ? a.lvl[0].query[bq * kHiresDim + f]
-                               : a.lvl[1].query[bq * kLowresDim + (f - kHiresDim)];
-    } else if (c >= ncorr0 + kPatch * a.n_levels) v = 0.f;
-    else continue;                            // correlation slots: written below
-    st(c, v);
-  }
+  // the position first: the window addresses of both levels depend on it, and the stores of the header loop below
+  // would otherwise sit in front of this load (the compiler cannot prove that they do not alias it)
   const float px = a.pos[r * 2 + 0], py = a.pos[r * 2 + 1];
+  // header + features + zero padding of the K tail: every lane's sources first (one unconditional load each, from a
+  // clamped address), then the stores -- element by element the loop was a chain of load / wait / store round trips
+  const int ncorr0 = kMixOut;
+  constexpr int HDR = 12;                       // ld <= 768 columns
+  const float* const f0 = a.feats != nullptr ? a.feats + r * kFeatDim : nullptr;
+  float hv[HDR];
+#pragma unroll
+  for (int k = 0; k < HDR; ++k) {
+    const int c = lane + 64 * k;
+    const int f = min(max(c - 4, 0), kFeatDim - 1);
+    const float* src = f0 != nullptr ? f0 + f
+                       : (f < kHiresDim ? a.lvl[0].query + bq * kHiresDim + f : a.lvl[1].query + bq * kLowresDim + (f - kHiresDim));
+    if (c == 2) src = a.occ + r;
+    if (c == 3) src = a.expd + r;
+    hv[k] = *src;
+  }
+#ifndef TAPIR_HIPEMU
+  // (pins the twelve loads HERE, in flight together: left alone, hipcc sinks each of them into the conditional store
+  // below and waits for it on the spot)
+#pragma unroll
+  for (int k = 0; k < HDR; ++k) asm volatile("" : "+v"(hv[k]));
+#endif
+#pragma unroll
+  for (int k = 0; k < HDR; ++k) {
+    const int c = lane + 64 * k;
+    if (c >= a.ld) break;
+    if (c >= ncorr0 && c < ncorr0 + kPatch * a.n_levels) continue;   // correlation slots: written below
+    const bool zero = c < 2 || c >= ncorr0;                          // position channels are always zero (:583); K tail
+    st(c, zero ? 0.f : hv[k]);
+  }
+  for (int c = lane + 64 * HDR; c < a.ld; c += 64) st(c, 0.f);      // (rows longer than 768 columns: zero tail)
   const long frame = (long)b * a.T + t;
   const int i = lane >> 3, j = lane & 7;
   for (int l = 0; l < a.n_levels; ++l) {

@@ -359,24 +359,24 @@ def bench_cv(model, reps, results):
   dev = model.device
   stream = model._stream()
   g = torch.Generator(device='cpu').manual_seed(0)
-  for Q, T in ((256, 48), (1024, 48)):
-    grid = torch.nn.functional.normalize(torch.randn(1, T, 32, 32, 256, generator=g), dim=-1).to(dev)
+  for Q, T, H in ((256, 48, 32), (1024, 48, 32), (256, 12, 64)):   # (64 x 64 cells: initial_resolution 512; only the row-streamed kernel covers it)
+    grid = torch.nn.functional.normalize(torch.randn(1, T, H, H, 256, generator=g), dim=-1).to(dev)
     qf = torch.nn.functional.normalize(torch.randn(1, Q, 256, generator=g), dim=-1).to(dev)
-    qp = torch.cat([torch.randint(0, T, (1, Q, 1), generator=g).float(), torch.rand(1, Q, 2, generator=g) * 256], -1).to(dev)
+    qp = torch.cat([torch.randint(0, T, (1, Q, 1), generator=g).float(), torch.rand(1, Q, 2, generator=g) * 8 * H], -1).to(dev)
     outs = {}
-    for mode, name in ((1, 'workspace'), (2, 'fused_tiled'), (0, 'fused')):
+    for mode, name in (((1, 'workspace'), (2, 'fused_tiled'), (0, 'fused')) if H == 32 else ((0, 'fused'),)):
       assert lib.tapir_debug_set_cv_mode(ctx, mode) == 0
       pts = torch.empty(1, Q, T, 2, device=dev); occ = torch.empty(1, Q, T, device=dev); expd = torch.empty(1, Q, T, device=dev)
 
       def run(i):
-        rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), qp.data_ptr(), 1, Q, T, 32, 32,
+        rc = lib.tapir_tracks_from_cost_volume(ctx, qf.data_ptr(), grid.data_ptr(), qp.data_ptr(), 1, Q, T, H, H,
                                                pts.data_ptr(), occ.data_ptr(), expd.data_ptr(), stream)
         assert rc == 0, lib.tapir_last_error(ctx)
       t = timeit(run, max(5, reps // 2), warm=2)
       outs[name] = (pts.clone(), occ.clone())
-      row = dict(kernel=f'cost_volume_stage_{name}', Q=Q, T=T, dtype=model.dtype, **t,
+      row = dict(kernel=f'cost_volume_stage_{name}', Q=Q, T=T, cells=f'{H}x{H}', dtype=model.dtype, **t,
                  ns_per_map=round(t['med_us'] * 1e3 / (Q * T), 1))
-      if name != 'workspace':
+      if name != 'workspace' and 'workspace' in outs:
         d = torch.linalg.norm(outs[name][0] - outs['workspace'][0], dim=-1)
         row['tracks_median_diff_px'] = float(d.median()); row['tracks_frac_within_0.05px'] = float((d < 0.05).float().mean())
         row['occ_max_diff'] = float((outs[name][1] - outs['workspace'][1]).abs().max())
