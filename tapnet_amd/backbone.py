@@ -605,6 +605,14 @@ def resize_bilinear(video: torch.Tensor, resolution: Tuple[int, int], antialias:
   held to a restatement of jax/_src/image/scale.py and, through it, to the JAX text run over numpy stand-ins
   (tests/test_jax_reference_pin.py::test_gpu_matches_the_jax_text[bootstapir_multires])."""
   b, t, h, w, c = video.shape
+  if (int(resolution[0]), int(resolution[1])) == (h, w) and os.environ.get('TAPIR_IDENTITY_RESIZE', '0') != '1':
+    # (TAPIR_IDENTITY_RESIZE=1: run the resize anyway -- the A/B switch of profiles/r04_ab_latency_chains.txt)
+    # The reference resizes even to the size the video already has (the quirk at tapir_model.py:667 makes the first
+    # level always take this branch).  At equal size align_corners=False samples every pixel centre with weights
+    # exactly (1, 0): the identity, bit for bit, with or without the anti-aliasing filter (torch's kernels copy) --
+    # tests/test_host_logic.py::test_resize_to_the_same_size_is_the_identity.  Returning the input saves the
+    # benchmarked 256 x 256 clip two transposing passes and a copy over its 38 MB (~65 us of a 4.7 ms step).
+    return video
   x = video.permute(0, 1, 4, 2, 3).reshape(b, t * c, h, w)
   down = resolution[0] < h or resolution[1] < w
   x = F.interpolate(x, size=tuple(resolution), mode='bilinear', align_corners=False,

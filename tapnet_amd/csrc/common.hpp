@@ -88,6 +88,26 @@ __device__ __forceinline__ void consume(const f32x4& v) {
   asm volatile("" ::"v"(v));
 #endif
 }
+// Arrival point of a batch of global loads: issued back to back, then passed through here one after the other, the
+// compiler can neither sink a load into the (conditional) code that uses it nor wait for each before issuing the next.
+__device__ __forceinline__ void pin(f32x4& v) {
+#ifndef TAPIR_HIPEMU
+  asm volatile("" : "+v"(v));
+#endif
+}
+__device__ __forceinline__ void pin(float& v) {
+#ifndef TAPIR_HIPEMU
+  asm volatile("" : "+v"(v));
+#endif
+}
+__device__ __forceinline__ void pin(uint4& v) {
+#ifndef TAPIR_HIPEMU
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t t = __builtin_bit_cast(u32x4_t, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(uint4, t);
+#endif
+}
 // "Arrival point" of an LDS read: the value is passed through an empty asm, so the compiler waits
 // for it HERE (with LDS-DMA in flight hipcc only ever emits lgkmcnt(0)) and treats every later
 // use as a plain register -- reads issued after this point stay in flight under those uses.

@@ -647,21 +647,40 @@ __global__ __launch_bounds__(STEM_WAVES * 64, 2) void stem_conv_kernel(StemArgs 
     Pb[i] = 2 * yy * RS + 6 * ES * xx + 16 * g;
   }
 
-  // ---- stage the input rows, a pair of f32 per thread and trip (zero outside the image and in the slack)
+  // ---- stage the input rows, pairs of f32 (zero outside the image and in the slack).  All (row, pair) slots of the
+  // tile form one index space walked in batches of SB unconditional loads per thread from clamped coordinates, masked
+  // on use: a load under the in-image lane condition is waited for on the spot, which made the staging a chain of
+  // 2 x in_rows (18 at 256 x 256) dependent 8-byte HBM round trips per workgroup (rounds 2-3; found in the ISA in
+  // round 4: one global_load / s_waitcnt vmcnt(0) pair per trip) -- now one or two.
   {
+    constexpr int SB = 16;
     const int pairs = RS / (2 * ES);
+    const int slots = in_rows * pairs;
     const float* xin = a.x + (long)n * H * W * 3;
-    for (int hy = 0; hy < in_rows; ++hy) {
-      const int y = y0 + hy;
-      const bool yok = y >= 0 && y < H;
-      const float* rowp = xin + (long)min(max(y, 0), H - 1) * W * 3;
-      for (int p = tid; p < pairs; p += THREADS) {
+    for (int base = tid; base < slots; base += SB * THREADS) {
+      float vx[SB], vy[SB];
+      int dst[SB];           // byte offset in the LDS image, -1 past its end
+      bool ok[SB];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        const int id = base + k * THREADS;
+        const int idc = id < slots ? id : slots - 1;
+        const int hy = idc / pairs, p = idc - hy * pairs;
+        const int y = y0 + hy;
         const int ge = e0 + 2 * p;                 // even: a pair never straddles the image edge (3 W is even)
-        const bool ok = yok && ge >= 0 && ge + 1 < 3 * W && 2 * p < PW * 3 + 1;
-        float2 v = make_float2(0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float2*>(rowp + ge);
-        if (BF) *reinterpret_cast<unsigned*>(tile + hy * RS + 4 * p) = pack_bf16x2(v.x, v.y);
-        else *reinterpret_cast<float2*>(tile + hy * RS + 8 * p) = v;
+        ok[k] = y >= 0 && y < H && ge >= 0 && ge + 1 < 3 * W && 2 * p < PW * 3 + 1;
+        const float2 v = *reinterpret_cast<const float2*>(xin + (long)min(max(y, 0), H - 1) * W * 3 + min(max(ge, 0), 3 * W - 2));
+        vx[k] = v.x; vy[k] = v.y;
+        dst[k] = id < slots ? hy * RS + 2 * ES * p : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) { pin(vx[k]); pin(vy[k]); }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        if (dst[k] < 0) continue;
+        const float wx = ok[k] ? vx[k] : 0.f, wy = ok[k] ? vy[k] : 0.f;
+        if (BF) *reinterpret_cast<unsigned*>(tile + dst[k]) = pack_bf16x2(wx, wy);
+        else *reinterpret_cast<float2*>(tile + dst[k]) = make_float2(wx, wy);
       }
     }
   }

@@ -252,10 +252,15 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
         for (int s = 0; s < KCH; ++s) f[s] = csrc[4 * s + g];
       }
     };
+    // Two tiles in flight per wave.  Every load_tile is UNCONDITIONAL (a tile index past the end is clamped to the last
+    // tile: a cache hit whose values are never multiplied): with the loads under `if (next tile exists)` the wait
+    // counters merge over both paths at the loop head and hipcc drains the queue -- s_waitcnt vmcnt(1) / vmcnt(0) in
+    // front of the MFMAs of the OLDER tile, i.e. no double buffering at all (found in the ISA, round 4).
     uint4 fa0[KCH], fa1[KCH];
     int it = wave;
-    if (it < ntile) load_tile(it, fa0);              // the first two tiles fly while the halos are zeroed
-    if (it + WAVES < ntile) load_tile(it + WAVES, fa1);
+    const int nmine = it < ntile ? (ntile - 1 - it) / WAVES + 1 : 0;   // tiles of this wave (wave-uniform)
+    load_tile(min(it, ntile - 1), fa0);              // the first two tiles fly while the halos are zeroed
+    load_tile(min(it + WAVES, ntile - 1), fa1);
     // zero: cost maps (halo cells are never written), rings (halo columns / out-of-image rows)
     static_assert((QPW * PAD) % 4 == 0, "16-byte zero fill");
     for (int i = tid; i < QPW * PAD / 4; i += THREADS) reinterpret_cast<uint4*>(&s_cm[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -289,13 +294,12 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
       cy += stepq; cx += stepr;
       if (cx >= w) { cx -= w; ++cy; }
     };
-    while (it < ntile) {
+    for (int k = 0; k < nmine; k += 2) {
       mul_tile(it, fa0);
-      if (it + 2 * WAVES < ntile) load_tile(it + 2 * WAVES, fa0);
+      load_tile(min(it + 2 * WAVES, ntile - 1), fa0);
       it += WAVES;
-      if (it >= ntile) break;
-      mul_tile(it, fa1);
-      if (it + 2 * WAVES < ntile) load_tile(it + 2 * WAVES, fa1);
+      if (k + 1 < nmine) mul_tile(it, fa1);
+      load_tile(min(it + 2 * WAVES, ntile - 1), fa1);
       it += WAVES;
     }
   }

@@ -454,7 +454,16 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_fp8w_kernel(FusedQArgs
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int t = NT * c + i;
-        if (o0 < kMixOut && t < T) fused_emit(a, (long)n * T + t, n, o0, oa[q][i]);
+        if (o0 < kMixOut && t < T) {   // (experiment: fetched on the spot, not batched as in mixer_fused.hpp)
+          const long r = (long)n * T + t;
+          f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
+          EmitState st = EmitState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (a.fuse_update) {
+            prev = fused_prev_feats(a, r, n, o0);
+            if (o0 == 0) st = fused_prev_state(a, r);
+          }
+          fused_emit(a, r, o0, oa[q][i], prev, st);
+        }
       }
     }
   }

@@ -99,28 +99,51 @@ struct FusedArgs {
 // Output of the mixer for token row r, output channels o0 .. o0 + 3 (o0 a multiple of 4, < 388): either stored to
 // res, or applied to the running estimate exactly as update_kernel does (same operations in the same order: the two
 // forms are bit-identical).  Channels 0..3 = [dx, dy, d_occ, d_expd] sit in ONE lane; channels 4.. are feats[o0 - 4 ..].
-__device__ __forceinline__ void fused_emit(const FusedArgs& a, long r, long bq, int o0, const f32x4& v) {
+//
+// What the update adds TO is fetched ahead of the output Linear (fused_prev_feats / fused_prev_state), not inside
+// fused_emit: there every one of a lane's 4 x NT read-modify-writes was a load under a lane condition, which hipcc
+// waits for on the spot -- twelve dependent memory round trips at the tail of every launch (round 4, found in the ISA
+// like patch_corr_kernel's).  The fetches are unconditional and back to back from clamped coordinates (a lane that
+// emits nothing reads something readable) and arrive at a common::pin.  Every (row, channel) is read and written by
+// the same lane only, so reading early changes nothing.
+struct EmitState { float px, py, oc, ex, oc0, ex0; };
+__device__ __forceinline__ f32x4 fused_prev_feats(const FusedArgs& a, long r, long bq, int o0) {
+  const UpdateArgs& u = a.upd;
+  const int f = o0 >= 4 ? o0 - 4 : 0;            // feats channels f .. f + 3 (f and the 128 boundary are multiples of 4)
+  const float* src = !u.first_of_level ? u.feats + r * kFeatDim + f
+                     : (f < kHiresDim ? u.q_hires + bq * kHiresDim + f : u.q_lowres + bq * kLowresDim + (f - kHiresDim));
+  return *reinterpret_cast<const f32x4*>(src);
+}
+__device__ __forceinline__ EmitState fused_prev_state(const FusedArgs& a, long r) {
+  const UpdateArgs& u = a.upd;
+  EmitState s;
+  s.px = u.pos[r * 2 + 0]; s.py = u.pos[r * 2 + 1]; s.oc = u.occ[r]; s.ex = u.expd[r];
+  s.oc0 = 0.f; s.ex0 = 0.f;
+  if (u.last_of_level) { s.oc0 = u.occ0[r]; s.ex0 = u.expd0[r]; }
+  return s;
+}
+__device__ __forceinline__ void pin(EmitState& s) {
+  pin(s.px); pin(s.py); pin(s.oc); pin(s.ex); pin(s.oc0); pin(s.ex0);
+}
+__device__ __forceinline__ void fused_emit(const FusedArgs& a, long r, int o0, const f32x4& v, const f32x4& prev,
+                                           const EmitState& st) {
   if (!a.fuse_update) {
     *reinterpret_cast<f32x4*>(a.res + r * kMixOut + o0) = v;
     return;
   }
   const UpdateArgs& u = a.upd;
   if (o0 == 0) {
-    const float px = u.pos[r * 2 + 0] + v[0] * u.sx;
-    const float py = u.pos[r * 2 + 1] + v[1] * u.sy;
-    const float oc = u.occ[r] + v[2];
-    const float ex = u.expd[r] + v[3];
+    const float px = st.px + v[0] * u.sx;
+    const float py = st.py + v[1] * u.sy;
+    const float oc = st.oc + v[2];
+    const float ex = st.ex + v[3];
     u.pos[r * 2 + 0] = px; u.pos[r * 2 + 1] = py;
     u.out_tracks[r * 2 + 0] = px * u.vx; u.out_tracks[r * 2 + 1] = py * u.vy;
     u.out_occ[r] = oc; u.out_expd[r] = ex;
-    u.occ[r] = u.last_of_level ? u.occ0[r] : oc;
-    u.expd[r] = u.last_of_level ? u.expd0[r] : ex;
+    u.occ[r] = u.last_of_level ? st.oc0 : oc;
+    u.expd[r] = u.last_of_level ? st.ex0 : ex;
   } else {
-    const int f = o0 - 4;                          // feats channels f .. f + 3 (f and the 128 boundary are multiples of 4)
-    const float* src = !u.first_of_level ? u.feats + r * kFeatDim + f
-                       : (f < kHiresDim ? u.q_hires + bq * kHiresDim + f : u.q_lowres + bq * kLowresDim + (f - kHiresDim));
-    const f32x4 prev = *reinterpret_cast<const f32x4*>(src);
-    *reinterpret_cast<f32x4*>(u.feats + r * kFeatDim + f) = v + prev;
+    *reinterpret_cast<f32x4*>(u.feats + r * kFeatDim + (o0 - 4)) = v + prev;
   }
 }
 
@@ -348,12 +371,29 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
     const int cpr = in_stride >> 4;   // 16-byte chunks per row (a multiple of 16)
     const uint4* src = reinterpret_cast<const uint4*>(
         reinterpret_cast<const char*>(a.mlp_in) + (long)n * T * in_stride);
-    for (int id = tid; id < ROWS * cpr; id += FM_THREADS) {
-      const int row = id / cpr, q = id - row * cpr;
-      const int tok = NT * (row & 15) + (row >> 4);   // LDS row 16 i + c holds token NT c + i
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tok < T) v = src[tok * cpr + q];
-      s_act[row * cpr + (q ^ (row & 15))] = v;
+    // batches of STG chunks per thread, loaded unconditionally from clamped coordinates, then stored (a load under
+    // `tok < T` is waited for on the spot: 8 dependent round trips per launch at 48 frames x 1280 bytes)
+    constexpr int STG = 8;
+    const int total = ROWS * cpr;
+    for (int base = tid; base < total; base += STG * FM_THREADS) {
+      uint4 v[STG];
+      int dst[STG];          // LDS chunk index, -1 past the end of the image
+      bool live[STG];        // false: a zero row (token >= T)
+#pragma unroll
+      for (int k = 0; k < STG; ++k) {
+        const int id = base + k * FM_THREADS;
+        const int idc = id < total ? id : total - 1;
+        const int row = idc / cpr, q = idc - row * cpr;
+        const int tok = NT * (row & 15) + (row >> 4);   // LDS row 16 i + c holds token NT c + i
+        live[k] = tok < T;
+        v[k] = src[(live[k] ? tok : T - 1) * cpr + q];
+        dst[k] = id < total ? row * cpr + (q ^ (row & 15)) : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < STG; ++k) pin(v[k]);
+#pragma unroll
+      for (int k = 0; k < STG; ++k)
+        if (dst[k] >= 0) s_act[dst[k]] = live[k] ? v[k] : make_uint4(0u, 0u, 0u, 0u);
     }
   }
   lds_barrier();
@@ -610,10 +650,38 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 
   // ---- final LayerNorm + output Linear (tapir_model.py:154-155): 388 outputs, rows padded to 512
   {
+    // what the state update will add to: in flight under the LayerNorm (see fused_emit)
+    f32x4 prev[4][NT];
+    EmitState st[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      st[i] = EmitState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) prev[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.fuse_update) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int t = NT * c + i;
+        const long r = (long)n * T + (t < T ? t : T - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o0 = ch_lane + 16 * q;
+          prev[q][i] = fused_prev_feats(a, r, n, o0 < kMixOut ? o0 : kMixOut - 4);
+        }
+        if (wave == 0) st[i] = fused_prev_state(a, r);   // channels 0..3 sit in wave 0 (q = 0, g = 0)
+      }
+    }
     float mean[NT], rstd[NT];
     ln_stats(mean, rstd);
     write_xn(a.lnF, mean, rstd);
     lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      pin(st[i]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pin(prev[q][i]);
+    }
     f32x4 oa[4][NT];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -630,7 +698,7 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_kernel(FusedArgs a) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int t = NT * c + i;
-        if (o0 < kMixOut && t < T) fused_emit(a, (long)n * T + t, n, o0, oa[q][i]);
+        if (o0 < kMixOut && t < T) fused_emit(a, (long)n * T + t, o0, oa[q][i], prev[q][i], st[i]);
       }
     }
   }

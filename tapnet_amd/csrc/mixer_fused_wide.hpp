@@ -86,14 +86,31 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
   {
     const int cpr = in_stride >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(a.mlp_in);
-    for (int id = tid; id < ROWS * cpr; id += FM_THREADS) {
-      const int row = id / cpr, q = id - row * cpr;
-      const int i = row >> 4;
-      const int tok = NTT * (row & 15) + (i % NTT);
-      const int trk = trk0 + i / NTT;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tok < T && trk < a.N) v = src[((long)trk * T + tok) * cpr + q];
-      s_act[row * cpr + (q ^ (row & 15))] = v;
+    // batches of unconditional loads from clamped coordinates, then the stores (mixer_fused.hpp: a load under a lane
+    // condition is waited for on the spot)
+    constexpr int STG = 8;
+    const int total = ROWS * cpr;
+    for (int base = tid; base < total; base += STG * FM_THREADS) {
+      uint4 v[STG];
+      int dst[STG];          // LDS chunk index, -1 past the end of the image
+      bool live[STG];        // false: a zero row (token >= T or track >= N)
+#pragma unroll
+      for (int k = 0; k < STG; ++k) {
+        const int id = base + k * FM_THREADS;
+        const int idc = id < total ? id : total - 1;
+        const int row = idc / cpr, q = idc - row * cpr;
+        const int i = row >> 4;
+        const int tok = NTT * (row & 15) + (i % NTT);
+        const int trk = trk0 + i / NTT;
+        live[k] = tok < T && trk < a.N;
+        v[k] = src[((long)(trk < a.N ? trk : a.N - 1) * T + (tok < T ? tok : T - 1)) * cpr + q];
+        dst[k] = id < total ? row * cpr + (q ^ (row & 15)) : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < STG; ++k) pin(v[k]);
+#pragma unroll
+      for (int k = 0; k < STG; ++k)
+        if (dst[k] >= 0) s_act[dst[k]] = live[k] ? v[k] : make_uint4(0u, 0u, 0u, 0u);
     }
   }
   lds_barrier();
@@ -318,14 +335,43 @@ __global__ __launch_bounds__(FM_THREADS) void mixer_fused_wide_kernel(FusedArgs 
 #pragma unroll
         for (int i = 0; i < NT; ++i) oa[q][i] = bo;
       }
+      // what the state update adds to: fetched in one batch (mixer_fused.hpp::fused_emit), in flight under the GEMM
+      f32x4 prev[2][NT];
+      EmitState st[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        st[i] = EmitState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) prev[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (a.fuse_update) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int t = NTT * c + (i % NTT), trk = trk0 + i / NTT;
+          const long trc = trk < a.N ? trk : a.N - 1;
+          const long r = trc * T + (t < T ? t : T - 1);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int o0 = ch_lane + 16 * (2 * half + q);
+            prev[q][i] = fused_prev_feats(a, r, trc, o0 < kMixOut ? o0 : kMixOut - 4);
+          }
+          if (half == 0 && wave == 0) st[i] = fused_prev_state(a, r);   // channels 0..3: wave 0, first row tile
+        }
+      }
       fused_gemm<TA, 2, NT, 0, NoEpilogue, RING, false>(wp, ring, s_xn, XN_STRIDE, (kHidden / KS) / (RING / 2), c, g, oa);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        pin(st[i]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pin(prev[q][i]);
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int o0 = ch_lane + 16 * (2 * half + q);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           const int t = NTT * c + (i % NTT), trk = trk0 + i / NTT;
-          if (o0 < kMixOut && t < T && trk < a.N) fused_emit(a, (long)trk * T + t, trk, o0, oa[q][i]);
+          if (o0 < kMixOut && t < T && trk < a.N) fused_emit(a, (long)trk * T + t, o0, oa[q][i], prev[q][i], st[i]);
         }
       }
     }

@@ -178,3 +178,25 @@ def test_resolution_answers_both_conventions():
   assert _res_hw(r) == (64, 96) and _res_hw((64, 96)) == (64, 96)
   import numpy as np
   assert _res_hw(np.zeros((64, 96, 0), np.float32)) == (64, 96)       # a JAX-style carrier passed in
+
+
+def test_resize_to_the_same_size_is_the_identity():
+  """resize_bilinear returns its input when the target size is the video's own (the reference's first level always
+  resizes, tapir_model.py:667-670): pin that what it skips -- F.interpolate(bilinear, align_corners=False) of the
+  reference's torch twin (tapnet/torch/utils.py:26-42), with and without anti-aliasing, and the restatement of
+  jax.image.resize -- is the identity bit for bit, so the shortcut changes no output."""
+  import torch
+  import torch.nn.functional as F
+  from tapnet_amd.backbone import resize_bilinear
+  from oracle import jax_resize
+  rng = np.random.default_rng(11)
+  v = rng.uniform(-1, 1, (1, 3, 24, 40, 3)).astype(np.float32)
+  v[0, 0, 0, 0, 0] = 0.0
+  t = torch.as_tensor(v)
+  x = t.permute(0, 1, 4, 2, 3).reshape(1, 9, 24, 40)
+  for aa in (False, True):
+    y = F.interpolate(x, size=(24, 40), mode='bilinear', align_corners=False, antialias=aa)
+    assert torch.equal(y, x), aa
+    out = resize_bilinear(t, (24, 40), antialias=aa)
+    assert out.shape == t.shape and torch.equal(out, t)
+  np.testing.assert_array_equal(jax_resize.resize_bilinear(v, (24, 40)), v)

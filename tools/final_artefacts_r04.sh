@@ -10,6 +10,7 @@ PART=${1:-tests}
 OUT=gpurun_out/${2:-r04final}
 mkdir -p $OUT
 export TMPDIR=/tmp
+export OUT
 R=$PWD
 if [ "$PART" == "tests" ]; then
   timeout 2400 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed" > $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
@@ -22,6 +23,23 @@ if [ "$PART" == "bench" ]; then
   timeout 300 python tools/bench_online.py --frames 60 2>&1 | grep workload > $OUT/online.json; cut -c1-230 $OUT/online.json
   timeout 600 python tools/run_config5.py > $OUT/config5_1gpu.json 2>/dev/null; cat $OUT/config5_1gpu.json
   timeout 300 python tools/kbench.py --what cv,contraction --reps 20 --out $OUT/kbench_cv.json 2>&1 | grep '"kernel"' > $OUT/kbench_cv.txt; cut -c1-200 $OUT/kbench_cv.txt
+fi
+if [ "$PART" == "ab" ]; then
+  # same-box A/B of the last commit's library (tools/bin/libtapir_hip_prev.so, built from `git show HEAD:...`) with the
+  # identity resize still executed, against the working tree; alternated twice
+  for rep in 1 2; do
+    TAPIR_HIP_LIB=$R/tools/bin/libtapir_hip_prev.so TAPIR_IDENTITY_RESIZE=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_prev_$rep.json
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_new_$rep.json
+  done
+  TAPIR_IDENTITY_RESIZE=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_new_with_resize.json
+  python - <<'EOF' | tee $OUT/ab_summary.txt
+import json,glob,os
+for f in sorted(glob.glob(os.environ.get('OUT','gpurun_out/r04final')+'/ab_*.json')):
+    try: d=json.loads(open(f).read())
+    except Exception as e: print(f,'unreadable',e); continue
+    k={a: b.get('avg_us') for a, b in (d.get('kernels') or {}).items() if b.get('launches')}
+    print(os.path.basename(f), d.get('ms_per_step'), d.get('value'), 'hot', d.get('hot_path_ms'), 'bb', d.get('backbone_ms'), k)
+EOF
 fi
 if [ "$PART" == "prof" ]; then
   cd /tmp
