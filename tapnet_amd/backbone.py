@@ -512,7 +512,10 @@ class Backbone:
     if chunk:
       bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
     else:
-      per = -(-n // streams)
+      # frame groups: one per stream, or more (TAPIR_BACKBONE_GROUPS: the groups of a stream run one after the other,
+      # which shrinks the set of activations alive at any time -- tools, A/B)
+      groups = max(streams, int(os.environ.get('TAPIR_BACKBONE_GROUPS', '0') or 0))
+      per = -(-n // groups)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
     key = (n, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds))
     if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need

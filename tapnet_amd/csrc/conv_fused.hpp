@@ -26,7 +26,9 @@
 namespace tapir {
 
 constexpr int CV3_NT = 4;                    // pixel tiles (16 pixels) per wave
-// A fragments in flight per wave: 12 (3 k-steps) for the 3x3 kernels, 8 for the 1x1 (2, 4 or 8 k-steps in all)
+// A fragments in flight per wave: 12 (3 k-steps) for the 3x3 kernels, 8 for the 1x1 (2, 4 or 8 k-steps in all).
+// (Deeper rings for C >= 128 -- 16 or 24 fragments, 236-256 VGPRs -- measured equal on the GPU with four streams in
+// flight, profiles/r04_ab_backbone_knobs.txt: the weight stream's latency is covered by the other resident workgroup.)
 constexpr int cv3_ring(int ks) { return ks == 3 ? 12 : 8; }
 // Two workgroup sizes: 4 waves with a 72-KiB tile -- two workgroups per CU, so that the VALU- and
 // memory-bound phases of one (staging, epilogue) run under the matrix phase of the other -- and

@@ -86,6 +86,9 @@ struct tapir_ctx {
                                                   // prologue costs what the separate launch costs, profiles/r04_ab_fuse_patch.txt -- opt-in)
   int cv_form = 1;                                // row-streamed cost volume: maps x waves per workgroup (costvol_rows.hpp; TAPIR_CV_FORM, A/B)
   int cv_mode = 0;                                // 0 auto (fused where it applies), 1 einsum workspace + heads kernel
+  bool warm_weights = true;                       // read the track-resident mixer's weight stream once in front of a level's first iteration
+                                                  // (TAPIR_WARM_WEIGHTS=0: off, A/B; warm_stream_kernel below)
+  DevBuf warm_sink;                               // 4 bytes the warming kernel never writes
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
@@ -808,6 +811,35 @@ int mixer_gemm(tapir_ctx* c, const GemmArgs& g, hipStream_t s) {
 template <typename TA>
 void launch_patch_args(tapir_ctx* c, const PatchArgs& pa, hipStream_t s);
 
+// Reads a buffer once and throws the values away.  Every workgroup of the track-resident mixer streams the SAME 51 MB of
+// weight fragments; between two clips the backbone moves ~2.6 GB through HBM, so the first refinement iteration of a
+// clip finds them neither in an L2 nor in the memory-side cache and -- every workgroup walking the stream in lock step
+// behind the one that misses -- runs 907 instead of 722 us (rocprofv3 timeline of bench.py, profiles/r04_mixer_cold_start.txt).
+// One pass over the stream in front of it (13-17 us at HBM speed) leaves it in the 256-MB memory-side cache.
+struct WarmArgs { const uint4* p; long n16; unsigned* sink; };
+__global__ __launch_bounds__(256) void warm_stream_kernel(WarmArgs a) {
+  constexpr int U = 8;
+  unsigned acc = 0;
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < a.n16; i0 += U * stride) {
+    uint4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) { const long i = i0 + k * stride; v[k] = a.p[i < a.n16 ? i : a.n16 - 1]; }
+#pragma unroll
+    for (int k = 0; k < U; ++k) acc += (v[k].x ^ v[k].y) + (v[k].z ^ v[k].w);
+  }
+  if (acc == 0x5bd1e995u) *a.sink = acc;   // keeps the loads alive; sink is a word of the context nobody reads
+}
+inline int warm_stream(tapir_ctx* c, const void* p, size_t bytes, hipStream_t s) {
+  if (p == nullptr || bytes < 16) return TAPIR_OK;
+  TRY(ensure(c, c->warm_sink, 4));
+  WarmArgs a{reinterpret_cast<const uint4*>(p), (long)(bytes / 16), (unsigned*)c->warm_sink.p};
+  const long per = 256L * 8;
+  const unsigned grid = (unsigned)std::min<long>((a.n16 + per - 1) / per, 2048);
+  hipLaunchKernelGGL(warm_stream_kernel, dim3(grid), dim3(256), 0, s, a);
+  return TAPIR_OK;
+}
+
 template <typename TA>
 int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
               float* ctx1_out, float* ctx2_out, hipStream_t s, const UpdateArgs* upd = nullptr,
@@ -850,6 +882,9 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
       if (wide) fused = false;
     }
+    if ((fused || wide) && !fp8w && c->warm_weights && upd != nullptr && upd->first_of_level)
+      TRY(warm_stream(c, wide ? c->fused_wide_stream : c->fused_stream,
+                      (size_t)FM_WAVES * (size_t)(wide ? c->fused_wide_fpw : c->fused_fpw) * 1024, s));
     const bool in_prologue = patch != nullptr && fused && !wide && !fp8w && c->fuse_patch && c->mixer_mode != 4;
     if (patch != nullptr && !in_prologue) launch_patch_args<TA>(c, *patch, s);
     patch = in_prologue ? patch : nullptr;
@@ -1223,6 +1258,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   *out = c;
   return TAPIR_OK;
@@ -1235,7 +1271,8 @@ void tapir_destroy(tapir_ctx* c) {
   for (void* p : c->conv_owned) (void)hipFree(p);
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
-                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk};
+                    &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk,
+                    &c->cyc_pts, &c->cyc_feat, &c->cyc_map, &c->cyc_inv, &c->grid_tiled, &c->warm_sink};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)

@@ -41,6 +41,25 @@ for f in sorted(glob.glob(os.environ.get('OUT','gpurun_out/r04final')+'/ab_*.jso
     print(os.path.basename(f), d.get('ms_per_step'), d.get('value'), 'hot', d.get('hot_path_ms'), 'bb', d.get('backbone_ms'), k)
 EOF
 fi
+if [ "$PART" == "warm" ]; then
+  # the weight-stream warming in front of a clip's first refinement iteration, on / off, alternated; then the timeline
+  for rep in 1 2; do
+    TAPIR_WARM_WEIGHTS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_cold_$rep.json
+    TAPIR_WARM_WEIGHTS=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_warm_$rep.json
+  done
+  python - <<'EOF' | tee $OUT/ab_summary.txt
+import json,glob,os
+for f in sorted(glob.glob(os.environ.get('OUT','gpurun_out/r04final')+'/ab_*.json')):
+    try: d=json.loads(open(f).read())
+    except Exception as e: print(f,'unreadable',e); continue
+    k={a: b.get('avg_us') for a, b in (d.get('kernels') or {}).items() if b.get('launches')}
+    print(os.path.basename(f), d.get('ms_per_step'), d.get('value'), 'hot', d.get('hot_path_ms'), 'bb', d.get('backbone_ms'), k)
+EOF
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/rocprof.err
+  cd $R; for f in $(find $OUT/prof -name '*.db'); do python tools/timeline.py $f 3 > $OUT/timeline.txt; python profiles/summarize_rocpd.py $f > $OUT/kernel_stats.csv; done
+  cat $OUT/timeline.txt | tail -24
+fi
 if [ "$PART" == "prof" ]; then
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/rocprof.err
