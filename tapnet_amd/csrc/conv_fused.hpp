@@ -283,6 +283,12 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
   lds_barrier();          // (also: the reads of s_stat above are done, the scratch is reused below)
   int* const s_flag = reinterpret_cast<int*>(scratch);
   if (tid == 0) {
+    // RELAXED on purpose.  An acq_rel ticket (or a __threadfence before it) is not free here: the release half is a
+    // write-back of the XCD's whole L2 (buffer_wbl2), which holds up to 100 MB of the activations this launch just
+    // stored -- measured 1.6 -> 6.1 ms per clip.  The ordering the hand-off needs is built from what
+    // the hardware guarantees instead: the summaries are stored write-through (sc1) and the wave's vector-memory
+    // queue is drained (dma_wait<0>, an asm volatile with a memory clobber the compiler cannot move the atomic
+    // across) before the ticket; the last arriver reads them with sc1 loads that bypass L1 and the non-coherent L2s.
     const int last = agent_fetch_add(fin.arrive + n, 1) == tiles - 1;
     if (last) agent_store_int(fin.arrive + n, 0);
     *s_flag = last;
