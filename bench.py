@@ -284,6 +284,33 @@ def accuracy_vs_f32(kw, weights, dev, video, qpts, out16):
                    '(profiles/r03_accuracy_bf16.json, r03_backbone_rounding_experiment.json)')
 
 
+def box_probe(dev):
+  """The boxes of the pool differ by up to 35 % on the backbone for the same graph: a device-to-device
+  copy rate and a dense bf16 GEMM rate measured after the timed region say which kind of box a line comes from.
+  Not part of any timed number."""
+  import torch
+  a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+  b = torch.empty_like(a)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  for _ in range(2):
+    b.copy_(a)
+  e0.record()
+  for _ in range(10):
+    b.copy_(a)
+  e1.record(); torch.cuda.synchronize()
+  copy = 2 * 10 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e12      # read + write
+  m = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+  for _ in range(2):
+    m @ m
+  e0.record()
+  for _ in range(10):
+    m @ m
+  e1.record(); torch.cuda.synchronize()
+  gemm = 10 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+  return dict(d2d_copy_TBps=round(copy, 2), library_bf16_gemm_8192_TFLOPs=round(gemm, 1),
+              note='copy counts read + write bytes of a 256-MiB buffer; GEMM is the library (hipBLASLt) on 8192^3')
+
+
 def main():
   args = parse()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -515,6 +542,8 @@ def main():
         hot_path_points_per_s=round(Q / hot_s, 2),
         point_frames_per_s=round(value * T, 1),
         roofline=roof, kernels=kernels)
+    if world == 1:
+      line['box'] = box_probe(dev)
     if sharded is not None:
       line['one_clip_sharded'] = sharded
     if batch2 is not None:
