@@ -22,9 +22,6 @@
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
 #include "mixer_fused_wide.hpp"
-#ifdef TAPIR_EXPERIMENTS
-#include "experiments/mixer_fused_fp8w.hpp"   // fp8 weight stream: opt-in third precision class, experiments builds only
-#endif
 #include "pips.hpp"
 
 using namespace tapir;
@@ -74,11 +71,6 @@ struct tapir_ctx {
   // track-resident fused mixer (mixer_fused.hpp): per-wave A-fragment streams + per-block vectors
   uint4* fused_stream = nullptr; long fused_fpw = 0;
   uint4* fused_wide_stream = nullptr; long fused_wide_fpw = 0;   // bf16: the 6-tile kernel's chunking (mixer_fused_wide.hpp)
-#ifdef TAPIR_EXPERIMENTS
-  uint4* fp8w_stream = nullptr;                                   // fp8 weight stream of mixer_fused_fp8w.hpp (8 waves)
-  float fp8w_s_in = 1.f, fp8w_s_out = 1.f;
-  std::vector<float> fp8w_s_dn; std::vector<float*> fp8w_ln2s;
-#endif
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   bool cv_tiled = true;                           // row-streamed cost volume, bf16: contraction operand in tile order (TAPIR_CV_TILED=0: row-major, A/B)
@@ -404,98 +396,6 @@ int build_fused_wide_weights(tapir_ctx* c) {
   c->fused_wide_fpw = fpw;
   return TAPIR_OK;
 }
-
-#ifdef TAPIR_EXPERIMENTS
-// OCP e4m3 (bias 7, max 448, no infinities), round to nearest even, saturating
-static uint8_t host_f2fp8(float v) {
-  const uint8_t sign = v < 0.f ? 0x80 : 0;
-  float a = std::min(std::fabs(v), 448.0f);
-  if (!(a > 0.f)) return sign;
-  int e;
-  std::frexp(a, &e);                       // a = m * 2^e, m in [0.5, 1)
-  e = std::max(e - 1, -6);                 // exponent of the leading bit, clamped to the subnormal range
-  const float q = std::ldexp(1.0f, e - 3); // value of one mantissa step
-  float n = std::nearbyint(a / q);         // 8..15 for normals (16 carries), 0..7 for subnormals
-  if (n >= 16.f) { n = 8.f; e += 1; }
-  if (e > 8 || (e == 8 && n > 14.f)) return sign | 0x7e;    // 448 = 1.75 * 2^8
-  if (n < 8.f) return sign | (uint8_t)n;                      // subnormal (e == -6)
-  return sign | (uint8_t)(((e + 7) << 3) | ((int)n - 8));
-}
-
-// fp8 copy of the 8-wave kernel's weight stream (build_fused_weights<bf16_t>'s order), ONE power-of-two scale per matrix
-// (amax / 448 rounded up: fp8 code x scale is then exactly a bf16, and folding the scale commutes with every rounding)
-int build_fused_fp8w_weights(tapir_ctx* c) {
-  typedef FusedCfg<bf16_t> CF;
-  const int nb = c->cfg.num_mixer_blocks;
-  const long fpw = fused_frags_per_wave<bf16_t>(c->k0_pad, nb);
-  std::vector<uint8_t> host((size_t)FM_WAVES * fpw * 512, 0);
-  const std::string mx = "torch_pips_mixer.";
-  const HostTensor *w0, *wout;
-  TRY(get_w(c, mx + "linear.weight", {kHidden, c->in_dim}, &w0));
-  TRY(get_w(c, mx + "linear_1.weight", {kMixOut, kHidden}, &wout));
-  std::vector<const HostTensor*> wup(nb), wdn(nb);
-  auto scale_of = [](const HostTensor* t) {
-    float amax = 0.f;
-    for (float v : t->data) amax = std::max(amax, std::fabs(v));
-    return amax > 0.f ? std::ldexp(1.0f, (int)std::ceil(std::log2(amax / 448.0f))) : 1.0f;
-  };
-  c->fp8w_s_dn.assign(nb, 1.f);
-  std::vector<float> s_up(nb, 1.f);
-  for (int b = 0; b < nb; ++b) {
-    const std::string p = mx + "blocks." + std::to_string(b) + ".conv_channels_mixer.";
-    TRY(get_w(c, p + "mlp2_up.weight", {kHidden4, kHidden}, &wup[b]));
-    TRY(get_w(c, p + "mlp2_down.weight", {kHidden, kHidden4}, &wdn[b]));
-    s_up[b] = scale_of(wup[b]); c->fp8w_s_dn[b] = scale_of(wdn[b]);
-  }
-  c->fp8w_s_in = scale_of(w0); c->fp8w_s_out = scale_of(wout);
-  constexpr int RAU = CF::HC / 8 / 16, NC = kHidden4 / CF::HC;
-  for (int w = 0; w < FM_WAVES; ++w) {
-    uint8_t* q = host.data() + (size_t)w * fpw * 512;
-    auto put = [&](const HostTensor* t, float sc, int rows, int cols, int row0, int k0) {
-      for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 8; ++j) {
-          const int r = row0 + (l & 15), k = k0 + (l >> 4) * 8 + j;
-          q[l * 8 + j] = (r < rows && k < cols) ? host_f2fp8(t->data[(size_t)r * cols + k] / sc) : 0;
-        }
-      q += 512;
-    };
-    for (int ks = 0; ks < c->k0_pad / 32; ++ks)
-      for (int a = 0; a < 4; ++a) put(w0, c->fp8w_s_in, kHidden, c->in_dim, 64 * w + 16 * a, ks * 32);
-    auto put_up = [&](int b, int hc) {
-      for (int ks = 0; ks < kHidden / 32; ++ks)
-        for (int a = 0; a < RAU; ++a)
-          put(wup[b], s_up[b], kHidden4, kHidden, hc * CF::HC + w * (CF::HC / 8) + 16 * a, ks * 32);
-    };
-    auto put_dn = [&](int b, int hc) {
-      for (int ks = 0; ks < CF::HC / 32; ++ks)
-        for (int a = 0; a < 4; ++a) put(wdn[b], c->fp8w_s_dn[b], kHidden, kHidden4, 64 * w + 16 * a, hc * CF::HC + ks * 32);
-    };
-    for (int b = 0; b < nb; ++b) {
-      put_up(b, 0);
-      for (int hc = 1; hc < NC; ++hc) { put_up(b, hc); put_dn(b, hc - 1); }
-      put_dn(b, NC - 1);
-    }
-    for (int ks = 0; ks < kHidden / 32; ++ks)
-      for (int a = 0; a < 4; ++a) put(wout, c->fp8w_s_out, kMixOut, kHidden, 64 * w + 16 * a, ks * 32);
-    if (q + (size_t)FM_RING * 512 != host.data() + (size_t)(w + 1) * fpw * 512)
-      return fail(c, TAPIR_ERR_WEIGHTS, "fp8 fused stream layout mismatch");
-  }
-  void* d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, host.size()));
-  c->owned.push_back(d);
-  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
-  c->fp8w_stream = (uint4*)d;
-  c->fp8w_ln2s.assign(nb, nullptr);
-  for (int b = 0; b < nb; ++b) {
-    const HostTensor* ln2;
-    TRY(get_w(c, mx + "blocks." + std::to_string(b) + ".layer_norm_1.weight", {kHidden}, &ln2));
-    std::vector<float> v(ln2->data);
-    for (float& x : v) x *= s_up[b];
-    TRY(upload_f32(c, v.data(), v.size(), &c->fp8w_ln2s[b]));
-  }
-  return TAPIR_OK;
-}
-#endif
 
 // ----------------------------------------------------------------------------
 // small helper kernels
@@ -858,13 +758,6 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
     bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
                 fused_wide_supported(T, c->k0_pad, causal, has_ctx);
-#ifdef TAPIR_EXPERIMENTS
-    const bool fp8w = c->mixer_mode == 7;
-    if (fp8w && !(sizeof(TA) == 2 && c->fp8w_stream != nullptr && fused))
-      return fail(c, TAPIR_ERR_UNSUPPORTED, "fp8-weight fused mixer forced, but it does not cover this shape");
-#else
-    const bool fp8w = false;
-#endif
     if (c->mixer_mode == 2 && !fused)
       return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
     if (c->mixer_mode == 3 && !wide)
@@ -872,7 +765,6 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     if (c->mixer_mode == 1) fused = wide = false;
     if (c->mixer_mode == 2) wide = false;
     if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
-    if (fp8w) wide = false;
     if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
@@ -882,10 +774,10 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
       if (wide) fused = false;
     }
-    if ((fused || wide) && !fp8w && c->warm_weights && upd != nullptr && upd->first_of_level)
+    if ((fused || wide) && c->warm_weights && upd != nullptr && upd->first_of_level)
       TRY(warm_stream(c, wide ? c->fused_wide_stream : c->fused_stream,
                       (size_t)FM_WAVES * (size_t)(wide ? c->fused_wide_fpw : c->fused_fpw) * 1024, s));
-    const bool in_prologue = patch != nullptr && fused && !wide && !fp8w && c->fuse_patch && c->mixer_mode != 4;
+    const bool in_prologue = patch != nullptr && fused && !wide && c->fuse_patch && c->mixer_mode != 4;
     if (patch != nullptr && !in_prologue) launch_patch_args<TA>(c, *patch, s);
     patch = in_prologue ? patch : nullptr;
     if (fused || wide) {
@@ -901,19 +793,10 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       fa.lnF = c->lnF; fa.bout = c->bout; fa.res = (float*)c->res.p;
       fa.N = N; fa.T = T;
       fa.pair_sim = c->mixer_mode == 4 ? 1 : 0;
-      if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim && !fp8w) {   // (fp8w: separate update kernel)
+      if (upd != nullptr && upd_done != nullptr && c->fuse_update && !fa.pair_sim) {
         fa.fuse_update = 1; fa.upd = *upd; *upd_done = true;
       }
       ProfScope ps(c, TAPIR_PROF_MIXER, s);
-#ifdef TAPIR_EXPERIMENTS
-      if (fp8w) {
-        FusedQArgs qa{};
-        qa.base = fa; qa.base.stream = c->fp8w_stream;
-        qa.s_in = c->fp8w_s_in; qa.s_out = c->fp8w_s_out;
-        for (int i = 0; i < nb; ++i) { qa.s_dn[i] = c->fp8w_s_dn[i]; qa.ln2s[i] = c->fp8w_ln2s[i]; }
-        launch_mixer_fused_fp8w(qa, s);
-      } else
-#endif
       if (wide) launch_mixer_fused_wide(fa, s);
       else launch_mixer_fused<TA>(fa, s);
       return TAPIR_OK;
@@ -1308,9 +1191,6 @@ int tapir_finalize_weights(tapir_ctx* c) {
   c->tapnet_ready = false; c->tapir_ready = false;
   c->fused_stream = nullptr; c->fused_blocks.clear(); c->fused_fpw = 0;
   c->fused_wide_stream = nullptr; c->fused_wide_fpw = 0;
-#ifdef TAPIR_EXPERIMENTS
-  c->fp8w_stream = nullptr; c->fp8w_ln2s.clear(); c->fp8w_s_dn.clear();
-#endif
   const bool has_tapnet = c->host_w.count("tapnet_cost_volume_track_mods.hid1.weight") != 0;
   bool has_tapir = !has_tapnet;   // a context without TAP-Net head weights must be a complete TAPIR
   for (const auto& kv : c->host_w)
@@ -1365,9 +1245,6 @@ static int finalize_tapir(tapir_ctx* c) {
   if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
     if (c->cfg.dtype == TAPIR_BF16) {
       TRY(build_fused_weights<bf16_t>(c)); TRY(build_fused_wide_weights(c));
-#ifdef TAPIR_EXPERIMENTS
-      TRY(build_fused_fp8w_weights(c));
-#endif
     }
     else TRY(build_fused_weights<float>(c));
   }
@@ -1900,7 +1777,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
 int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
   bool ok = mode >= 0 && mode <= 3;
 #ifdef TAPIR_EXPERIMENTS
-  ok = ok || mode == 4 || mode == 7;   // 4: timing-only pair simulation of the wide kernel; 7: fp8 weight stream
+  ok = ok || mode == 4;   // timing-only pair simulation of the wide kernel
 #endif
   if (!c || !ok) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;

@@ -323,8 +323,6 @@ def bench_mixer(model, reps, results, shapes=((256, 48), (1024, 48), (512, 48), 
       modes.append((2, 'fused'))
     if model.dtype == 'bfloat16' and T > 16:
       modes.append((3, 'fused_wide'))
-    if model.dtype == 'bfloat16' and T <= 48 and lib.tapir_debug_set_mixer_mode(ctx, 7) == 0:
-      modes.append((7, 'fused_fp8_weights'))      # (-DTAPIR_EXPERIMENTS builds: experiments/mixer_fused_fp8w.hpp; diff vs separate = quantisation)
     if os.environ.get('KBENCH_PAIRSIM') and model.dtype == 'bfloat16' and T == 48 and N % 2 == 0:
       modes.append((4, 'pair_sim_TIMING_ONLY'))   # (-DTAPIR_EXPERIMENTS builds; meaningless outputs)
     for mode, name in modes:

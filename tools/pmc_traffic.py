@@ -21,7 +21,6 @@ KERNELS = {
     # round 2
     'mixer_fused': ('mixer_fused_kernel<unsigned short, 3, false', ''),
     'mixer_fused_wide': ('mixer_fused_wide_kernel<3, 2, false', ''),
-    'mixer_fused_half': ('mixer_fused_half_kernel<3, false', ''),
     'cv_fused': ('cv_fused_kernel<unsigned short', ''),
     'patch_corr': ('patch_corr_kernel<unsigned short', ''),
     'conv3x3_c64_shortcut': ('conv_fused_kernel<', '64, 64, 3, 1, 4, 4, true'),
