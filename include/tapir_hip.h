@@ -119,8 +119,11 @@ int tapir_tapnet_tracks_from_cost_volume(tapir_ctx* ctx, const float* qfeat, con
  * vector against the grid of the frame its query came from (:501-531); a point whose backward track lands more than
  * dist_threshold (48) pixels from the query is occluded: logit +10, else -10 (:533-539; the intended indexing of :537).
  * Both passes are the row-streamed cost-volume kernel without heads -- no [B,N,T,h,w] tensor exists.
- * query_feats [B,Q,256], feature_grid [B,T,h,w,256] (w <= 32), query_points [B,Q,3] (t,y,x) in img_h x img_w pixels;
- * tracks [B,Q,T,2] (x,y), occlusion [B,Q,T], inverse_tracks [B,Q,T,2] or NULL.  No weights needed. */
+ * query_feats [B,Q,256], feature_grid [B,T,h,w,256] (rows of up to 32 cells on up to 32 rows -- 64 rows for w <= 16 --
+ * or rows of 33..64 cells on up to 64 rows; TAPIR_ERR_UNSUPPORTED otherwise), query_points [B,Q,3] (t,y,x) in
+ * img_h x img_w pixels; tracks [B,Q,T,2] (x,y), occlusion [B,Q,T], inverse_tracks [B,Q,T,2] or NULL.  No weights needed.
+ * Queries are processed in chunks (at most 256 MiB of sampled vectors at a time, the reference's eval_chunk_size loop).
+ * Its workspaces are not part of tapir_reserve(): call it once at the largest shape before tapir_pin_workspaces(). */
 int tapir_cycle_consistency_tracks(tapir_ctx* ctx, const float* query_feats, const float* feature_grid,
                                    const float* query_points, int B, int Q, int T, int h, int w, int img_h, int img_w,
                                    float softmax_temperature, float dist_threshold, float* tracks, float* occlusion,

@@ -28,6 +28,10 @@ from tapnet_amd import synthetic  # noqa: E402
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                           'tests', 'golden')
+# --check tolerance.  The fixtures are reference OUTPUTS; regenerating them re-runs the reference's float32 torch-CPU
+# path, which is reproducible to float noise only: observed 0.0 for tapir / causal / multires / causal_update /
+# headline_tapir and 3.8e-6 px for bootstapir (the ExtraConvs convolutions), against the 1e-3 parity bar.
+CHECK_ATOL = 1e-5
 
 # name -> dict(kwargs for the reference ctor, clip, queries)
 CASES = {
@@ -227,15 +231,17 @@ def make_headline_case(tm, name, cfg, check=False):
   if check:
     old = np.load(path)
     worst = max(float(np.abs(old[k] - v).max()) for k, v in res.items())
-    print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e}')
-    assert set(old.files) == set(res) and worst == 0.0, name
+    print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {CHECK_ATOL:g})')
+    assert set(old.files) == set(res) and worst <= CHECK_ATOL, name
     return
   np.savez_compressed(path, **res)
   print(name, {k: v.shape for k, v in res.items() if k == 'tracks'}, f'{os.path.getsize(path) / 1e6:.2f} MB')
 
 
 def check_case(tm, name, cfg):
-  """--check: the committed stage-boundary fixture against a fresh run of the reference (bit for bit)."""
+  """--check: the committed stage-boundary fixture against a fresh run of the reference, within CHECK_ATOL: the
+  reference's torch-CPU convolutions do not promise one summation order from day to day (oneDNN picks by thread
+  count and shape heuristics), so a regeneration is float noise away from the committed file, not always 0."""
   global GOLDEN_DIR
   keep = GOLDEN_DIR
   old = {k: v for k, v in np.load(os.path.join(keep, name + '.npz')).items()}
@@ -250,8 +256,8 @@ def check_case(tm, name, cfg):
     GOLDEN_DIR = keep
   assert set(old) == set(new), (name, set(old) ^ set(new))
   worst = max(float(np.abs(old[k].astype(np.float64) - new[k].astype(np.float64)).max()) for k in old)
-  print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e}')
-  assert worst == 0.0, name
+  print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {CHECK_ATOL:g})')
+  assert worst <= CHECK_ATOL, name
 
 
 def main():

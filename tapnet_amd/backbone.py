@@ -476,7 +476,11 @@ class Backbone:
       # workgroups per launch; the library's split-K kernels win there)
       xe = self._extra_convs_hip(x) if (self.extra_convs_mode == 'hip' and self._hip_now) else None
       x = xe if xe is not None else self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
-    if staged is not None and x.shape[-1] == 256:
+    if staged is not None:
+      # the caller publishes these buffers to the hot path (last_staged -> tapir_set_staged_grid): they must be written
+      if x.shape[-1] != 256:
+        raise RuntimeError('tapnet_amd.backbone: staged grid copies requested for a %d-channel low-res map '
+                           '(_stage_ok and the weights disagree)' % x.shape[-1])
       return self._hip_l2norm(x, out_low, staged[0], staged[1]), self._hip_l2norm(unit1, out_hi, staged[2])
     return self._hip_l2norm(x, out_low), self._hip_l2norm(unit1, out_hi)
 
@@ -527,15 +531,17 @@ class Backbone:
         ent = {'seen': 0}
       self._graphs[key] = ent
       ent['seen'] += 1
-      # a few captured shapes at most (their static buffers are large): evict the least recently used
-      # CAPTURED entry; entries that were only counted cost nothing and are trimmed separately
-      captured = [k for k, e in self._graphs.items() if 'graph' in e and k != key]
-      if len(captured) >= 4 and 'graph' not in ent:      # at most four captured graphs resident, this one included
-        self._graphs.pop(captured[0])
+      # entries that were only counted cost nothing and are trimmed here; captured graphs (large static buffers) are
+      # evicted only at the moment another one is about to be captured (below): a one-off shape that never reaches
+      # its third call does not push a captured graph out
       if len(self._graphs) > 64:
-        for k in [k for k, e in self._graphs.items() if 'graph' not in e][:32]:
+        for k in [k for k, e in self._graphs.items() if 'graph' not in e and k != key][:32]:
           self._graphs.pop(k)
       if 'graph' not in ent and not ent.get('failed') and ent['seen'] >= 3:
+        # at most four captured graphs resident, this one included: drop the least recently used one
+        captured = [k for k, e in self._graphs.items() if 'graph' in e and k != key]
+        if len(captured) >= 4:
+          self._graphs.pop(captured[0])
         ent['in'] = frames_nhwc.contiguous().clone()
         ent['low'], ent['hi'] = torch.empty_like(low), torch.empty_like(hi)
         ent['staged'] = self.staged_like(low, hi) if self._stage_ok(low) else None

@@ -622,9 +622,14 @@ int do_cycle_consistency(tapir_ctx* c, const float* qfeat, const float* grid, co
                          float* occlusion, float* inverse_tracks, hipStream_t s) {
   const int C = kLowresDim;
   if (!cv_rows_supported(h, w))
-    return fail(c, TAPIR_ERR_UNSUPPORTED, "cycle-consistency tracker: grids of up to 64 x 64 cells");
+    return fail(c, TAPIR_ERR_UNSUPPORTED,
+                "cycle-consistency tracker: the row-streamed cost-volume kernel covers rows of up to 32 cells on up to "
+                "32 (w <= 16: 64) rows, and rows of 33..64 cells on up to 64 rows");
   const long BQ = (long)B * Q, R = BQ * T;
-  TRY(ensure(c, c->cyc_pts, (size_t)R * 12)); TRY(ensure(c, c->cyc_feat, (size_t)R * C * 4));
+  // The sampled vectors (1 KiB per query and frame) are held for a chunk of queries at a time, like the reference's
+  // eval_chunk_size loop over queries (supervised_point_prediction.py:444-452): at most 256 MiB whatever Q is.
+  const long qc = std::max<long>(1, std::min<long>(Q, (256L << 20) / ((long)T * C * 4)));
+  TRY(ensure(c, c->cyc_pts, (size_t)R * 12)); TRY(ensure(c, c->cyc_feat, (size_t)qc * T * C * 4));
   TRY(ensure(c, c->cyc_map, (size_t)BQ * 4));
   if (inverse_tracks == nullptr) { TRY(ensure(c, c->cyc_inv, (size_t)R * 8)); inverse_tracks = (float*)c->cyc_inv.p; }
   const void* qf_op = qfeat; const void* grid_op = grid; const void* tiled_op = nullptr;
@@ -636,20 +641,28 @@ int do_cycle_consistency(tapir_ctx* c, const float* qfeat, const float* grid, co
   }
   // forward (:453-469): every query against every frame, the query's own frame overridden by the query point
   cycle_pass<TA>(c, qf_op, grid_op, tiled_op, qpts, nullptr, B, Q, T, h, w, (float)img_h, (float)img_w, temperature, tracks, s);
-  // features at the tracked points (:473-496) and the frames the queries came from (:501-514)
+  // the tracked points as (t, y, x) and the frames the queries came from (:489-514)
   CycPtsArgs pa{tracks, qpts, (float*)c->cyc_pts.p, (int*)c->cyc_map.p, BQ, Q, T};
   hipLaunchKernelGGL(cycle_points_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, pa);
-  SampleArgs sa{grid, (const float*)c->cyc_pts.p, (float*)c->cyc_feat.p, B, Q * T, T, h, w, C, (float)img_h, (float)img_w};
-  hipLaunchKernelGGL(query_feature_kernel, dim3((unsigned)R), dim3(128), 0, s, sa);
-  // backward (:516-531): the T sampled vectors of a query against the ONE frame the query came from -- B * Q "clips"
-  // of one frame with T "queries" each; frame_map picks the grid frame
-  const void* f_op = c->cyc_feat.p;
-  if (sizeof(TA) == 2) {
-    TRY(cast_or_pool<TA>(c, (const float*)c->cyc_feat.p, 1, 1, (int)R, C, 0, c->qf_cast, s));
-    f_op = c->qf_cast.p;
+  for (int b = 0; b < B; ++b) {
+    for (long q0 = 0; q0 < Q; q0 += qc) {
+      const int nq = (int)std::min<long>(qc, Q - q0);
+      const long bq = (long)b * Q + q0;
+      // features at the tracked points (:473-496): nq * T samples of clip b
+      SampleArgs sa{grid + (size_t)b * T * h * w * C, (const float*)c->cyc_pts.p + bq * T * 3, (float*)c->cyc_feat.p,
+                    1, nq * T, T, h, w, C, (float)img_h, (float)img_w};
+      hipLaunchKernelGGL(query_feature_kernel, dim3((unsigned)(nq * T)), dim3(128), 0, s, sa);
+      // backward (:516-531): the T sampled vectors of a query against the ONE frame the query came from -- nq "clips"
+      // of one frame with T "queries" each; frame_map picks the grid frame (an index into all B * T frames)
+      const void* f_op = c->cyc_feat.p;
+      if (sizeof(TA) == 2) {
+        TRY(cast_or_pool<TA>(c, (const float*)c->cyc_feat.p, 1, 1, nq * T, C, 0, c->qf_cast, s));
+        f_op = c->qf_cast.p;
+      }
+      cycle_pass<TA>(c, f_op, grid_op, tiled_op, nullptr, (const int*)c->cyc_map.p + bq, nq, T, 1, h, w, (float)img_h,
+                     (float)img_w, temperature, inverse_tracks + bq * T * 2, s);
+    }
   }
-  cycle_pass<TA>(c, f_op, grid_op, tiled_op, nullptr, (const int*)c->cyc_map.p, (int)BQ, T, 1, h, w, (float)img_h,
-                 (float)img_w, temperature, inverse_tracks, s);
   CycOccArgs oa{inverse_tracks, qpts, occlusion, BQ, T, threshold * threshold};
   hipLaunchKernelGGL(cycle_occlusion_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, oa);
   return TAPIR_OK;
@@ -1274,6 +1287,7 @@ int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
     TRY(ensure_zeroed(c, c->grid_tiled, tiled_bytes((long)frames, (int)mh, (int)mw)));
   }
   if (c->cfg.pyramid_level >= 1) TRY(ensure(c, c->pooled, frames * (mh / 2) * (mw / 2) * kLowresDim * es));
+  TRY(ensure(c, c->warm_sink, 4));   // (warm_stream_kernel's sink: the first fused-mixer iteration of a level must not allocate while pinned)
   return TAPIR_OK;
 }
 

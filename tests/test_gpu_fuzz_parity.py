@@ -9,11 +9,13 @@ What is asserted, per sweep:
     1e-4 between the two largest soft-max cells of the oracle's heat map (a near-tie arg max may legitimately flip
     between two f32 evaluation orders, and the temporal convolutions spread the flip over the query's frames);
     at least 90 % of the queries must remain;
-  * on the remaining queries every point, every frame: tracks within 1e-3 px IN INITIAL-RESOLUTION PIXELS, logits within
-    1e-3.  The engine's tracks are in video pixels (tapir_model.py:906-912 rescales by video / initial resolution), so
-    on a frame at twice the initial resolution a deviation of 5.7e-4 px of the 256-coordinate estimate reads 1.14e-3 px
-    -- the one value above 1e-3 in round 3's sweep (profiles/r03_fuzz_parity.txt); north_star's tolerance is stated
-    for video = initial resolution.  Both numbers are recorded (gpurun_out/fuzz_parity.json).
+  * on the remaining queries every point, every frame, PER CASE: tracks within 1e-3 x (video / initial resolution) px
+    in VIDEO pixels -- i.e. within 1e-3 px of the initial-resolution estimate -- and logits within 1e-3.  The engine's
+    tracks are in video pixels (tapir_model.py:906-912 rescales by video / initial resolution), so on a frame at twice
+    the initial resolution a deviation of 5.7e-4 px of the 256-coordinate estimate reads 1.14e-3 px (round 3's sweep,
+    profiles/r03_fuzz_parity.txt); north_star states its tolerance for video = initial resolution, and the re-scaling
+    is in the ASSERTION (`tracks_video_px_max <= 1e-3 * scale` below), not only here.  Both numbers are recorded
+    (gpurun_out/fuzz_parity.json).  40 + 8 cases (round 5; 10 + 2 before).
 Reference arithmetic: tapnet/models/tapir_model.py:626-729, 858-1154; tapnet/utils/model_utils.py:209-314."""
 import json
 import os
@@ -27,7 +29,7 @@ from tapnet_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEPS = {'A_small': dict(seed=1, cases=10, tmax=20, qmax=24), 'B_fused_mixer': dict(seed=7, cases=2, tmax=50, qmax=96)}
+SWEEPS = {'A_small': dict(seed=1, cases=40, tmax=20, qmax=24), 'B_fused_mixer': dict(seed=7, cases=8, tmax=50, qmax=96)}
 
 
 def _case(rng, tmax, qmax):
@@ -85,6 +87,8 @@ def test_random_shapes_against_the_oracle(sweep):
                masked_tracks_video_px_max=float(d[~clear].max()) if (~clear).any() else 0.0,
                min_top2_rel_gap=float(st['top2_rel_gap'].min()))
     rows.append(row)
+    # the bound in video pixels, per case: 1e-3 px of the initial-resolution estimate, re-scaled as the model re-scales
+    assert row['tracks_video_px_max'] <= 1e-3 * scale and row['logits_max'] < 1e-3, row
     n_q += Q; n_clear += int(clear.sum())
     del m
   frac = n_clear / n_q

@@ -4,7 +4,8 @@ configs[1] -- 256x256x48 clip, 256 queries, both checkpoint kwarg sets -- commit
 (outputs only; the clip, the queries and the weights are seeds).
 
   * CPU, `reference` marker: the committed torch-twin fixtures (the stage-boundary ones of tests/golden/ AND these)
-    regenerate bit for bit from the reference tree (skipped where the tree is absent);
+    regenerate from the reference tree within 1e-5 (float noise of the reference's torch-CPU convolutions; observed
+    0 .. 3.8e-6; skipped where the tree is absent);
   * GPU: the f32 engine, video -> tracks through every production kernel (HIP backbone, row-streamed cost volume,
     patch correlation, track-resident mixer), against those outputs at north_star's 1e-3: every frame and every
     refinement iteration of every query whose heat maps have no near-tie -- 255 of 256 (TAPIR kwargs; the TAPIR case
@@ -32,15 +33,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(not ref_import.reference_available() or ref_import.reference_is_staged_copy(),
                     reason='reference tree not present')
 def test_torch_twin_goldens_regenerate_from_the_reference():
-  """oracle/make_golden.py --check: two of the small stage-boundary cases by default (~10 s); TAPNET_FULL_REGEN=1
-  re-runs all five and both headline cases (~1.5 min)."""
+  """oracle/make_golden.py --check: all five small stage-boundary cases by default (seconds each);
+  TAPNET_FULL_REGEN=1 adds both headline cases (~1.5 min).  The comparison carries a stated tolerance
+  (make_golden.CHECK_ATOL = 1e-5: the reference's torch-CPU convolutions are reproducible to float noise, not bit for
+  bit -- bootstapir regenerates at 3.8e-6 px); the observed maxima are printed."""
   full = os.environ.get('TAPNET_FULL_REGEN') == '1'
-  cases = ['tapir', 'bootstapir', 'causal', 'multires', 'causal_update', 'headline_tapir', 'headline_bootstapir'] if full \
-      else ['tapir', 'causal']
+  cases = ['tapir', 'bootstapir', 'causal', 'multires', 'causal_update']
+  if full:
+    cases += ['headline_tapir', 'headline_bootstapir']
   r = subprocess.run([sys.executable, '-m', 'oracle.make_golden', '--check'] + cases, cwd=ROOT,
                      capture_output=True, text=True, timeout=1800)
+  print(r.stdout)
   assert r.returncode == 0, r.stdout + r.stderr
-  assert r.stdout.count('max |diff| 0.000e+00') == len(cases), r.stdout
+  assert r.stdout.count('committed vs regenerated from the reference') == len(cases), r.stdout
 
 
 def test_headline_fixtures_are_outputs_only():
