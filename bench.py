@@ -65,6 +65,10 @@ def parse():
   ap.add_argument('--no-accuracy', action='store_true')
   ap.add_argument('--cpu-sample-queries', type=int, default=48)
   ap.add_argument('--cpu-sample-frames', type=int, default=12)
+  ap.add_argument('--emulate-rank', type=int, nargs='*', default=None, metavar='N',
+                  help='N = 1 only: time what ONE rank of an N-rank sharded call does on this GPU (backbone on T/N frames, '
+                       'hot path on Q/N queries against the full grids) and PROJECT the N-GPU rate with the SURVEY 8e link '
+                       'arithmetic; no values = 2 4 8.  A projection, labelled as such -- never `value`.')
   return ap.parse_args()
 
 
@@ -116,23 +120,24 @@ v = torch.from_numpy(synthetic.make_video(cfg['vseed'], cfg['T'], cfg['size'], c
 q = torch.from_numpy(synthetic.make_queries(cfg['qseed'], cfg['Q'], cfg['T'], cfg['size'], cfg['size']))
 times = []
 with torch.no_grad():
-  for i in range(2):
+  for i in range(4):   # 1 warm-up + 3 timed (SURVEY.md 8d: median of 3); every call is reported as soon as it ends
     t0 = time.perf_counter()
     model(v, q)
     times.append(time.perf_counter() - t0)
     print(json.dumps(dict(times=times, staged=ref_import.reference_is_staged_copy(), root=ref_import.REFERENCE_ROOT)), flush=True)
-    if times[0] > cfg['one_call_above_s']:
+    if times[0] > cfg['one_call_above_s'] or sum(times) + 1.3 * max(times) > cfg['budget_s']:
       break
 """
 
 
 def reference_torch_cpu(args, kw, weights, video_np, qpts_np, budget_s=150.0):
   """The reference's own CPU path (tapnet/torch/tapir_model.py TAPIR.forward; JAX is not installable offline) at
-  the FULL workload on this host's cores: 1 warm-up + 1 timed call (~12-16 s each on 8 cores).  The reference tree is
+  the FULL workload on this host's cores: 1 warm-up + 3 timed calls, the MEDIAN reported (~6.5 s each on 16 cores).  The reference tree is
   /root/reference in the build container; on the GPU box it is the copy oracle/stage_ref.py staged into the
   git-ignored oracle/_ref/ (shipped with the push like the built .so files).  None when neither exists.
   BOUNDED: the calls run in a child process that is killed after `budget_s` seconds; if the first call alone takes
-  more than a third of the budget it is the measurement (no warm-up); a child that produces nothing in time yields an
+  more than a third of the budget it is the measurement (no warm-up), and fewer timed calls are made when three would
+  not fit the budget; a child that produces nothing in time yields an
   `error` entry and the caller falls back to the port."""
   del weights, video_np, qpts_np   # (the child regenerates the same seeded inputs; nothing large crosses the pipe)
   try:
@@ -142,7 +147,7 @@ def reference_torch_cpu(args, kw, weights, video_np, qpts_np, budget_s=150.0):
     cores = host_cores()
     cfg = dict(cores=cores, wseed=0, vseed=1, qseed=101, T=args.frames, Q=args.queries, size=args.size,
                pyramid_level=kw['pyramid_level'], extra_convs=kw['extra_convs'],
-               softmax_temperature=kw['softmax_temperature'], one_call_above_s=budget_s / 3)
+               softmax_temperature=kw['softmax_temperature'], one_call_above_s=budget_s / 3, budget_s=0.8 * budget_s)
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
     p = subprocess.Popen([sys.executable, '-c', _REF_CHILD, ROOT, json.dumps(cfg)], stdout=subprocess.PIPE,
                          stderr=subprocess.DEVNULL, text=True, env=env)
@@ -157,12 +162,15 @@ def reference_torch_cpu(args, kw, weights, video_np, qpts_np, budget_s=150.0):
     r = json.loads(lines[-1])
     times = r['times']
     T, Q = args.frames, args.queries
-    return dict(value=round(Q / times[-1], 3), unit='points/s', cores=cores, kind='reference',
+    timed = sorted(times[1:]) if len(times) > 1 else list(times)
+    med = timed[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed[len(timed) // 2 - 1] + timed[len(timed) // 2])
+    return dict(value=round(Q / med, 3), unit='points/s', cores=cores, kind='reference',
                 sample=f'the FULL workload ({args.size}x{args.size}x{T} clip, {Q} queries, {args.model} kwargs): '
                        'tapnet/torch/tapir_model.py TAPIR.forward of the reference (its torch twin; the JAX path '
                        'needs jax, not installable offline), f32, torch CPU, ' +
-                       ('1 warm-up + 1 timed call' if len(times) == 2 else '1 timed call (no warm-up: time bound)'),
-                seconds=round(times[-1], 2), warmup_seconds=round(times[0], 2) if len(times) == 2 else None,
+                       (f'1 warm-up + {len(times) - 1} timed call(s), median' if len(times) > 1 else '1 timed call (no warm-up: time bound)'),
+                seconds=round(med, 2), timed_seconds=[round(t, 2) for t in (times[1:] if len(times) > 1 else times)],
+                warmup_seconds=round(times[0], 2) if len(times) > 1 else None,
                 source=('oracle/_ref (staged from the reference tree by oracle/stage_ref.py)' if r['staged'] else r['root']))
   except Exception as e:   # the reference is not part of the product: never fail the bench over it
     return dict(error=f'{type(e).__name__}: {e}')
@@ -311,6 +319,183 @@ def box_probe(dev):
               note='copy counts read + write bytes of a 256-MiB buffer; GEMM is the library (hipBLASLt) on 8192^3')
 
 
+BACKBONE_KINDS = ('stem', 'conv3x3_c64', 'conv3x3_c128', 'conv3x3_c256', 'conv_other', 'l2norm')
+
+
+def backbone_kernel_profile(model, video):
+  """Per-kernel-class durations of the backbone from EAGER single-stream launches (events cannot be recorded inside the
+  replayed hipGraph; one stream so that a kernel's start / stop timestamps are its own time on the whole chip, not a
+  share of it).  Untimed; {class: (ms, launches)} for ONE clip."""
+  bb = model._backbone
+  saved_streams, saved_env = bb.streams, os.environ.get('TAPIR_BACKBONE_GRAPH')
+  bb.streams, os.environ['TAPIR_BACKBONE_GRAPH'] = 1, '0'
+  try:
+    model.get_feature_grids(video)          # this lane's scratch
+    torch.cuda.synchronize()
+    model.profile_enable(BACKBONE_KINDS)
+    model.profile_read()
+    reps = 3
+    for _ in range(reps):
+      model.get_feature_grids(video)
+    torch.cuda.synchronize()
+    prof = model.profile_read()
+    return {k: (prof[k][0] / reps, prof[k][1] // reps) for k in BACKBONE_KINDS if prof[k][1]}
+  finally:
+    model.profile_enable(False)
+    bb.streams = saved_streams
+    if saved_env is None:
+      os.environ.pop('TAPIR_BACKBONE_GRAPH', None)
+    else:
+      os.environ['TAPIR_BACKBONE_GRAPH'] = saved_env
+
+
+def roofline_all(prof, bbprof, T, Q, S, es, dtype, pyramid_level, blocks_per_group=(2, 2, 2, 2)):
+  """One roofline entry per kernel class of a step: {avg_us, launches, flops | bytes, bound, achieved, peak, frac}.
+  Algorithmic work per launch as DESIGN.md 3 states it (flops of the contractions only; unique bytes in + out for the
+  memory-bound classes).  Hot-path classes: events of the two untimed profiling steps; backbone classes: eager
+  single-stream launches of one clip (backbone_kernel_profile) -- in the timed step the same kernels run from a
+  replayed hipGraph on four streams, overlapping each other."""
+  peak_tf, peak_f32, peak_bw = PEAK_TFLOPS[dtype], PEAK_TFLOPS['float32'], 8000.0
+  R, h = Q * T, S // 8
+  in_dim = 388 + 49 * (2 + pyramid_level)
+  out = {}
+
+  def mfma(name, ms_n, flops_per_launch, note=None):
+    ms, n = ms_n
+    if not n:
+      return
+    us = ms / n * 1e3
+    ach = flops_per_launch / (us * 1e-6) / 1e12
+    out[name] = dict(avg_us=round(us, 2), launches=n, flops=flops_per_launch, bound='mfma', achieved=round(ach, 1),
+                     peak=peak_tf, unit='TFLOP/s', frac=round(ach / peak_tf, 4))
+    if note:
+      out[name]['note'] = note
+
+  def hbm(name, ms_n, bytes_per_launch, note=None):
+    ms, n = ms_n
+    if not n:
+      return
+    us = ms / n * 1e3
+    ach = bytes_per_launch / (us * 1e-6) / 1e9
+    out[name] = dict(avg_us=round(us, 2), launches=n, bytes=int(bytes_per_launch), bound='hbm', achieved=round(ach, 1),
+                     peak=peak_bw, unit='GB/s', frac=round(ach / peak_bw, 4))
+    if note:
+      out[name]['note'] = note
+
+  z = (0.0, 0)
+  mfma('mixer_fused', prof.get('mixer_fused', z), 2.0 * R * (in_dim * 512 + 12 * 2 * 512 * 2048 + 512 * 388))
+  # cost volume: einsum (operand type) + hid1 / hid2 3x3 convolutions (exact f32 in both builds) + hid3 3x3 / stride 2
+  # (operand type); the composite floor prices each part at its own matrix peak
+  cells = R * h * h
+  f_op, f_f32 = 2.0 * cells * 256 + 2.0 * 144 * 32 * cells / 4, 2.0 * 2 * 144 * cells
+  ms, n = prof.get('cv_heads', z)
+  if n:
+    us = ms / n * 1e3
+    floor_us = (f_op / (peak_tf * 1e12) + f_f32 / (peak_f32 * 1e12)) * 1e6
+    out['cv_rows'] = dict(avg_us=round(us, 2), launches=n, flops=f_op + f_f32, bound='mfma',
+                          achieved=round((f_op + f_f32) / (us * 1e-6) / 1e12, 1), peak=peak_tf, unit='TFLOP/s',
+                          composite_floor_us=round(floor_us, 1), frac=round(floor_us / us, 4),
+                          note='frac = composite floor / measured: einsum + hid3 at the operand-type peak, hid1 + hid2 at the '
+                               'exact-f32 MFMA peak (157.3 TFLOP/s); the heads, soft arg max and the LDS traffic are not priced')
+  # patch correlation: unique bytes = both grid levels once + the mixer input rows written
+  k0_pad = -(-in_dim // (256 // es)) * (256 // es)
+  grids = T * (h * h * 256 + 4 * h * h * 128) * es + (T * (h // 2) ** 2 * 256 * es if pyramid_level else 0)
+  hbm('patch_corr', prof.get('patch_corr', z), grids + R * k0_pad * es,
+      note='unique bytes (grids once + rows out); the 7x7 gathers re-read the grids ~8x from L2')
+  hw = [(S // 2) ** 2, (S // 4) ** 2, (S // 8) ** 2]
+  mfma('conv3x3_c64', bbprof.get('conv3x3_c64', z), 2.0 * T * hw[0] * 64 * 64 * 9)
+  mfma('conv3x3_c128', bbprof.get('conv3x3_c128', z), 2.0 * T * hw[1] * 128 * 128 * 9)
+  mfma('conv3x3_c256', bbprof.get('conv3x3_c256', z), 2.0 * T * hw[2] * 256 * 256 * 9)
+  ms, n = bbprof.get('conv_other', z)
+  if n:   # the class mixes shapes: total flops of its launches over their total time
+    tot = 2.0 * T * (hw[1] * 64 * 128 * 9 + hw[2] * 128 * 256 * 9 + hw[0] * 64 * 64 + hw[1] * 64 * 128 + hw[2] * 128 * 256
+                     + hw[2] * 256 * 256)
+    ach = tot / (ms * 1e-3) / 1e12
+    out['conv_other'] = dict(total_us=round(ms * 1e3, 2), launches=n, flops=tot, bound='mfma', achieved=round(ach, 1),
+                             peak=peak_tf, unit='TFLOP/s', frac=round(ach / peak_tf, 4),
+                             note='3x3 stride-2 convolutions + 1x1 projections: all launches of a clip together')
+  hbm('stem', bbprof.get('stem', z), T * S * S * 3 * 4 + T * hw[0] * 64 * es, note='f32 frames in, activations out')
+  ms, n = bbprof.get('l2norm', z)
+  if n:
+    by = T * (hw[2] * 256 + hw[1] * 128) * (es + 4 + (2 if es == 2 else 0)) + (T * hw[2] * 256 * 2 if es == 2 else 0)
+    ach = by / (ms * 1e-3) / 1e9
+    out['l2norm'] = dict(total_us=round(ms * 1e3, 2), launches=n, bytes=int(by), bound='hbm', achieved=round(ach, 1),
+                         peak=peak_bw, unit='GB/s', frac=round(ach / peak_bw, 4),
+                         note='both maps: raw in, f32 grid + bf16 row-major (+ tile order for the low-res map) out')
+  return out
+
+
+def emulate_ranks(model, video, qpts, worlds, steps, es):
+  """What ONE rank of an N-rank sharded call (tapnet_amd.distributed.sharded_call) does, timed on this GPU: the backbone
+  on its T/N frames (the convolution path the WHOLE clip selects), the hot path on its Q/N queries against the full
+  gathered grids (the staged bf16 copies, as the sharded call hands them over).  The exchange is NOT run: it is priced
+  with SURVEY.md 8e's arithmetic (every peer's shard travels its own xGMI link, 153 GB/s, all links in parallel) plus a
+  fixed latency per collective.  PROJECTION, not a measurement of N GPUs."""
+  from tapnet_amd import distributed as tdist, tapir_model
+  B, T = video.shape[:2]
+  Q = qpts.shape[1]
+  S = video.shape[2]
+  LINK_GBPS, COLL_LAT_US = 153.0, 30.0
+
+  def timed(fn, warm):
+    for _ in range(warm):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+  # full grids with the staged copies, as gather_feature_grids returns them
+  model._staged = []
+  fg = model.get_feature_grids(video, _borrow=True)
+  staged, model._staged = list(model._staged), []
+  # (borrowed buffers belong to the backbone's captured graph, which the shard-shaped graphs captured below may evict:
+  # keep private copies, as the gathered grids of a real sharded call are)
+  own = {}
+  def mine(t):
+    if t is None:
+      return None
+    k = (t.data_ptr(), tuple(t.shape), t.dtype)
+    if k not in own:
+      own[k] = t.clone()
+    return own[k]
+  # (staged f32 entries are the backbone's [B*T,h,w,C] views of the grids' storage: same pointer, so the copies are keyed
+  # by pointer only for them)
+  by_ptr = {}
+  lows, his = [], []
+  for lo, hi in zip(fg.lowres, fg.hires):
+    lows.append(mine(lo)); his.append(mine(hi))
+    by_ptr[lo.data_ptr()] = lows[-1]; by_ptr[hi.data_ptr()] = his[-1]
+  if staged:
+    sfg = tapir_model.StagedFeatureGrids(tuple(lows), tuple(his), fg.resolutions)
+    sfg.staged = [(by_ptr[f.data_ptr()], mine(op), mine(tl)) for f, op, tl in staged]
+  else:
+    sfg = tapir_model.FeatureGrids(tuple(lows), tuple(his), fg.resolutions)
+  h = S // 8
+  wire = T * (h * h * 256 * (2 if staged else 1) + 4 * h * h * 128) * (es if staged else 4) * B
+  rows = []
+  for n in worlds:
+    t_loc, q_loc = -(-T // n), -(-Q // n)
+    v_loc = video[:, :t_loc]
+    bb_ms = timed(lambda: model.get_feature_grids(v_loc, _global_frames=T), 4)
+    q_sub = qpts[:, :q_loc]
+    hot_ms = timed(lambda: model(tdist.ShapeOnly(video.shape), False, q_sub, feature_grids=sfg), 3)
+    n_coll = (3 if staged else 2) + 3
+    ex_ms = (wire / n) / (LINK_GBPS * 1e9) * 1e3 + n_coll * COLL_LAT_US * 1e-3 if n > 1 else 0.0
+    per_rank = bb_ms + ex_ms + hot_ms
+    rows.append(dict(world=n, frames_per_rank=t_loc, queries_per_rank=q_loc, backbone_ms=round(bb_ms, 3),
+                     hot_path_ms=round(hot_ms, 3), exchange_ms_priced=round(ex_ms, 3), per_rank_ms=round(per_rank, 3),
+                     projected_points_per_s=round(B * Q / (per_rank * 1e-3), 1)))
+  return dict(what='PROJECTION of one clip sharded over N GPUs from one rank\'s measured share on THIS GPU + priced exchange; '
+                   'not a multi-GPU measurement',
+              exchange=dict(bytes_total=int(wire), link_GBps_assumed=LINK_GBPS, collective_latency_us_assumed=COLL_LAT_US,
+                            form='each peer\'s shard on its own xGMI link, links in parallel (SURVEY.md 8e)',
+                            wire=('bf16 row-major + tile-order copies (staged)' if staged else 'f32')),
+              ranks=rows)
+
+
 def main():
   args = parse()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -401,6 +586,13 @@ def main():
     if k != dom:
       prof[k] = v
   model.profile_enable(False)
+  bbprof = {}
+  if world == 1 and model._backbone is not None and model._backbone.engine is not None:
+    try:
+      bbprof = backbone_kernel_profile(model, video)
+    except Exception as e:   # a measurement aid: never fail the bench over it
+      bbprof = {}
+      print(f'bench: backbone kernel profile failed: {type(e).__name__}: {e}', file=sys.stderr)
   elapsed = max_over_ranks(elapsed)
   assert torch.isfinite(torch.as_tensor(out['tracks'])).all()
 
@@ -542,8 +734,12 @@ def main():
         hot_path_points_per_s=round(Q / hot_s, 2),
         point_frames_per_s=round(value * T, 1),
         roofline=roof, kernels=kernels)
+    if world == 1 and args.shard == 'clips':
+      line['roofline_all'] = roofline_all(prof, bbprof, T, Q, S, es, dtype, kw['pyramid_level'])
     if world == 1:
       line['box'] = box_probe(dev)
+    if world == 1 and args.emulate_rank is not None:
+      line['emulated_ranks'] = emulate_ranks(model, video, qpts, args.emulate_rank or [2, 4, 8], args.steps, es)
     if sharded is not None:
       line['one_clip_sharded'] = sharded
     if batch2 is not None:

@@ -207,7 +207,15 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 #define TAPIR_PROF_CV_GEMM 5    /* cost-volume einsum GEMM                                 */
 #define TAPIR_PROF_MIXER 6      /* track-resident fused PIPs mixer (mixer_fused_kernel): one launch
                                    per refinement iteration = input Linear + all blocks + output Linear */
-#define TAPIR_PROF_KINDS 7
+/* backbone kernel classes (conv_fused.hpp, backbone.hpp).  Events cannot be recorded inside a captured hipGraph: these
+ * are read from EAGER launches (tapnet_amd.backbone with TAPIR_BACKBONE_GRAPH=0; bench.py's untimed profiling pass). */
+#define TAPIR_PROF_STEM 7        /* 7x7 / stride-2 stem (stem_conv_kernel)                                  */
+#define TAPIR_PROF_CONV3_C64 8   /* 3x3 stride-1 block convolutions, 64 -> 64 channels (conv_fused_kernel)  */
+#define TAPIR_PROF_CONV3_C128 9  /* ... 128 -> 128                                                         */
+#define TAPIR_PROF_CONV3_C256 10 /* ... 256 -> 256                                                         */
+#define TAPIR_PROF_CONV_OTHER 11 /* the 3x3 stride-2 convolutions and the 1x1 projections                   */
+#define TAPIR_PROF_L2NORM 12     /* L2 normalisation + operand-type copies (l2norm_kernel)                  */
+#define TAPIR_PROF_KINDS 13
 /* on: bit mask of kernel classes (1 << TAPIR_PROF_*) to bracket with events; -1 = all, 0 = off. */
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
@@ -303,6 +311,17 @@ int tapir_conv_fused_nn(tapir_ctx* ctx, const void* x, const float* part_in, int
                         const float* gamma, const float* beta, float* ss, const void* wstream,
                         const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                         int cout, int ks, int stride, const tapir_next_norm* next, void* stream);
+/* conv_0 (3x3) AND proj_conv (1x1, same stride) of the first block of a group -- resnet.py:232-247: both read
+ * relu(norm(x)) -- in ONE launch: the projection is the centre tap of the tile the 3x3 convolution stages anyway, so
+ * the second staging of the input (and a launch of the dependency chain) disappears.  w3 [cout,cin,3,3], w1 [cout,cin,1,1]
+ * (torch layouts) -> one stream; supported: 64->64 and 256->256 at stride 1, 64->128 and 128->256 at stride 2
+ * (TAPIR_ERR_UNSUPPORTED otherwise).  y = the 3x3 result with its statistics (part_out / next as above), y_proj = the
+ * projection (the block's shortcut; no statistics).  Both outputs are bit-identical to the two separate launches. */
+int tapir_conv_pack_dual(tapir_ctx* ctx, const float* w3, const float* w1, int cout, int cin, int stride, void** wstream);
+int tapir_conv_fused_dual_nn(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                             const float* gamma, const float* beta, float* ss, const void* wstream_dual, void* y,
+                             void* y_proj, float* part_out, int N, int H, int W, int cin, int cout, int stride,
+                             const tapir_next_norm* next, void* stream);
 
 /* The stem of the ResNet (resnet.py:356-364: initial_conv, 7x7 / stride 2 / SAME, 3 -> 64 channels):
  * x = the f32 frames [N,H,W,3] as the model receives them (bf16 contexts: rounded to bf16 on load, as the

@@ -112,6 +112,10 @@ PROTOTYPES = {
     'tapir_conv_fused_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, POINTER(TapirNextNorm), c_void_p]),
+    'tapir_conv_pack_dual': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    'tapir_conv_fused_dual_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, POINTER(TapirNextNorm), c_void_p]),
     'tapir_debug_gemm': (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                  c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
@@ -129,7 +133,8 @@ PROTOTYPES = {
 }
 
 PROF_KINDS = {'gemm_up': 0, 'gemm_down': 1, 'mix': 2, 'patch_corr': 3, 'cv_heads': 4, 'cv_gemm': 5,
-              'mixer_fused': 6}
+              'mixer_fused': 6, 'stem': 7, 'conv3x3_c64': 8, 'conv3x3_c128': 9, 'conv3x3_c256': 10, 'conv_other': 11,
+              'l2norm': 12}
 
 
 def declare_prototypes(lib: ctypes.CDLL) -> ctypes.CDLL:

@@ -104,6 +104,10 @@ class Backbone:
     # the producing convolution merges the next InstanceNorm's (a, b) pairs itself (tapir_conv_fused_nn) instead of a
     # merge launch in front of the consuming convolution; '0' = the separate launches (the A/B switch)
     self.fuse_finalize = os.environ.get('TAPIR_FUSE_FINALIZE', '1') != '0'
+    # conv_0 and proj_conv of a group's first block in one launch (they read the same normalised tensor: one staging of
+    # it instead of two, 4 launches off a frame group's chain); '0' = two launches (the A/B switch)
+    self.fuse_proj = os.environ.get('TAPIR_FUSE_PROJ', '1') != '0'
+    self._wdual = {}
     self.extra_convs_mode = os.environ.get('TAPIR_EXTRA_CONVS', 'hip')   # 'hip' | 'torch' (MIOpen convolutions + torch glue: the A/B switch)
     self._bufs: Dict[tuple, torch.Tensor] = {}
     self.dtype = dtype
@@ -135,6 +139,23 @@ class Backbone:
                                  ctypes.byref(h))
         if rc == 0:       # (TAPIR_ERR_UNSUPPORTED: that convolution stays on MIOpen)
           self._wstream[k[:-len('.weight')]] = (h.value, a.shape[1], a.shape[0], a.shape[2])
+      # conv_0 + proj_conv of a group's first block as ONE launch (csrc/conv_fused.hpp DUAL): a combined weight stream
+      self._wdual: Dict[str, tuple] = {}
+      strides = (1, 2, 2, 1)
+      for g in range(4):
+        p = f'resnet_torch.block_groups.{g}.blocks.0.'
+        w3, w1 = weights.get(p + 'conv_0.weight'), weights.get(p + 'proj_conv.weight')
+        if w3 is None or w1 is None or (p + 'conv_0') not in self._wstream or (p + 'proj_conv') not in self._wstream:
+          continue
+        a3 = np.ascontiguousarray(w3.detach().cpu().numpy() if isinstance(w3, torch.Tensor) else w3, dtype=np.float32)
+        a1 = np.ascontiguousarray(w1.detach().cpu().numpy() if isinstance(w1, torch.Tensor) else w1, dtype=np.float32)
+        if a3.shape[2:] != (3, 3) or a1.shape[2:] != (1, 1) or a3.shape[:2] != a1.shape[:2]:
+          continue
+        h = ctypes.c_void_p()
+        rc = lib.tapir_conv_pack_dual(ctx, a3.ctypes.data_as(ctypes.c_void_p), a1.ctypes.data_as(ctypes.c_void_p),
+                                      a3.shape[0], a3.shape[1], strides[g], ctypes.byref(h))
+        if rc == 0:
+          self._wdual[p] = (h.value, a3.shape[1], a3.shape[0], strides[g])
       for k, v in weights.items():          # ExtraConvs kernels: packed on first use (the chunking depends on the map)
         if k.startswith('extra_convs.') and k.endswith(('conv.weight', 'conv_1.weight')):
           self._xhost[k[:-len('.weight')]] = np.ascontiguousarray(
@@ -163,7 +184,8 @@ class Backbone:
       s = ('HIP: 7x7 stem + every ResNet block convolution (3x3 / 1x1, stride 1 / 2) as fused implicit-GEMM MFMA '
            'kernels (InstanceNorm+ReLU in the operand load, residual add + next-norm statistics in the epilogue' +
            (', the next norm\'s (a, b) pairs merged by the last-arriving workgroup of each image), HIP L2-normalise kernel'
-            if self.fuse_finalize else '), HIP finalize / L2-normalise kernels'))
+            if self.fuse_finalize else '), HIP finalize / L2-normalise kernels') +
+           ('; conv_0 + proj_conv of a group\'s first block in one launch' if (self.fuse_proj and self._wdual) else ''))
     elif hip:
       s = 'HIP fused convolutions except ' + ', '.join(missing or ['(unpacked shapes)']) + ' (MIOpen) + HIP norm kernels'
     else:
@@ -354,6 +376,30 @@ class Backbone:
                             ssn.data_ptr(), arrive.data_ptr())
     return nn, ssn
 
+  def _fused_conv_dual(self, x, st: '_Stats', p, tag, stride, next_norm):
+    """conv_0 and proj_conv of block `p` (resnet.py:232-247: both read relu(bn_0(x))) in ONE launch
+    (tapir_conv_fused_dual_nn) -> (conv_0's raw output, the projected shortcut, conv_0's summaries)."""
+    lib, ctx = self.engine
+    n, h, w, _ = x.shape
+    ws, cin, cout, _ = self._wdual[p]
+    rows, tiles = self._plan(h, w, cin, cout, 3, stride)
+    ho, wo = -(-h // stride), -(-w // stride)
+    y = self._buf(('fy', tag + 'c', n, ho, wo, cout), (n, ho, wo, cout), self.dtype)
+    yp = self._buf(('fy', tag + 'p', n, ho, wo, cout), (n, ho, wo, cout), self.dtype)
+    part = self._buf(('fpart', tag + 'c', n, tiles, cout), (n, tiles, cout, 2), torch.float32)
+    norm_name = p + 'bn_0'
+    merged = st.ss is not None and st.ss_norm == norm_name     # the producer of x merged this norm's pairs already
+    ss = st.ss if merged else self._buf(('ss', n, cin), (n, cin, 2), torch.float32)
+    assert y.data_ptr() != x.data_ptr() and yp.data_ptr() != x.data_ptr()
+    import ctypes
+    nn, ssn = self._next_norm(next_norm, n, cout, tag + 'c')
+    self._check(lib.tapir_conv_fused_dual_nn(
+        ctx, x.data_ptr(), None if merged else st.part.data_ptr(), st.slabs, st.per_s,
+        self.w[norm_name + '.weight'].data_ptr(), self.w[norm_name + '.bias'].data_ptr(), ss.data_ptr(), ws,
+        y.data_ptr(), yp.data_ptr(), part.data_ptr(), n, h, w, cin, cout, stride,
+        ctypes.byref(nn) if nn is not None else None, self._stream()), 'tapir_conv_fused_dual_nn')
+    return y, yp, _Stats(part, tiles, rows * wo, ssn, next_norm if nn is not None else None)
+
   def _fused_conv(self, x, st: '_Stats', norm_name, conv_name, shortcut, tag, stride=1, stats=True, reuse_ss=False,
                   next_norm=None):
     """conv(relu(instance_norm(x))) (+ shortcut) and the summaries of the result, one launch
@@ -390,6 +436,10 @@ class Backbone:
     if not f0 or (use_projection and not fp):
       y, ysub = self._hip_norm_relu(x, st, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
     shortcut = x
+    if (use_projection and f0 and fp and self.fuse_proj and p in self._wdual and self._wdual[p][3] == stride
+        and self._fusable(p + 'conv_1', -(-h // stride), -(-w // stride), 1)):
+      y0, shortcut, st0 = self._fused_conv_dual(x, st, p, tag, stride, next_norm=p + 'bn_1')
+      return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}', next_norm=next_norm)
     if use_projection:
       if fp:
         shortcut, _ = self._fused_conv(x, st, p + 'bn_0', p + 'proj_conv', None, tag + 'p', stride, stats=False)

@@ -60,6 +60,7 @@ struct Conv3Args {
   long frags_per_cg;
   const void* shortcut;   // null, or [N, Ho, Wo, C_out] added before rounding (T)
   void* y;                // [N, Ho, Wo, C_out] (T)
+  void* y_proj;           // DUAL launches: [N, Ho, Wo, C_out] (T), the block's 1x1 projection of the same operand
   float* part;            // null, or [N, tiles, C_out, 2]: (mean, M2) of the stored values of each tile
   int N, H, W;            // input image
   int Ho, Wo;             // output image = ceil(H / stride), ceil(W / stride)
@@ -71,6 +72,10 @@ struct Conv3Args {
 };
 
 inline long conv3_frags_per_cg(int cin, int ks, int kstep) { return (long)ks * ks * (cin / kstep) * 4 + cv3_ring(ks); }
+// DUAL streams (conv_0 + proj_conv of a block in one launch): the projection's k-steps come first, padded with zero
+// fragments to whole ring turns (3 k-steps), so that the 3x3 loop behind them starts at ring phase 0
+inline int conv3_proj_ksteps(int cin, int kstep) { const int g = cv3_ring(3) / 4; return (cin / kstep + g - 1) / g * g; }
+inline long conv3_dual_frags_per_cg(int cin, int kstep) { return conv3_frags_per_cg(cin, 3, kstep) + 4L * conv3_proj_ksteps(cin, kstep); }
 
 // XLA SAME: total = max((ceil(n / s) - 1) * s + k - n, 0), low = total / 2
 inline int conv3_pad_lo(int n, int k, int s) {
@@ -83,6 +88,11 @@ inline bool conv3_supported(int cin, int cout, int ks, int stride) {
   if (!c_ok || (ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return false;
   if (stride == 1) return cin == cout && (ks == 3 || cin != 128);   // conv_0 / conv_1 / proj_conv of a stride-1 block
   return cout == 2 * cin;                                    // conv_0 / proj_conv of the first block of a stride-2 group
+}
+
+// blocks whose conv_0 (3x3) and proj_conv (1x1, same stride) run as ONE dual launch
+inline bool conv3_dual_supported(int cin, int cout, int stride) {
+  return stride == 1 ? (cin == cout && (cin == 64 || cin == 256)) : ((cin == 64 || cin == 128) && cout == 2 * cin);
 }
 
 // output rows per tile / tiles per image / waves per workgroup for an [H, W, C_in] input; false if the
@@ -298,7 +308,11 @@ __device__ __forceinline__ void cv3_epilogue(const f32x4 (&acc)[4][NT], const in
   fin_merge<COUT, WAVES * 64>(fin, part_img, n, tiles, per_s, HW, reinterpret_cast<float*>(scratch) + 16);
 }
 
-template <typename T, int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false>
+// DUAL (3x3 only): the launch also computes the block's 1x1 projection (resnet.py:232-240 proj_conv; same stride) of the
+// SAME normalised operand -- the centre tap of the staged tile -- into y_proj, in front of the 3x3 loop: one staging of
+// the input instead of two launches that each stage it (the weight stream carries the projection's fragments first).
+template <typename T, int CIN, int COUT, int KS, int STRIDE, int NT, int WAVES, bool HAS_SC, bool TRACE = false,
+          bool DUAL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int EPC = CvT<T>::EPC;
@@ -313,6 +327,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
   constexpr int RING = cv3_ring(KS), G = RING / 4; // k-steps per ring turn
   constexpr int UNR = KS == 3 ? 2 * G : G;         // k-steps per loop trip (even: the B buffers alternate)
   static_assert(UNR % 2 == 0 && UNR % G == 0 && (TAPS * KPT) % UNR == 0, "whole loop trips");
+  static_assert(!DUAL || (KS == 3 && !HAS_SC), "the projection is fused into conv_0 (3x3, no shortcut)");
+  constexpr int KP = DUAL ? (KPT + G - 1) / G * G : 0;   // k-steps of the projection, padded to whole ring turns (conv3_proj_ksteps)
   __shared__ uint4 s_tile[cv3_lds_bytes(WAVES) / 16];
 
   const int tid = threadIdx.x;
@@ -470,6 +486,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_fused_kernel(Conv3Args a) 
   lds_barrier();
   tick(1);
 
+  if constexpr (DUAL) {
+    // ---- proj_conv: KPT k-steps on the tap that reads input pixel (stride y, stride x) of output pixel (y, x) -- the
+    // tile's tap (pad_y, pad_x); the zero fragments that pad the stream to whole ring turns multiply whatever the
+    // clamped k-step reads.  Stores only: the shortcut it produces is not normalised (no statistics).
+    const int toffp = a.pad_y * PW + a.pad_x;
+    auto read_p = [&](int ks, uint4 (&fb)[NT]) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int P = Pc[i] + toffp;
+        fb[i] = *reinterpret_cast<const uint4*>(tile + P * CB + (((4 * ks + g) ^ (P & SWZ)) << 4));
+      }
+    };
+    uint4 fb0[NT], fb1[NT];
+    read_p(0, fb0);
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
+      uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
+      read_p(kk + 1 < KPT ? kk + 1 : KPT - 1, nxt);
+      sched_fence();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint4 fa = ring[(kk % G) * 4 + r];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) MfmaStep<T>::run(fa, cur[i], acc[r][i]);
+        ring[(kk % G) * 4 + r] = *wp;
+        wp += 64;
+        sched_fence();
+      }
+    }
+    cv3_epilogue<T, COUT, NT, WAVES>(acc, qpix, TP, reinterpret_cast<T*>(a.y_proj) + img * COUT, nullptr, tile);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
   // ---- TAPS x KPT k-steps; B fragments one k-step ahead, A fragments refilled after their last MFMA
   auto read_b = [&](int tap, int ks, uint4 (&fb)[NT]) {
     const int dy = (tap * 11) >> 5;                // tap / 3 for tap < 9
@@ -551,6 +604,17 @@ inline void launch_conv_fused(const Conv3Args& a, int cin, int cout, int ks, int
       else TAPIR_CV3_SC(CI_, CO_, K_, S_, 8, false);                                   \
     }                                                                                  \
   } while (0)
+  if (a.y_proj != nullptr) {   // conv_0 + proj_conv of a block (launch_conv_fused is only handed shapes conv3_dual_supported takes)
+#define TAPIR_CV3_DUAL(CI_, CO_, S_)                                                                                     \
+  do {                                                                                                                  \
+    if (a.waves == 4) TAPIR_LAUNCH((conv_fused_kernel<T, CI_, CO_, 3, S_, CV3_NT, 4, false, false, true>), grid, block, s, a); \
+    else TAPIR_LAUNCH((conv_fused_kernel<T, CI_, CO_, 3, S_, CV3_NT, 8, false, false, true>), grid, block, s, a);       \
+  } while (0)
+    if (stride == 1) { if (cin == 64) TAPIR_CV3_DUAL(64, 64, 1); else TAPIR_CV3_DUAL(256, 256, 1); }
+    else { if (cin == 64) TAPIR_CV3_DUAL(64, 128, 2); else TAPIR_CV3_DUAL(128, 256, 2); }
+#undef TAPIR_CV3_DUAL
+    return;
+  }
   if (stride == 1) {
     if (ks == 3) {
       if (cin == 64) TAPIR_CV3(64, 64, 3, 1);

@@ -81,6 +81,8 @@ struct tapir_ctx {
   bool warm_weights = true;                       // read the track-resident mixer's weight stream once in front of a level's first iteration
                                                   // (TAPIR_WARM_WEIGHTS=0: off, A/B; warm_stream_kernel below)
   DevBuf warm_sink;                               // 4 bytes the warming kernel never writes
+  int fused_min_tracks = 128;                     // fewest tracks the track-resident mixer is chosen for (TAPIR_FUSED_MIN_TRACKS; one
+                                                  // workgroup per track: below it the tiled / few-row GEMMs on all rows take over)
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
@@ -119,6 +121,10 @@ struct ProfScope {
   tapir_ctx* c; int kind; hipStream_t s; tapir_ctx::ProfEv ev; bool on, single;
   ProfScope(tapir_ctx* c_, int kind_, hipStream_t s_, bool single_ = true)
       : c(c_), kind(kind_), s(s_), on((c_->prof >> kind_) & 1u), single(single_) {
+    if (on) {   // events cannot be recorded while the stream is being captured into a hipGraph: the scope is a no-op there
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) on = false;
+    }
     if (!on) return;
     if (!c->prof_free.empty()) { ev = c->prof_free.back(); c->prof_free.pop_back(); }
     else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
@@ -783,7 +789,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
       // share the weight stream (MFMA-bound instead of L2-fill-bound); below ~128 tracks the tiled /
       // split-K GEMMs on all rows are faster than a mostly idle chip
-      if (fused) fused = N >= 128 && R >= 4096;
+      if (fused) fused = N >= c->fused_min_tracks && R >= (long)c->fused_min_tracks * 32;
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
       if (wide) fused = false;
     }
@@ -1156,6 +1162,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));
   *out = c;
   return TAPIR_OK;
 }
@@ -1487,10 +1494,11 @@ int tapir_l2_normalize_staged(tapir_ctx* c, const void* x, float* out, void* out
   const int PP = NORM_THREADS / (C / ept);
   L2Args la{x, out, pixels, C, out_op, out_tiled, cells_per_frame};
   const unsigned grid = (unsigned)std::min<long>((pixels + PP - 1) / PP, 8192);
+  ProfScope ps(c, TAPIR_PROF_L2NORM, (hipStream_t)stream);
   if (c->cfg.dtype == TAPIR_BF16)
-    hipLaunchKernelGGL((l2norm_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+    TAPIR_LAUNCH((l2norm_kernel<bf16_t>), dim3(grid), dim3(NORM_THREADS), (hipStream_t)stream, la);
   else
-    hipLaunchKernelGGL((l2norm_kernel<float>), dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, la);
+    TAPIR_LAUNCH((l2norm_kernel<float>), dim3(grid), dim3(NORM_THREADS), (hipStream_t)stream, la);
   return TAPIR_OK;
 }
 
@@ -1502,33 +1510,59 @@ int tapir_conv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int ks, int s
   return TAPIR_OK;
 }
 
+// Fragments of one convolution weight [cout, cin, ks, ks] for channel group cg, appended at q in the order the kernel's
+// k loop consumes them: for tap, k-step, row tile r: fragment row m = l & 15 holds output channel
+// cg*64 + 16 (m >> 2) + 4 r + (m & 3) -- so that lane group g = m >> 2 of the accumulator layout
+// (rows 4 g + e of tile r) owns the 16 consecutive channels 16 g + 4 r + e of its pixel --
+// input channels KSTEP kstep + EPC (l >> 4) + j (bf16: 32 per k-step, 8 per lane; f32: 16 / 4)
+static uint8_t* conv_pack_frags(uint8_t* q, const float* w, int cg, int cin, int ks, bool bf) {
+  const int kstep_n = bf ? 32 : 16, epc = bf ? 8 : 4, taps = ks * ks;
+  for (int tap = 0; tap < taps; ++tap)
+    for (int kstep = 0; kstep < cin / kstep_n; ++kstep)
+      for (int r = 0; r < 4; ++r, q += 1024)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < epc; ++j) {
+            const int m = l & 15;
+            const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = kstep_n * kstep + epc * (l >> 4) + j;
+            const float v = w[((size_t)co * cin + ci) * taps + tap];
+            if (bf) ((uint16_t*)q)[l * epc + j] = host_f2bf(v);
+            else ((float*)q)[l * epc + j] = v;
+          }
+  return q;
+}
+
 int tapir_conv_pack(tapir_ctx* c, const float* w, int cout, int cin, int ks, void** wstream) {
   if (!c || !w || !wstream) return TAPIR_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!conv3_supported(cin, cout, ks, 1) && !conv3_supported(cin, cout, ks, 2))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: channel counts / kernel size");
-  // stream of channel group cg: for tap, k-step, row tile r: fragment row m = l & 15 holds output channel
-  // cg*64 + 16 (m >> 2) + 4 r + (m & 3) -- so that lane group g = m >> 2 of the accumulator layout
-  // (rows 4 g + e of tile r) owns the 16 consecutive channels 16 g + 4 r + e of its pixel --
-  // input channels KSTEP kstep + EPC (l >> 4) + j (bf16: 32 per k-step, 8 per lane; f32: 16 / 4)
   const bool bf = c->cfg.dtype == TAPIR_BF16;
-  const int kstep_n = bf ? 32 : 16, epc = bf ? 8 : 4;
-  const long fpc = conv3_frags_per_cg(cin, ks, kstep_n);
-  const int taps = ks * ks;
+  const long fpc = conv3_frags_per_cg(cin, ks, bf ? 32 : 16);
+  std::vector<uint8_t> host((size_t)(cout / 64) * fpc * 1024, 0);
+  for (int cg = 0; cg < cout / 64; ++cg) conv_pack_frags(host.data() + (size_t)cg * fpc * 1024, w, cg, cin, ks, bf);
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size()));
+  c->conv_owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+  *wstream = d;
+  return TAPIR_OK;
+}
+
+// conv_0 (3x3) + proj_conv (1x1) of a block as ONE stream per channel group: the projection's k-steps first, padded with
+// zero fragments to whole ring turns (conv3_proj_ksteps), then the 3x3 fragments (conv_fused.hpp, DUAL)
+int tapir_conv_pack_dual(tapir_ctx* c, const float* w3, const float* w1, int cout, int cin, int stride, void** wstream) {
+  if (!c || !w3 || !w1 || !wstream) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!conv3_dual_supported(cin, cout, stride))
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused dual: channel counts / stride");
+  const bool bf = c->cfg.dtype == TAPIR_BF16;
+  const int kstep_n = bf ? 32 : 16;
+  const long fpc = conv3_dual_frags_per_cg(cin, kstep_n);
   std::vector<uint8_t> host((size_t)(cout / 64) * fpc * 1024, 0);
   for (int cg = 0; cg < cout / 64; ++cg) {
     uint8_t* q = host.data() + (size_t)cg * fpc * 1024;
-    for (int tap = 0; tap < taps; ++tap)
-      for (int kstep = 0; kstep < cin / kstep_n; ++kstep)
-        for (int r = 0; r < 4; ++r, q += 1024)
-          for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < epc; ++j) {
-              const int m = l & 15;
-              const int co = cg * 64 + 16 * (m >> 2) + 4 * r + (m & 3), ci = kstep_n * kstep + epc * (l >> 4) + j;
-              const float v = w[((size_t)co * cin + ci) * taps + tap];
-              if (bf) ((uint16_t*)q)[l * epc + j] = host_f2bf(v);
-              else ((float*)q)[l * epc + j] = v;
-            }
+    conv_pack_frags(q, w1, cg, cin, 1, bf);
+    conv_pack_frags(q + (size_t)conv3_proj_ksteps(cin, kstep_n) * 4 * 1024, w3, cg, cin, 3, bf);
   }
   void* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, host.size()));
@@ -1562,10 +1596,34 @@ static bool next_norm_ok(const tapir_next_norm* nx, const float* part_out) {
   return nx == nullptr || (nx->gamma && nx->beta && nx->ss && nx->arrive && part_out);
 }
 
+static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                           const float* gamma, const float* beta, float* ss, const void* wstream,
+                           const void* shortcut, void* y, void* y_proj, float* part_out, int N, int H, int W, int cin,
+                           int cout, int ks, int stride, const tapir_next_norm* next, void* stream);
+
 int tapir_conv_fused_nn(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
                         const float* gamma, const float* beta, float* ss, const void* wstream,
                         const void* shortcut, void* y, float* part_out, int N, int H, int W, int cin,
                         int cout, int ks, int stride, const tapir_next_norm* next, void* stream) {
+  return conv_fused_impl(c, x, part_in, slabs_in, per_s_in, gamma, beta, ss, wstream, shortcut, y, nullptr, part_out, N, H, W,
+                         cin, cout, ks, stride, next, stream);
+}
+
+int tapir_conv_fused_dual_nn(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                             const float* gamma, const float* beta, float* ss, const void* wstream_dual, void* y,
+                             void* y_proj, float* part_out, int N, int H, int W, int cin, int cout, int stride,
+                             const tapir_next_norm* next, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  if (!y_proj) return fail(c, TAPIR_ERR_INVALID, "conv_fused dual: y_proj");
+  if (!conv3_dual_supported(cin, cout, stride)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused dual: channel counts / stride");
+  return conv_fused_impl(c, x, part_in, slabs_in, per_s_in, gamma, beta, ss, wstream_dual, nullptr, y, y_proj, part_out, N, H, W,
+                         cin, cout, 3, stride, next, stream);
+}
+
+static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
+                           const float* gamma, const float* beta, float* ss, const void* wstream,
+                           const void* shortcut, void* y, void* y_proj, float* part_out, int N, int H, int W, int cin,
+                           int cout, int ks, int stride, const tapir_next_norm* next, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
   if (!next_norm_ok(next, part_out)) return fail(c, TAPIR_ERR_INVALID, "next norm: gamma, beta, ss, arrive and part_out are all needed");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1583,15 +1641,21 @@ int tapir_conv_fused_nn(tapir_ctx* c, const void* x, const float* part_in, int s
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   }
   Conv3Args ca{};
-  ca.x = x; ca.ss = ss; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = conv3_frags_per_cg(cin, ks, bf ? 32 : 16);
-  ca.shortcut = shortcut; ca.y = y; ca.part = part_out;
+  ca.x = x; ca.ss = ss; ca.wstream = (const uint4*)wstream;
+  ca.frags_per_cg = y_proj ? conv3_dual_frags_per_cg(cin, bf ? 32 : 16) : conv3_frags_per_cg(cin, ks, bf ? 32 : 16);
+  ca.shortcut = shortcut; ca.y = y; ca.y_proj = y_proj; ca.part = part_out;
   ca.N = N; ca.H = H; ca.W = W; ca.Ho = (H + stride - 1) / stride; ca.Wo = (W + stride - 1) / stride;
   ca.pad_y = conv3_pad_lo(H, ks, stride); ca.pad_x = conv3_pad_lo(W, ks, stride);
   ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
   ca.dbg_times = (long long*)c->dbg_times;
   if (next != nullptr) ca.fin = FinArgs{next->gamma, next->beta, next->ss, next->arrive, bf ? 8 : 4};
-  if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
-  else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+  {
+    const int kind = (ks == 3 && stride == 1) ? (cin == 64 ? TAPIR_PROF_CONV3_C64 : cin == 128 ? TAPIR_PROF_CONV3_C128 : TAPIR_PROF_CONV3_C256)
+                                              : TAPIR_PROF_CONV_OTHER;
+    ProfScope ps(c, kind, (hipStream_t)stream);
+    if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+    else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+  }
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }
@@ -1746,8 +1810,11 @@ int tapir_stem_conv_nn(tapir_ctx* c, const float* x, const void* wstream, void* 
   sa.pad_y = conv3_pad_lo(H, 7, 2); sa.pad_x = conv3_pad_lo(W, 7, 2);
   sa.TH = rows; sa.tiles = tiles;
   if (next != nullptr) sa.fin = FinArgs{next->gamma, next->beta, next->ss, next->arrive, bf ? 8 : 4};
-  if (bf) launch_stem_conv<bf16_t>(sa, (hipStream_t)stream);
-  else launch_stem_conv<float>(sa, (hipStream_t)stream);
+  {
+    ProfScope ps(c, TAPIR_PROF_STEM, (hipStream_t)stream);
+    if (bf) launch_stem_conv<bf16_t>(sa, (hipStream_t)stream);
+    else launch_stem_conv<float>(sa, (hipStream_t)stream);
+  }
   HIP_TRY(c, hipGetLastError());
   return TAPIR_OK;
 }

@@ -115,39 +115,79 @@ def gather_feature_grids(model, video_local, num_frames: int, group=None,
   from tapnet_amd import tapir_model
   B, t_local = video_local.shape[:2]
   lows, his = [], []
+  # (the convolution implementation is chosen from the WHOLE clip's frame count, so a small shard runs
+  # the kernels the unsharded call runs: bit-identical sharding, tapnet_amd/backbone.py)
+  # (an engine-internal keyword: any other object with the reference's get_feature_grids works unchanged)
+  # (ParameterizedTAPIR forwards get_feature_grids of the TAPIR it wraps: look through the wrapper, or a small
+  # shard of a wrapped model would pick the per-shard convolution path and lose bit-identical sharding)
+  inner = getattr(model, '_model', model)
+  ours = hasattr(inner, '_backbone')
+  # bf16 on the wire AND a bf16 engine whose backbone writes the hot path's operand copies (row-major bf16 + the
+  # cost-volume kernel's tile order): gather THOSE and hand them to the hot path -- no
+  # bf16 -> f32 -> bf16 round trip, no pool_cast_kernel pass over the gathered grids on every rank
+  stage = bool(ours and grid_dtype == torch.bfloat16 and getattr(inner, 'dtype', None) == 'bfloat16'
+               and inner._backbone is not None
+               and inner._backbone._stage_ok(torch.empty((0, 1, 1, tapir_model.LOWRES_DIM))))
+  staged_local = []
   if t_local > 0:
-    # (the convolution implementation is chosen from the WHOLE clip's frame count, so a small shard runs
-    # the kernels the unsharded call runs: bit-identical sharding, tapnet_amd/backbone.py)
-    # (an engine-internal keyword: any other object with the reference's get_feature_grids works unchanged)
-    # (ParameterizedTAPIR forwards get_feature_grids of the TAPIR it wraps: look through the wrapper, or a small
-    # shard of a wrapped model would pick the per-shard convolution path and lose bit-identical sharding)
-    inner = getattr(model, '_model', model)
-    kw = {'_global_frames': num_frames} if hasattr(inner, '_backbone') else {}
+    kw = {'_global_frames': num_frames} if ours else {}
+    if stage:
+      inner._staged = []
+      kw['_borrow'] = True
     fg = (inner if kw else model).get_feature_grids(video_local, **kw)
     res = tuple(fg.resolutions)
     levels = list(zip(fg.lowres, fg.hires))
+    if stage:
+      staged_local, inner._staged = list(inner._staged), []
+      n_runs = sum(1 for i, r in enumerate(res) if i == 0 or tuple(r) != tuple(res[i - 1]))
+      if len(staged_local) != 2 * n_runs:
+        # (whether the backbone stages depends on the engine's dtype, the channel count and TAPIR_STAGE_GRIDS only --
+        # identical on every rank; a silent per-rank fallback here would desynchronise the collectives below)
+        raise RuntimeError('gather_feature_grids: the backbone wrote %d staged copies for %d backbone passes'
+                           % (len(staged_local), n_runs))
   else:   # empty frame shard: contribute zero-length tensors of the right trailing shape
     res = tuple(_level_resolutions(model, video_local.shape[2:4]))
     dev = video_local.device
-    levels, seen = [], {}
-    for r in res:
-      if r not in seen:
-        seen[r] = (torch.zeros((B, 0, r[0] // 8, r[1] // 8, 256), device=dev),
-                   torch.zeros((B, 0, r[0] // 4, r[1] // 4, 128), device=dev))
-      levels.append(seen[r])
+    levels = []
+    for i, r in enumerate(res):
+      if i == 0 or tuple(r) != tuple(res[i - 1]):
+        cur = (torch.zeros((B, 0, r[0] // 8, r[1] // 8, 256), device=dev),
+               torch.zeros((B, 0, r[0] // 4, r[1] // 4, 128), device=dev))
+        if stage:
+          cells = -(-((r[0] // 8) * (r[1] // 8)) // 16) * 16
+          staged_local.append((cur[0], cur[0].to(torch.bfloat16),
+                               torch.zeros((0, cells * 256), dtype=torch.bfloat16, device=dev)))
+          staged_local.append((cur[1], cur[1].to(torch.bfloat16), None))
+      levels.append(cur)
   # one exchange per DISTINCT level: consecutive levels of one resolution share their arrays
   # (get_feature_grids, tapir_model.py:666,722); keyed by position so that every rank -- empty
   # shards included -- issues the same sequence of collectives
   prev_res, pair = None, None
+  staged_full, k = [], 0
   for (lo, hi), r in zip(levels, res):
     if pair is None or tuple(r) != prev_res:
       out = []
-      for g in (lo, hi):
-        wire = g if grid_dtype is None else g.to(grid_dtype)
-        full = all_gather_cat(wire, 1, num_frames, group)
-        out.append(full if grid_dtype is None else full.to(torch.float32))
+      if stage:
+        (_, lo16, lo_t), (_, hi16, _) = staged_local[k], staged_local[k + 1]
+        k += 2
+        lo16f = all_gather_cat(lo16.reshape(B, t_local, *lo.shape[2:]), 1, num_frames, group)
+        lotf = all_gather_cat(lo_t.reshape(B, t_local, -1), 1, num_frames, group)
+        hi16f = all_gather_cat(hi16.reshape(B, t_local, *hi.shape[2:]), 1, num_frames, group)
+        # the f32 grids the API hands out (query-feature sampling reads them; they key the staged copies)
+        out = [lo16f.to(torch.float32), hi16f.to(torch.float32)]
+        staged_full.append((out[0], lo16f, lotf))
+        staged_full.append((out[1], hi16f, None))
+      else:
+        for g in (lo, hi):
+          wire = g if grid_dtype is None else g.to(grid_dtype)
+          full = all_gather_cat(wire, 1, num_frames, group)
+          out.append(full if grid_dtype is None else full.to(torch.float32))
       pair, prev_res = tuple(out), tuple(r)
     lows.append(pair[0]); his.append(pair[1])
+  if stage:
+    fg = tapir_model.StagedFeatureGrids(tuple(lows), tuple(his), res)
+    fg.staged = staged_full
+    return fg
   return tapir_model.FeatureGrids(tuple(lows), tuple(his), res)
 
 

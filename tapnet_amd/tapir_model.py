@@ -52,6 +52,15 @@ class FeatureGrids(NamedTuple):
   resolutions: Sequence[Tuple[int, int]]
 
 
+class StagedFeatureGrids(FeatureGrids):
+  """FeatureGrids that also carry, for the bf16 engine, the hot path's operand-type copies of their grids:
+  ``staged`` = [(f32 grid, bf16 row-major copy, bf16 tile-order copy or None), ...].  TAPIR.__call__ registers them
+  with the engine for exactly that call (tapir_set_staged_grid) instead of re-casting the f32 grids.  Produced by
+  tapnet_amd.distributed.gather_feature_grids, which gathers the bf16 copies the backbone's L2-normalise kernel wrote
+  (they ARE the wire format); a plain FeatureGrids works everywhere this one does."""
+  staged: Any = None
+
+
 class QueryFeatures(NamedTuple):
   """tapir_model.py:273-293."""
   lowres: Sequence[Any]
@@ -545,6 +554,8 @@ class TAPIR:
     self._staged = []
     if feature_grids is None:
       feature_grids = self.get_feature_grids(video, is_training, refinement_resolutions, _borrow=True)
+    elif self.dtype == 'bfloat16' and getattr(feature_grids, 'staged', None):
+      self._staged = list(feature_grids.staged)   # (gathered operand copies: tapnet_amd.distributed)
     query_features = self.get_query_features(video, is_training, query_points, feature_grids,
                                              refinement_resolutions)
     fg = FeatureGrids(tuple(self._dev(x) for x in feature_grids.lowres),

@@ -275,6 +275,66 @@ def test_conv_fused_f32(cin, cout, ks, stride, H, W, shortcut):
   lib.tapir_destroy(ctx)
 
 
+@pytest.mark.parametrize('cin,cout,stride,H,W,dtype', [
+    (64, 64, 1, 6, 20, _ffi.TAPIR_BF16), (256, 256, 1, 5, 8, _ffi.TAPIR_BF16), (64, 128, 2, 8, 16, _ffi.TAPIR_BF16),
+    (64, 128, 2, 7, 10, _ffi.TAPIR_BF16), (128, 256, 2, 6, 9, _ffi.TAPIR_BF16), (64, 128, 2, 4, 140, _ffi.TAPIR_BF16),
+    (64, 64, 1, 5, 12, _ffi.TAPIR_F32), (128, 256, 2, 5, 6, _ffi.TAPIR_F32)])
+def test_conv0_and_projection_in_one_launch(cin, cout, stride, H, W, dtype):
+  """tapir_conv_fused_dual_nn: conv_0 (3x3) and proj_conv (1x1, same stride) of a group's first block
+  (resnet.py:232-247: both read relu(bn_0(x))) from ONE staging of the input -- the projection is the centre tap
+  (odd sizes at stride 2: tap (1, 1); even: tap (0, 0); mixed parities: (7, 10)).  Both outputs, the tile summaries
+  and the in-launch merged pairs of the next norm are BIT-identical to the two separate launches."""
+  lib = emu_lib()
+  ctx = _ctx(lib, dtype)
+  bf = dtype == _ffi.TAPIR_BF16
+  rng = np.random.default_rng(cin + cout + H + W)
+  N = 2
+  x = _r(rng.standard_normal((N, H, W, cin)) * 1.5 + 0.5)
+  w3 = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+  w1 = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+  g0, b0 = rng.uniform(0.5, 1.5, cin).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+  g1, b1 = rng.uniform(0.5, 1.5, cout).astype(np.float32), (rng.standard_normal(cout) * 0.3).astype(np.float32)
+  xb = to_bf16_bits(x) if bf else x.astype(np.float32)
+  part_in = np.zeros((N, 2, cin, 2), np.float32)
+  assert lib.tapir_inorm_stats(ctx, _p(xb), None, None, _p(part_in), N, H * W, cin, 2, None) == 0
+  ws3, ws1, wsd = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, _p(w3), cout, cin, 3, ctypes.byref(ws3)) == 0
+  assert lib.tapir_conv_pack(ctx, _p(w1), cout, cin, 1, ctypes.byref(ws1)) == 0
+  assert lib.tapir_conv_pack_dual(ctx, _p(w3), _p(w1), cout, cin, stride, ctypes.byref(wsd)) == 0
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, H, W, cin, cout, 3, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  ydt = np.uint16 if bf else np.float32
+  # the two separate launches (proj_conv merges bn_0's pairs, conv_0 re-uses them)
+  ss = np.zeros((N, cin, 2), np.float32)
+  yp_ref, y_ref = np.zeros((N, Ho, Wo, cout), ydt), np.zeros((N, Ho, Wo, cout), ydt)
+  part_ref = np.zeros((N, tiles.value, cout, 2), np.float32)
+  ssn_ref, arrive = np.full((N, cout, 2), np.nan, np.float32), np.zeros(N, np.int32)
+  nn = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn_ref.ctypes.data, arrive.ctypes.data)
+  assert lib.tapir_conv_fused_nn(ctx, _p(xb), _p(part_in), 2, 0, _p(g0), _p(b0), _p(ss), ws1, None, _p(yp_ref), None,
+                                 N, H, W, cin, cout, 1, stride, None, None) == 0, lib.tapir_last_error(ctx)
+  assert lib.tapir_conv_fused_nn(ctx, _p(xb), None, 2, 0, _p(g0), _p(b0), _p(ss), ws3, None, _p(y_ref), _p(part_ref),
+                                 N, H, W, cin, cout, 3, stride, ctypes.byref(nn), None) == 0, lib.tapir_last_error(ctx)
+  # one launch
+  ss2 = np.zeros((N, cin, 2), np.float32)
+  yp, y = np.zeros_like(yp_ref), np.zeros_like(y_ref)
+  part = np.zeros_like(part_ref)
+  ssn = np.full((N, cout, 2), np.nan, np.float32)
+  nn2 = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn.ctypes.data, arrive.ctypes.data)
+  rc = lib.tapir_conv_fused_dual_nn(ctx, _p(xb), _p(part_in), 2, 0, _p(g0), _p(b0), _p(ss2), wsd, _p(y), _p(yp), _p(part),
+                                    N, H, W, cin, cout, stride, ctypes.byref(nn2), None)
+  assert rc == 0, lib.tapir_last_error(ctx)
+  np.testing.assert_array_equal(ss2, ss)
+  np.testing.assert_array_equal(y, y_ref)
+  np.testing.assert_array_equal(yp, yp_ref)
+  np.testing.assert_array_equal(part, part_ref)
+  np.testing.assert_array_equal(ssn, ssn_ref)
+  assert (arrive == 0).all() and np.abs(from_bf16_bits(yp) if bf else yp).max() > 0.1
+  # shapes the dual form does not take
+  assert lib.tapir_conv_pack_dual(ctx, _p(w3), _p(w1), cout, cin, 3 - stride, ctypes.byref(wsd)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  lib.tapir_destroy(ctx)
+
+
 def test_conv_rejects_bad_shapes():
   lib = emu_lib()
   ctx = _ctx(lib, _ffi.TAPIR_F32)

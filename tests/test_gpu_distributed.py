@@ -23,7 +23,7 @@ torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, T, Q, q, wrap=False, shard_tol=None):
+def _worker(rank, world, port, T, Q, q, wrap=False, shard_tol=None, bf16=False):
   try:
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -37,13 +37,20 @@ def _worker(rank, world, port, T, Q, q, wrap=False, shard_tol=None):
     dist.init_process_group(backend, rank=rank, world_size=world)
     S = 64
     w = synthetic.make_weights(17, pyramid_level=1, extra_convs=False)
+    ekw = dict(dtype='bfloat16') if bf16 else {}
     if wrap:   # the reference's entry point: the whole-clip convolution choice has to look through the wrapper
-      m = tapir_model.ParameterizedTAPIR(w, None, dict(pyramid_level=1, initial_resolution=(S, S)), device=dev)
+      m = tapir_model.ParameterizedTAPIR(w, None, dict(pyramid_level=1, initial_resolution=(S, S)), device=dev, **ekw)
     else:
-      m = tapir_model.TAPIR(pyramid_level=1, weights=w, device=dev, initial_resolution=(S, S))
+      m = tapir_model.TAPIR(pyramid_level=1, weights=w, device=dev, initial_resolution=(S, S), **ekw)
     video = torch.as_tensor(synthetic.make_video(3, T, S, S), device=dev)
     qp = torch.as_tensor(synthetic.make_queries(4, Q, T, S, S), device=dev)
-    out, fg = tdist.sharded_call(m, video, qp, return_grids=True)
+    out, fg = tdist.sharded_call(m, video, qp, return_grids=True, grid_dtype=torch.bfloat16 if bf16 else None)
+    if bf16:
+      # bf16 engine, bf16 on the wire: the ranks gathered the backbone's own operand copies (row-major bf16 + tile order)
+      # and the hot path used them; the unsharded call below gets PLAIN FeatureGrids with the same f32 arrays and casts
+      # them itself (pool_cast_kernel) -- the same bits, or the gathered copies are not what the cast would produce
+      assert isinstance(fg, tapir_model.StagedFeatureGrids) and len(fg.staged) == 2, type(fg)   # one backbone pass (video = initial resolution): low + hi
+      fg = tapir_model.FeatureGrids(fg.lowres, fg.hires, fg.resolutions)
     same = m(tdist.ShapeOnly(video.shape), False, qp, feature_grids=fg)
     bitwise = all(torch.equal(out[k], same[k]) for k in ('tracks', 'occlusion', 'expected_dist'))
     if not bitwise and shard_tol is not None:
@@ -76,6 +83,27 @@ def test_sharded_call_two_ranks_real_model(T, Q):
     assert shapes_ok
     assert bitwise, f'rank {rank} ({backend}): sharded != unsharded on the same grids'
     assert med < 1e-3 and mx < 0.05, (med, mx)
+
+
+def test_sharded_call_gathers_the_staged_bf16_copies():
+  """bf16 engine with bf16 on the wire (what bench.py --gpus N runs): gather_feature_grids exchanges the bf16 row-major
+  and tile-order copies the L2-normalise kernel wrote and registers them with the hot path (no bf16 -> f32 -> bf16 round
+  trip, no pool_cast_kernel over the gathered grids).  Bitwise equal to the unsharded call that casts the same f32
+  arrays itself; ragged frame shards (9 = 5 + 4).  The comparison with a plain single-process call is loose here: the
+  wire rounds the grids the query features are sampled from to bf16."""
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, 9, 10, q, False, None, True)) for r in range(2)]
+  for p in procs: p.start()
+  res = [q.get(timeout=600) for _ in range(2)]
+  for p in procs: p.join(60)
+  for rank, backend, bitwise, shapes_ok, med, mx, err in res:
+    assert not err, err
+    assert shapes_ok
+    assert bitwise, f'rank {rank} ({backend}): staged gather != cast path on the same grids'
+    assert np.isfinite(med) and np.isfinite(mx)
 
 
 @pytest.mark.parametrize('T,Q,wrap,shard_tol', [(6, 3, False, None), (9, 10, True, None), (48, 13, False, 1e-3)])

@@ -1,0 +1,64 @@
+#!/bin/bash
+# Round-5 GPU calls, one part per gpurun call; everything lands in gpurun_out/$2 (default r05).
+#   tests  : pytest -m gpu (every test by name, durations), smoke
+#   bench  : headline bench line with roofline_all + emulated ranks, small-N mixer A/B, f32 / BootsTAPIR / online / config 5 lines
+#   prof   : rocprofv3 kernel stats of the bench command, PMC traffic + SQ passes
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+PART=${1:-tests}
+OUT=gpurun_out/${2:-r05}
+mkdir -p $OUT
+export TMPDIR=/tmp
+export OUT
+R=$PWD
+summ() { python - "$@" <<'PY'
+import json,sys,os
+for f in sys.argv[1:]:
+    try: d=json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e: print(f,'unreadable',e); continue
+    k={a: b.get('avg_us') for a, b in (d.get('kernels') or {}).items() if b.get('launches')}
+    print(os.path.basename(f), d.get('ms_per_step'), d.get('value'), 'hot', d.get('hot_path_ms'), 'bb', d.get('backbone_ms'), k)
+PY
+}
+if [ "$PART" == "tests" ]; then
+  timeout 2400 python -m pytest tests -m gpu -q -rA --durations=15 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed|^[0-9.]+s " > $OUT/pytest_gpu.log; tail -22 $OUT/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > $OUT/smoke.log 2>&1; tail -4 $OUT/smoke.log
+fi
+if [ "$PART" == "bench" ]; then
+  timeout 900 python bench.py --steps 20 --warmup 5 --emulate-rank 2 4 8 2>$OUT/bench.err | tail -1 > $OUT/bench_bf16.json; cut -c1-260 $OUT/bench_bf16.json; tail -3 $OUT/bench.err
+  python - <<'PY'
+import json,os
+d=json.loads(open(os.environ['OUT']+'/bench_bf16.json').read())
+print(json.dumps(d.get('roofline_all'),indent=0)[:3000])
+print(json.dumps(d.get('emulated_ranks'),indent=0)[:3000])
+print(d.get('cpu_baseline'))
+PY
+  KBENCH_MIXER_SHAPES=16x48,32x48,64x48,96x48,128x48 timeout 600 python tools/kbench.py --what mixer --reps 20 --out $OUT/kbench_mixer_small.json 2>&1 | grep '"kernel"' > $OUT/kbench_mixer_small.txt; cut -c1-220 $OUT/kbench_mixer_small.txt
+fi
+if [ "$PART" == "abproj" ]; then
+  # conv_0 + proj_conv in one launch (TAPIR_FUSE_PROJ) on / off, alternated on the same box
+  for rep in 1 2 3; do
+    TAPIR_FUSE_PROJ=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_off_$rep.json
+    TAPIR_FUSE_PROJ=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_on_$rep.json
+  done
+  summ $OUT/ab_proj_*.json | tee $OUT/ab_proj_summary.txt
+fi
+if [ "$PART" == "more" ]; then
+  timeout 600 python bench.py --steps 10 --warmup 3 --dtype fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp32.json; cut -c1-200 $OUT/bench_fp32.json
+  timeout 600 python bench.py --model bootstapir --queries 1024 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_boots_q1024.json; cut -c1-200 $OUT/bench_boots_q1024.json
+  timeout 300 python tools/bench_online.py --frames 60 2>&1 | grep workload > $OUT/online.json; cut -c1-230 $OUT/online.json
+  timeout 600 python tools/run_config5.py > $OUT/config5_1gpu.json 2>/dev/null; cat $OUT/config5_1gpu.json
+fi
+if [ "$PART" == "prof" ]; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/rocprof.err
+  cd $R; for f in $(find $OUT/prof -name '*.db'); do python profiles/summarize_rocpd.py $f > $OUT/kernel_stats.csv; done
+  find $OUT/prof -name '*.db' -size +20M -delete
+  head -24 $OUT/kernel_stats.csv | cut -c1-150
+  cd /tmp
+  TAPIR_BACKBONE_GRAPH=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-accuracy --no-cpu-baseline > /dev/null 2> $R/$OUT/pmc_fetch.err
+  TAPIR_BACKBONE_GRAPH=0 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/pmc_write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-accuracy --no-cpu-baseline > /dev/null 2> $R/$OUT/pmc_write.err
+  TAPIR_BACKBONE_GRAPH=0 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $R/$OUT/pmc_sq -o q -- python $R/bench.py --steps 3 --warmup 1 --no-accuracy --no-cpu-baseline > /dev/null 2> $R/$OUT/pmc_sq.err
+  cd $R; python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -40 $OUT/pmc_traffic.json
+  python tools/pmc_sq.py $OUT/pmc_sq > $OUT/pmc_sq.txt 2>$OUT/pmc_sq.err; head -30 $OUT/pmc_sq.txt
+  find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq -size +8M -delete
+fi
