@@ -141,7 +141,10 @@ template <typename TA, int QPW, int NTX, bool TRACE = false, int HEADS = 1, bool
           int PW = CVR_PW>
 __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES == 8) ? 2 : 4) void cv_rows_kernel(CvFusedArgs a) {
   constexpr int THREADS = WAVES * 64;
-  constexpr int PAD = PW == CVR_PW ? CVF_PAD : PW * PW;   // floats per cost map incl. the halo
+  // floats per cost map incl. the halo.  Rows of <= 32 cells: 34 x 34 = 1156 rounded up to 1163 = 11 (mod 32): the contraction
+  // stores cell 4 g + r of map c from lane (c, g) -- with a map stride of 4 (mod 32) the 16 active lanes of a half wave hit 8
+  // banks, with 11 they hit 16 (round 5; the wide form keeps 66 x 66: 6 maps need an even stride for the 16-byte zero fill)
+  constexpr int PAD = PW == CVR_PW ? CVF_PAD + 7 : PW * PW;
   constexpr bool ZSTREAM = PW > CVR_PW;                     // soft arg max: two passes over the in-place logits
   constexpr int NOT = NTX > 2 ? 2 : 1;                      // 16-pixel tiles of an occlusion-convolution output row
   static_assert(NTX * 16 <= PW - 2, "tiles per row");
@@ -355,6 +358,13 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int tx = 0; tx < NTX; ++tx) cbase[j][tx] = pw + min(16 * tx + c, w - 1) + 1 + off1[j];
+  // Ring rows are stored with the EVEN pixels first and the odd pixels behind them (round 5): the stride-2 window of the
+  // occlusion convolution reads pixels 2 c + k of 16 lanes c -- 64 bytes apart in a pixel-major row, 4 of 16 lanes per
+  // bank group (a 2-way conflict on every ds_read_b128, the worst ratio of the tree in profiles/r04_pmc_sq.txt); in this
+  // order they are 32 bytes apart, and with the two 16-byte halves of the odd pixels swapped the 16 lanes of a pass and
+  // the 32 lanes of a ring store hit 64 distinct banks.
+  constexpr int RHALF = PW / 2;
+  auto rpos = [](int pix) { return (pix >> 1) + (pix & 1) * RHALF; };
   // occlusion convolution: this lane's A row of tile ot = output pixel min(16 ot + c, ow - 1); ring column of tap column 0
   int ocol[NOT];
   int otap_row[5], otap_off[NOT][5];   // k-step s: ring row (relative to 2 oy - ply) and uint4 offset inside the row
@@ -365,11 +375,13 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
     for (int s5 = 0; s5 < 5; ++s5) {
       const int tap = min(2 * s5 + (g >> 1), 8);       // tap 9 has zero weights
       otap_row[s5] = tap / 3;
-      otap_off[ot][s5] = (ocol[ot] + tap % 3) * 2 + (g & 1);
+      const int pix = ocol[ot] + tap % 3;
+      otap_off[ot][s5] = rpos(pix) * 2 + ((g & 1) ^ (pix & 1));
     }
   }
   uint4* const ring = s_ring[wave];
   float* const vec = s_vec[wave];
+
   tick(0);
   lds_barrier();   // cost maps complete; the waves part here
   tick(1);
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
           const float* h1 = reinterpret_cast<const float*>(ring);
           for (int tap = 0; tap < 9; ++tap) {
             const int rr = (r0 + tap / 3) & (CVR_RING - 1);
-            const int pp = rr * PW + ocol[ot] + tap % 3;
+            const int pp = rr * PW + rpos(ocol[ot] + tap % 3);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               const int ci = 4 * jj + g;
@@ -489,16 +501,17 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES =
     };
     // hid1 -> ring: lane holds channels 4 g .. 4 g + 3 of pixel px
     auto ring_store = [&](int y, const f32x4 (&d1)[NTX]) {
-      const int rrow = (y & (CVR_RING - 1)) * PW + 1;
+      const int rrow = (y & (CVR_RING - 1)) * PW;
 #pragma unroll
       for (int tx = 0; tx < NTX; ++tx) {
         if (!ragw || pin[tx]) {
-          const int ridx = rrow + px[tx];
+          const int pix = 1 + px[tx];                  // (column 0 is the halo)
+          const int ridx = rrow + rpos(pix);
           if (BF) {
             uint2 o;
             o.x = pack_bf16x2(d1[tx][0], d1[tx][1]);
             o.y = pack_bf16x2(d1[tx][2], d1[tx][3]);
-            reinterpret_cast<uint2*>(ring)[ridx * 4 + g] = o;
+            reinterpret_cast<uint2*>(ring)[ridx * 4 + (g ^ ((pix & 1) << 1))] = o;   // odd pixels: 16-byte halves swapped
           } else {
             reinterpret_cast<f32x4*>(ring)[ridx * 4 + g] = d1[tx];
           }

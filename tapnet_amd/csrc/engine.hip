@@ -81,8 +81,12 @@ struct tapir_ctx {
   bool warm_weights = true;                       // read the track-resident mixer's weight stream once in front of a level's first iteration
                                                   // (TAPIR_WARM_WEIGHTS=0: off, A/B; warm_stream_kernel below)
   DevBuf warm_sink;                               // 4 bytes the warming kernel never writes
-  int fused_min_tracks = 128;                     // fewest tracks the track-resident mixer is chosen for (TAPIR_FUSED_MIN_TRACKS; one
-                                                  // workgroup per track: below it the tiled / few-row GEMMs on all rows take over)
+  int fused_min_tracks = 48;                      // fewest tracks the track-resident mixer is chosen for (TAPIR_FUSED_MIN_TRACKS).  One
+                                                  // workgroup per track runs 613-640 us per launch whatever the track count; the separate
+                                                  // launches take 580 / 588 / 652 / 780 / 858 us at 16 / 32 / 64 / 96 / 128 tracks x 48 frames
+                                                  // (profiles/r05_kbench_mixer_small.txt): the crossover is between 32 and 64 tracks
+  int cv_stream_out = 0;                          // cost-volume workspace GEMM: non-temporal stores of the f32 volume (TAPIR_CV_STREAM_OUT=1; measured
+                                                  // SLOWER at the production chunk: 101 against 84 us at M = 682, profiles/r05_kbench_contraction.txt -- off)
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
@@ -480,6 +484,7 @@ int cost_volume_gemm(tapir_ctx* c, const void* qf, const void* grid, int Q, int 
   const int n = T * hw, n4 = (n + 3) & ~3;
   g.C = vol; g.ldc = n4;
   g.M = Q; g.N = n4; g.K = C; g.w_rows = n == n4 ? 0 : n;
+  g.stream_out = c->cv_stream_out;
   { ProfScope ps(c, TAPIR_PROF_CV_GEMM, s); launch_gemm<TA, float, EPI_BIAS>(g, s); }
   return TAPIR_OK;
 }
@@ -787,8 +792,8 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
     if (c->mixer_mode == 0) {
       // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
-      // share the weight stream (MFMA-bound instead of L2-fill-bound); below ~128 tracks the tiled /
-      // split-K GEMMs on all rows are faster than a mostly idle chip
+      // share the weight stream (MFMA-bound instead of L2-fill-bound); below fused_min_tracks (48) the tiled /
+      // few-row GEMMs on all rows are faster than a mostly idle chip
       if (fused) fused = N >= c->fused_min_tracks && R >= (long)c->fused_min_tracks * 32;
       if (wide) wide = T > 48 ? N >= 64 : N > 256;
       if (wide) fused = false;
@@ -1162,6 +1167,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_CV_STREAM_OUT")) c->cv_stream_out = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));
   *out = c;
   return TAPIR_OK;
@@ -1832,6 +1838,7 @@ int tapir_debug_gemm(tapir_ctx* c, const void* A, long lda, const void* W, long 
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.dbg_times = (long long*)c->dbg_times;
+  g.stream_out = getenv("TAPIR_DEBUG_GEMM_NT") != nullptr;   // (tools/kbench.py: the cost-volume GEMM's non-temporal stores, A/B)
   hipStream_t s = (hipStream_t)stream;
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   const int mg = (tile >> 8) & 0xfff;   // test hook: cap the persistent grid (several tiles per workgroup)

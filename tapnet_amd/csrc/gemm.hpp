@@ -55,6 +55,7 @@ struct GemmArgs {
   int w_rows;                              // 0, or the rows W really has (< N: N is rounded up to a multiple of 4 for the
                                            // vector stores; the extra columns repeat W's last row and land in C's row padding)
   long long* dbg_times;                    // null, or [workgroups][16] wall-clock stamps (tools/kbench.py --what gemmtrace)
+  int stream_out;                          // f32 outputs nobody re-reads soon (the cost-volume workspace, 268 MB per launch): non-temporal stores
 };
 
 template <typename T> struct MfmaStep;
@@ -263,7 +264,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, TO* __restrict_
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int n = nb + TL::template col<PAIR>(j, fg);
-        if (INTERIOR || (m < g.M && n + 4 <= g.N)) Store4<TO>::run(row + n, v[j][0], v[j][1], v[j][2], v[j][3]);
+        if (INTERIOR || (m < g.M && n + 4 <= g.N)) {
+          if (sizeof(TO) == 4 && g.stream_out)
+            __builtin_nontemporal_store(f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}, reinterpret_cast<f32x4*>(row + n));
+          else
+            Store4<TO>::run(row + n, v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
       }
     }
   }
@@ -730,6 +736,10 @@ inline int gemm_pick_tile(int M, int N, int K) {
   // reads per MFMA; 1536 tiles at config-3 size = 6 per CU): mlp2_up 158 -> 144 us standalone
   if (M >= 24576 && N >= 2048) return GEMM_TILE_256x256;
   if (N >= 512 && (M >= 24576 || (N <= 1024 && K >= 1024 && M >= 6144))) return GEMM_TILE_256x128_W16_S3;
+  // short K, very wide N (the cost volume as a GEMM writing the f32 volume, K = 256, N = T h w): the launch is bound by what
+  // it stores; the largest tiles re-read the grid least (profiles/r05_kbench_contraction.txt: 84 us at M = 682 against
+  // 104 us with 128x128; 505 against 732 us at M = 4096)
+  if (K <= 256 && N >= 16384 && M >= 128) return M >= 2048 ? GEMM_TILE_256x256 : GEMM_TILE_256x128_W16_S3;
   if ((M % 192 == 0 || M >= 192 * 32) && N <= 1024) return GEMM_TILE_192x64;
   return GEMM_TILE_128x128_W8;
 }

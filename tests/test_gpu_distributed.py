@@ -47,10 +47,26 @@ def _worker(rank, world, port, T, Q, q, wrap=False, shard_tol=None, bf16=False):
     out, fg = tdist.sharded_call(m, video, qp, return_grids=True, grid_dtype=torch.bfloat16 if bf16 else None)
     if bf16:
       # bf16 engine, bf16 on the wire: the ranks gathered the backbone's own operand copies (row-major bf16 + tile order)
-      # and the hot path used them; the unsharded call below gets PLAIN FeatureGrids with the same f32 arrays and casts
-      # them itself (pool_cast_kernel) -- the same bits, or the gathered copies are not what the cast would produce
-      assert isinstance(fg, tapir_model.StagedFeatureGrids) and len(fg.staged) == 2, type(fg)   # one backbone pass (video = initial resolution): low + hi
-      fg = tapir_model.FeatureGrids(fg.lowres, fg.hires, fg.resolutions)
+      # and the hot path used them.  The SAME query shard against PLAIN FeatureGrids with the same f32 arrays makes the
+      # engine cast them itself (pool_cast_kernel): the same kernels on the same shapes, so the same bits -- or the
+      # gathered copies are not what the cast would produce.  (Shard vs whole batch is a different question: see below.)
+      assert isinstance(fg, tapir_model.StagedFeatureGrids) and len(fg.staged) == 2, type(fg)   # one backbone pass: low + hi
+      q0, q1 = tdist.shard_range(Q, world, rank)
+      plain = tapir_model.FeatureGrids(fg.lowres, fg.hires, fg.resolutions)
+      a = m(tdist.ShapeOnly(video.shape), False, qp[:, q0:q1], feature_grids=fg)
+      b = m(tdist.ShapeOnly(video.shape), False, qp[:, q0:q1], feature_grids=plain)
+      keys = ('tracks', 'occlusion', 'expected_dist')
+      d_stage = max(float((a[k] - b[k]).abs().max()) if q1 > q0 else 0.0 for k in keys)
+      d_shard = max(float((out[k][:, q0:q1] - a[k]).abs().max()) if q1 > q0 else 0.0 for k in keys)
+      whole = m(tdist.ShapeOnly(video.shape), False, qp, feature_grids=plain)
+      d_full = max(float((out[k] - whole[k]).abs().max()) for k in keys)
+      ok = d_stage == 0.0 and d_shard == 0.0
+      shapes_ok = tuple(out['tracks'].shape) == (1, Q, T, 2) and tuple(fg.lowres[0].shape[:2]) == (1, T)
+      q.put((rank, backend, ok, shapes_ok, d_full, d_full,
+             '' if ok else f'staged vs cast on the same shard: {d_stage:.3e}; gathered result vs this shard recomputed: '
+                           f'{d_shard:.3e}; sharded vs whole batch: {d_full:.3e}'))
+      dist.destroy_process_group()
+      return
     same = m(tdist.ShapeOnly(video.shape), False, qp, feature_grids=fg)
     bitwise = all(torch.equal(out[k], same[k]) for k in ('tracks', 'occlusion', 'expected_dist'))
     if not bitwise and shard_tol is not None:
@@ -103,7 +119,7 @@ def test_sharded_call_gathers_the_staged_bf16_copies():
     assert not err, err
     assert shapes_ok
     assert bitwise, f'rank {rank} ({backend}): staged gather != cast path on the same grids'
-    assert np.isfinite(med) and np.isfinite(mx)
+    assert np.isfinite(med) and med < 0.05, med   # sharded vs the whole batch on the same grids (few-row GEMM forms may differ)
 
 
 @pytest.mark.parametrize('T,Q,wrap,shard_tol', [(6, 3, False, None), (9, 10, True, None), (48, 13, False, 1e-3)])

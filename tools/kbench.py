@@ -76,7 +76,11 @@ def bench_gemm(model, reps, results, only_shapes=None, only_tiles=None):
             # the online model's per-frame shapes (256 points x 1 frame)
             ('up256', 256, 2048, 512, 1), ('down256', 256, 512, 2048, 2), ('costvol1', 256, 1024, 256, 0),
             # one rank's share of config 3 (1024 queries x 48 frames)
-            ('up4', 4 * R, 2048, 512, 1), ('down4', 4 * R, 512, 2048, 2)]
+            ('up4', 4 * R, 2048, 512, 1), ('down4', 4 * R, 512, 2048, 2),
+            # config 5's cost volume as a GEMM writing the f32 volume (row N3): one 256-MiB query chunk, and all 4096 queries
+            ('costvol5', 682, 98304, 256, 0), ('costvol5full', 4096, 98304, 256, 0)]
+  if not only_shapes:
+    shapes = [s_ for s_ in shapes if not s_[0].startswith('costvol5')]   # (1.6-GB outputs: only when asked for)
   g = torch.Generator(device='cpu').manual_seed(0)
   for name, M, N, K, epi in shapes:
     nset = 3
@@ -111,11 +115,40 @@ def bench_gemm(model, reps, results, only_shapes=None, only_tiles=None):
       tb = timeit_batch(run, reps)
       row = dict(kernel=f'gemm_{name}', tile=tname, M=M, N=N, K=K, dtype=model.dtype, max_err=round(err, 5),
                  **t, batch_us=tb, tflops=round(flops / (t['med_us'] * 1e-6) / 1e12, 1),
+                 out_GBps=round(M * N * (es if epi == 1 else 4) / (t['med_us'] * 1e-6) / 1e9, 1),
+                 frac_of_mfma_peak=round(flops / (t['med_us'] * 1e-6) / (2.5e15 if bf else 157.3e12), 4),
                  tflops_batch=round(flops / (tb * 1e-6) / 1e12, 1),
                  alg_GBps=round(bytes_alg / (t['med_us'] * 1e-6) / 1e9, 1))
       results.append(row)
       print(json.dumps(row), flush=True)
     del A, C
+
+
+def bench_fill(model, reps, results):
+  """Write-only and copy ceilings of this box (the rooflines of the kernels that are bound by what they store): torch
+  fill_ / copy_ of 256-MiB and 1.5-GiB f32 buffers, and the library GEMM at the cost-volume shape with a bf16 output."""
+  dev = model.device
+  for mb in (256, 1536):
+    a = torch.empty(mb << 18, device=dev)
+    b = torch.empty_like(a)
+    t = timeit(lambda i: a.fill_(1.0), max(5, reps // 2), warm=2)
+    row = dict(kernel='fill_f32', MiB=mb, **t, write_GBps=round(a.numel() * 4 / (t['med_us'] * 1e-6) / 1e9, 1))
+    results.append(row); print(json.dumps(row), flush=True)
+    t = timeit(lambda i: b.copy_(a), max(5, reps // 2), warm=2)
+    row = dict(kernel='copy_f32', MiB=mb, **t, write_GBps=round(a.numel() * 4 / (t['med_us'] * 1e-6) / 1e9, 1),
+               read_plus_write_GBps=round(2 * a.numel() * 4 / (t['med_us'] * 1e-6) / 1e9, 1))
+    results.append(row); print(json.dumps(row), flush=True)
+    del a, b
+  for M in (682, 4096):
+    A = torch.randn(M, 256, device=dev, dtype=torch.bfloat16)
+    W = torch.randn(98304, 256, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(M, 98304, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda i: torch.mm(A, W.t(), out=out), max(5, reps // 2), warm=2)
+    f = 2.0 * M * 98304 * 256
+    row = dict(kernel='library_gemm_bf16_out', M=M, N=98304, K=256, **t, tflops=round(f / (t['med_us'] * 1e-6) / 1e12, 1),
+               frac_of_mfma_peak=round(f / (t['med_us'] * 1e-6) / 2.5e15, 4),
+               out_GBps=round(M * 98304 * 2 / (t['med_us'] * 1e-6) / 1e9, 1))
+    results.append(row); print(json.dumps(row), flush=True)
 
 
 def bench_mix(model, reps, results):
@@ -659,6 +692,8 @@ def main():
                  set(int(t) for t in args.tiles.split(',')) if args.tiles else None)
     if 'mix' in what:
       bench_mix(model, args.reps, results)
+    if 'fill' in what:
+      bench_fill(model, args.reps, results)
     if 'gemmtrace' in what:
       trace_gemm(model)
     if 'gemmsteps' in what:

@@ -34,12 +34,49 @@ print(d.get('cpu_baseline'))
 PY
   KBENCH_MIXER_SHAPES=16x48,32x48,64x48,96x48,128x48 timeout 600 python tools/kbench.py --what mixer --reps 20 --out $OUT/kbench_mixer_small.json 2>&1 | grep '"kernel"' > $OUT/kbench_mixer_small.txt; cut -c1-220 $OUT/kbench_mixer_small.txt
 fi
+if [ "$PART" == "dbg" ]; then
+  timeout 600 python -m pytest tests/test_gpu_distributed.py -x -q -k "staged" 2>&1 | tail -60 > $OUT/dbg_staged.log; tail -40 $OUT/dbg_staged.log
+  timeout 900 python -m pytest tests/test_gpu_fuzz_parity.py -x -q --durations=3 2>&1 | tail -12 > $OUT/dbg_fuzz.log; cat $OUT/dbg_fuzz.log
+fi
+if [ "$PART" == "c3" ]; then
+  timeout 600 python -m pytest tests/test_gpu_distributed.py -x -q -k "staged" > $OUT/dbg_staged.log 2>&1; tail -25 $OUT/dbg_staged.log
+  timeout 900 python -m pytest tests/test_gpu_fuzz_parity.py -x -q --durations=3 > $OUT/dbg_fuzz.log 2>&1; tail -12 $OUT/dbg_fuzz.log
+  # previous commit's library (no ring swizzle, fused mixer from 128 tracks) against the working tree; then 3 streams
+  for rep in 1 2 3; do
+    TAPIR_HIP_LIB=$R/tools/bin/libtapir_hip_prev.so timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_cv_prev_$rep.json
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_cv_new_$rep.json
+    TAPIR_BACKBONE_STREAMS=3 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_cv_new_streams3_$rep.json
+  done
+  summ $OUT/ab_cv_*.json | tee $OUT/ab_cv_summary.txt
+  timeout 300 python tools/kbench.py --what fill --reps 20 --out $OUT/kbench_fill.json 2>&1 | grep '"kernel"' > $OUT/kbench_fill.txt; cut -c1-220 $OUT/kbench_fill.txt
+  timeout 400 python tools/kbench.py --what gemm --shapes costvol5,costvol5full --tiles 3,8,14,16 --reps 12 --out $OUT/kbench_cvgemm.json 2>&1 | grep '"kernel"' > $OUT/kbench_cvgemm.txt; cut -c1-330 $OUT/kbench_cvgemm.txt
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace -d $R/$OUT/prof_online -o online -- python $R/tools/bench_online.py --frames 30 --eager-only > $R/$OUT/online_eager.log 2> $R/$OUT/online_rocprof.err
+  cd $R; for f in $(find $OUT/prof_online -name '*.db'); do python tools/online_timeline.py $f 3 > $OUT/online_timeline.txt 2>&1; done
+  find $OUT/prof_online -name '*.db' -size +20M -delete
+  head -40 $OUT/online_timeline.txt
+fi
+if [ "$PART" == "c4" ]; then
+  timeout 300 python tools/probe_bf16_determinism.py > $OUT/probe_determinism.txt 2>&1; tail -12 $OUT/probe_determinism.txt
+  timeout 400 python tools/kbench.py --what gemm --shapes costvol5,costvol5full --tiles 14,16 --reps 12 --out $OUT/kbench_cvgemm_plain.json 2>&1 | grep '"kernel"' > $OUT/kbench_cvgemm_plain.txt; cut -c1-330 $OUT/kbench_cvgemm_plain.txt
+  TAPIR_DEBUG_GEMM_NT=1 timeout 400 python tools/kbench.py --what gemm --shapes costvol5,costvol5full --tiles 14,16 --reps 12 --out $OUT/kbench_cvgemm_nt.json 2>&1 | grep '"kernel"' > $OUT/kbench_cvgemm_nt.txt; cut -c1-330 $OUT/kbench_cvgemm_nt.txt
+  timeout 300 python tools/kbench.py --what contraction --reps 20 --out $OUT/kbench_contraction.json 2>&1 | grep '"kernel"' > $OUT/kbench_contraction.txt; cut -c1-400 $OUT/kbench_contraction.txt
+  TAPIR_CV_FORM=2 timeout 300 python tools/kbench.py --what contraction --reps 20 --out $OUT/kbench_contraction_form2.json 2>&1 | grep '"kernel"' > $OUT/kbench_contraction_form2.txt; cut -c1-400 $OUT/kbench_contraction_form2.txt
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16_stages.py -q -x 2>&1 | tail -5
+fi
+if [ "$PART" == "c5" ]; then
+  timeout 300 python tools/probe_sharded_staged.py > $OUT/probe_sharded.txt 2>&1; grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_sharded.txt | tail -20
+  TAPIR_HIP_LIB=$R/tools/bin/libtapir_hip_exp.so timeout 300 python tools/kbench.py --what convtrace --out $OUT/kbench_convtrace.json > $OUT/convtrace.txt 2>&1; grep -v amdgpu.ids $OUT/convtrace.txt | tail -30
+  timeout 300 python tools/kbench.py --what conv --reps 20 --out $OUT/kbench_conv.json 2>&1 | grep '"kernel"' > $OUT/kbench_conv.txt; cut -c1-300 $OUT/kbench_conv.txt
+fi
 if [ "$PART" == "abproj" ]; then
   # conv_0 + proj_conv in one launch (TAPIR_FUSE_PROJ) on / off, alternated on the same box
   for rep in 1 2 3; do
     TAPIR_FUSE_PROJ=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_off_$rep.json
     TAPIR_FUSE_PROJ=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_on_$rep.json
   done
+  TAPIR_BACKBONE_STREAMS=6 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_on_streams6.json
+  TAPIR_BACKBONE_STREAMS=3 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_on_streams3.json
   summ $OUT/ab_proj_*.json | tee $OUT/ab_proj_summary.txt
 fi
 if [ "$PART" == "more" ]; then
