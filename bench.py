@@ -697,7 +697,7 @@ def main():
     # the committed counter passes of THIS workload and names the artefact
     traffic, traffic_src = None, None
     if (args.model, T, Q, S, args.dtype, world) == ('tapir', 48, 256, 256, 'bf16', 1):
-      for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+      for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
           try:

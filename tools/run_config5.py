@@ -28,11 +28,16 @@ t0 = time.perf_counter()
 out = m(video, False, qp, feature_grids=fg)
 torch.cuda.synchronize()
 t_hot = time.perf_counter() - t0
+m.profile_enable(True); m.profile_read()
+m(video, False, qp, feature_grids=fg)
+torch.cuda.synchronize()
+prof = {k: (round(v[0], 3), v[1]) for k, v in m.profile_read().items() if v[1]}
+m.profile_enable(False)
 sub = m(video, False, qp[:, 1000:1256], feature_grids=fg)
 err = float((sub['tracks'] - out['tracks'][:, 1000:1256]).abs().max())
 print(json.dumps(dict(config='512x512x96, Q=4096, BootsTAPIR kwargs, 8 iterations, bf16, 1 GPU',
                       backbone_s=round(t_bb, 4), hot_path_s=round(t_hot, 4),
                       points_per_s=round(Q / (t_bb + t_hot), 1),
                       point_frames_per_s=round(Q * T / (t_bb + t_hot), 1),
-                      subset_max_abs_diff_px=err,
+                      subset_max_abs_diff_px=err, kernels_ms_launches=prof,
                       peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2**30, 2))))
