@@ -438,3 +438,29 @@ def test_next_norm_merged_in_the_launch_is_bit_identical(dtype, monkeypatch):
   torch.cuda.synchronize()
   arrive = [t for k, t in m._backbone._bufs.items() if 'arrive' in k]
   assert arrive and all(int(t.abs().sum()) == 0 for t in arrive)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,size', [('bfloat16', 256), ('float32', 128), ('bfloat16', 200)])
+def test_conv0_and_projection_in_one_launch_is_bit_identical(dtype, size, monkeypatch):
+  """conv_0 + proj_conv of a group's first block as ONE launch (tapir_conv_fused_dual_nn, conv_fused.hpp DUAL; resnet.py:
+  232-247) against the two launches (TAPIR_FUSE_PROJ=0): the feature grids of a whole backbone pass are bit-identical
+  -- eager and as a replayed hipGraph -- in both builds, also on a frame size whose rows do not fill the pixel tiles
+  (200 -> 100 -> 50 -> 25 cells).  (Odd inputs to the stride-2 pair -- centre tap (1, 1) -- cannot occur in the model:
+  resolutions are multiples of 8; the emulator test covers them.)"""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(6, 0, False)
+  video = synthetic.make_video(8, 12, size, size)
+  kw = dict(pyramid_level=0, weights=w, dtype=dtype, device='cuda:0', initial_resolution=(size, size))
+  monkeypatch.setenv('TAPIR_FUSE_PROJ', '0')
+  ref_model = tapir_model.TAPIR(**kw)
+  assert not ref_model._backbone.fuse_proj
+  fg0 = ref_model.get_feature_grids(video, False)
+  low0, hi0 = fg0.lowres[0].clone(), fg0.hires[0].clone()
+  monkeypatch.setenv('TAPIR_FUSE_PROJ', '1')
+  m = tapir_model.TAPIR(**kw)
+  assert m._backbone.fuse_proj and len(m._backbone._wdual) == 4      # groups 0-3: 64->64, 64->128 s2, 128->256 s2, 256->256
+  assert 'one launch' in m._backbone.describe(12)
+  for i in range(5):                                                   # (from the third call on: the captured graph, bf16)
+    fg = m.get_feature_grids(video, False)
+    assert torch.equal(fg.lowres[0], low0) and torch.equal(fg.hires[0], hi0), i
