@@ -171,7 +171,7 @@ def gather_feature_grids(model, video_local, num_frames: int, group=None,
         (_, lo16, lo_t), (_, hi16, _) = staged_local[k], staged_local[k + 1]
         k += 2
         lo16f = all_gather_cat(lo16.reshape(B, t_local, *lo.shape[2:]), 1, num_frames, group)
-        lotf = all_gather_cat(lo_t.reshape(B, t_local, -1), 1, num_frames, group)
+        lotf = all_gather_cat(lo_t.reshape(B, t_local, lo_t.shape[-1]), 1, num_frames, group)   # (explicit: t_local may be 0)
         hi16f = all_gather_cat(hi16.reshape(B, t_local, *hi.shape[2:]), 1, num_frames, group)
         # the f32 grids the API hands out (query-feature sampling reads them; they key the staged copies)
         out = [lo16f.to(torch.float32), hi16f.to(torch.float32)]

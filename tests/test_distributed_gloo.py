@@ -72,6 +72,84 @@ def test_sharded_call_world2(T, Q):
     assert shape == (1, Q, T, 2)
 
 
+class StagedStubModel(StubModel):
+  """Stand-in for a bf16 engine whose backbone writes the hot path's operand copies: the attributes
+  tapnet_amd.distributed.gather_feature_grids looks at (dtype, _backbone._stage_ok, _staged, the _borrow /
+  _global_frames keywords) and a __call__ that checks what it is handed."""
+  dtype = 'bfloat16'
+
+  class _BB:
+    def _stage_ok(self, low):
+      return low.shape[-1] == 256
+
+  def __init__(self):
+    self._backbone = self._BB()
+    self._staged = []
+    self.seen = None
+
+  def get_feature_grids(self, video, is_training=False, refinement_resolutions=None, _borrow=False, _global_frames=None):
+    fg = StubModel.get_feature_grids(self, video)
+    if _borrow:
+      b, t = video.shape[:2]
+      low, hi = fg.lowres[0].reshape(b * t, 2, 2, 256), fg.hires[0].reshape(b * t, 4, 4, 128)
+      low16 = low.to(torch.bfloat16)
+      # tile order of a frame of 4 cells (one tile of 16, 12 of them padding): [tile][32 chunks][16 cells][8]
+      tiled = torch.zeros(b * t, 1, 32, 16, 8, dtype=torch.bfloat16)
+      tiled[:, 0, :, :4, :] = low16.reshape(b * t, 4, 32, 8).permute(0, 2, 1, 3)
+      self._staged.append((low, low16, tiled.reshape(b * t, -1)))
+      self._staged.append((hi, hi.to(torch.bfloat16), None))
+    return fg
+
+  def __call__(self, video, is_training, query_points, feature_grids=None, **kw):
+    self.seen = feature_grids
+    return StubModel.__call__(self, video, is_training, query_points, feature_grids=feature_grids, **kw)
+
+
+def _staged_worker(rank, world, port, T, Q, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  g = torch.Generator().manual_seed(0)
+  video = torch.rand(1, T, 16, 16, 3, generator=g)
+  qp = torch.rand(1, Q, 3, generator=g) * 10
+  m = StagedStubModel()
+  out, fg = tdist.sharded_call(m, video, qp, grid_dtype=torch.bfloat16, return_grids=True)
+  ok = isinstance(fg, tapir_model.StagedFeatureGrids) and len(fg.staged) == 2
+  if ok:
+    (lo32, lo16, lot), (hi32, hi16, hit) = fg.staged
+    # what the whole clip gives on one rank
+    whole = StagedStubModel()
+    whole.get_feature_grids(video, _borrow=True)
+    (_, wlo16, wlot), (_, whi16, _) = whole._staged
+    ok = (hit is None and lo32.data_ptr() == fg.lowres[0].data_ptr() and hi32.data_ptr() == fg.hires[0].data_ptr()
+          and torch.equal(lo32, lo16.float()) and torch.equal(hi32, hi16.float())
+          and tuple(lo16.shape) == (1, T, 2, 2, 256) and tuple(lot.shape) == (1, T, 32 * 16 * 8)
+          and torch.equal(lo16.reshape(wlo16.shape), wlo16) and torch.equal(lot.reshape(wlot.shape), wlot)
+          and torch.equal(hi16.reshape(whi16.shape), whi16)
+          and (m.seen is None or m.seen is fg))          # the hot path got the staged grids (None: empty query shard)
+  ref = StubModel()(video, False, qp)
+  ok = ok and all(torch.allclose(out[k], ref[k], rtol=2e-2, atol=1e-2) for k in ref)
+  q.put((rank, bool(ok), tuple(out['tracks'].shape)))
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('T,Q', [(8, 6), (7, 5), (1, 1)])   # even, ragged and EMPTY frame / query shards
+def test_sharded_call_gathers_staged_copies_world2(T, Q):
+  """bf16 engine + bf16 wire: gather_feature_grids exchanges the operand copies the backbone wrote (row-major bf16, tile
+  order, hi-res bf16) and returns StagedFeatureGrids keyed by the f32 grids it hands out; every gathered tensor equals
+  what one rank computes for the whole clip (the collective logic with padded / empty shards of 2-D and 5-D tensors)."""
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, T, Q, q)) for r in range(2)]
+  for p in procs: p.start()
+  res = [q.get(timeout=120) for _ in range(2)]
+  for p in procs: p.join(30)
+  for rank, ok, shape in res:
+    assert ok, f'rank {rank}: staged gather mismatch'
+    assert shape == (1, Q, T, 2)
+
+
 def test_shard_range_covers():
   for n in (1, 5, 48, 256):
     for w in (1, 2, 3, 8):
