@@ -211,10 +211,10 @@ class Backbone:
       return
     lib, ctx = eng
     for h in ([v[0] for v in getattr(self, '_wstream', {}).values()] + [getattr(self, '_stem_ws', None)] +
-              list(getattr(self, '_xstream', {}).values())):
+              list(getattr(self, '_xstream', {}).values()) + [v[0] for v in getattr(self, '_wdual', {}).values()]):
       if h:
         lib.tapir_conv_free(ctx, h)
-    self._wstream, self._stem_ws, self._xstream = {}, None, {}
+    self._wstream, self._stem_ws, self._xstream, self._wdual = {}, None, {}, {}
 
   # -- ExtraConvs (BootsTAPIR): small 32x32 maps, PyTorch ops on the GPU -----
   def _conv(self, x, name, stride=1, bias=False):
