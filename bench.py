@@ -349,7 +349,7 @@ def backbone_kernel_profile(model, video):
       os.environ['TAPIR_BACKBONE_GRAPH'] = saved_env
 
 
-def roofline_all(prof, bbprof, T, Q, S, es, dtype, pyramid_level, blocks_per_group=(2, 2, 2, 2)):
+def roofline_all(prof, bbprof, T, Q, S, es, dtype, pyramid_level, dual=True):
   """One roofline entry per kernel class of a step: {avg_us, launches, flops | bytes, bound, achieved, peak, frac}.
   Algorithmic work per launch as DESIGN.md 3 states it (flops of the contractions only; unique bytes in + out for the
   memory-bound classes).  Hot-path classes: events of the two untimed profiling steps; backbone classes: eager
@@ -403,13 +403,17 @@ def roofline_all(prof, bbprof, T, Q, S, es, dtype, pyramid_level, blocks_per_gro
   hbm('patch_corr', prof.get('patch_corr', z), grids + R * k0_pad * es,
       note='unique bytes (grids once + rows out); the 7x7 gathers re-read the grids ~8x from L2')
   hw = [(S // 2) ** 2, (S // 4) ** 2, (S // 8) ** 2]
-  mfma('conv3x3_c64', bbprof.get('conv3x3_c64', z), 2.0 * T * hw[0] * 64 * 64 * 9)
+  # (dual launches: the 1x1 projection of a group's first block runs inside that block's conv_0 launch -- the stride-1
+  # ones are counted with the 3x3 classes (4 / 7 launches per clip at C = 64 / 256: the average launch carries a share),
+  # the stride-2 ones with conv_other; two launches otherwise)
+  p64, p256 = 2.0 * T * hw[0] * 64 * 64, 2.0 * T * hw[2] * 256 * 256
+  mfma('conv3x3_c64', bbprof.get('conv3x3_c64', z), 2.0 * T * hw[0] * 64 * 64 * 9 + (p64 / 4 if dual else 0.0))
   mfma('conv3x3_c128', bbprof.get('conv3x3_c128', z), 2.0 * T * hw[1] * 128 * 128 * 9)
-  mfma('conv3x3_c256', bbprof.get('conv3x3_c256', z), 2.0 * T * hw[2] * 256 * 256 * 9)
+  mfma('conv3x3_c256', bbprof.get('conv3x3_c256', z), 2.0 * T * hw[2] * 256 * 256 * 9 + (p256 / 7 if dual else 0.0))
   ms, n = bbprof.get('conv_other', z)
   if n:   # the class mixes shapes: total flops of its launches over their total time
-    tot = 2.0 * T * (hw[1] * 64 * 128 * 9 + hw[2] * 128 * 256 * 9 + hw[0] * 64 * 64 + hw[1] * 64 * 128 + hw[2] * 128 * 256
-                     + hw[2] * 256 * 256)
+    tot = 2.0 * T * (hw[1] * 64 * 128 * 9 + hw[2] * 128 * 256 * 9 + hw[1] * 64 * 128 + hw[2] * 128 * 256) + \
+        (0.0 if dual else p64 + p256)
     ach = tot / (ms * 1e-3) / 1e12
     out['conv_other'] = dict(total_us=round(ms * 1e3, 2), launches=n, flops=tot, bound='mfma', achieved=round(ach, 1),
                              peak=peak_tf, unit='TFLOP/s', frac=round(ach / peak_tf, 4),
@@ -735,7 +739,9 @@ def main():
         point_frames_per_s=round(value * T, 1),
         roofline=roof, kernels=kernels)
     if world == 1 and args.shard == 'clips':
-      line['roofline_all'] = roofline_all(prof, bbprof, T, Q, S, es, dtype, kw['pyramid_level'])
+      bb_ = model._backbone
+      line['roofline_all'] = roofline_all(prof, bbprof, T, Q, S, es, dtype, kw['pyramid_level'],
+                                          dual=bool(getattr(bb_, 'fuse_proj', False) and getattr(bb_, '_wdual', None)))
     if world == 1:
       line['box'] = box_probe(dev)
     if world == 1 and args.emulate_rank is not None:
