@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel SQ counters from one rocprofv3 --pmc pass (see tools/final_artefacts.sh / profiles/README.md):
+"""Per-kernel SQ counters from one rocprofv3 --pmc pass (see tools/r05.sh prof / profiles/README.md):
 wave cycles, wait / active shares, MFMA busy cycles, LDS bank conflicts, averaged per launch.
 
     python tools/pmc_sq.py gpurun_out/<dir>/pmc_sq > profiles/rNN_pmc_sq.txt
