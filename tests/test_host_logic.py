@@ -200,3 +200,35 @@ def test_resize_to_the_same_size_is_the_identity():
     out = resize_bilinear(t, (24, 40), antialias=aa)
     assert out.shape == t.shape and torch.equal(out, t)
   np.testing.assert_array_equal(jax_resize.resize_bilinear(v, (24, 40)), v)
+
+
+def test_bench_roofline_all_prices_every_kernel_class():
+  """bench.py's `roofline_all` (round 5): one entry per kernel class with the algorithmic work DESIGN.md 3 states --
+  the mixer's three GEMM families, the cost volume's composite floor (operand-type einsum + hid3, exact-f32 hid1 / hid2),
+  unique bytes for the memory-bound classes, and the 1x1 projections booked where the dual launches run them."""
+  import importlib.util
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  T, Q, S = 48, 256, 256
+  prof = {'mixer_fused': (4 * 0.700, 4), 'cv_heads': (0.172, 1), 'patch_corr': (4 * 0.035, 4)}
+  bbprof = {'stem': (0.077, 1), 'conv3x3_c64': (4 * 0.112, 4), 'conv3x3_c128': (3 * 0.088, 3), 'conv3x3_c256': (7 * 0.086, 7),
+            'conv_other': (0.196, 2), 'l2norm': (0.043, 2)}
+  ra = bench.roofline_all(prof, bbprof, T, Q, S, 2, 'bfloat16', 0, dual=True)
+  assert set(ra) == {'mixer_fused', 'cv_rows', 'patch_corr', 'conv3x3_c64', 'conv3x3_c128', 'conv3x3_c256', 'conv_other',
+                     'stem', 'l2norm'}
+  R = Q * T
+  assert ra['mixer_fused']['flops'] == 2.0 * R * (486 * 512 + 12 * 2 * 512 * 2048 + 512 * 388)      # 629.5 GFLOP
+  np.testing.assert_allclose(ra['mixer_fused']['frac'], 629.47e9 / 700e-6 / 2.5e15, rtol=1e-3)
+  cells = R * 32 * 32
+  np.testing.assert_allclose(ra['cv_rows']['flops'], 2.0 * cells * 256 + 2.0 * 144 * 32 * cells / 4 + 2.0 * 2 * 144 * cells)
+  np.testing.assert_allclose(ra['cv_rows']['composite_floor_us'], 60.2, atol=0.1)                      # 35.4 GF bf16 + 7.2 GF f32
+  base = 2.0 * T * 128 * 128 * 64 * 64 * 9
+  proj = 2.0 * T * 128 * 128 * 64 * 64
+  assert ra['conv3x3_c64']['flops'] == base + proj / 4 and ra['conv3x3_c128']['flops'] == 2.0 * T * 64 * 64 * 128 * 128 * 9
+  two = bench.roofline_all(prof, bbprof, T, Q, S, 2, 'bfloat16', 0, dual=False)
+  assert two['conv3x3_c64']['flops'] == base and two['conv_other']['flops'] > ra['conv_other']['flops']
+  for k, v in ra.items():
+    assert v['bound'] in ('mfma', 'hbm') and 0 < v['frac'] < 1.2 and v['peak'] in (2500.0, 8000.0), (k, v)
+  assert ra['stem']['bytes'] == T * S * S * 3 * 4 + T * 128 * 128 * 64 * 2
