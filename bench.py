@@ -616,11 +616,14 @@ def main():
     barrier()
     tsh = max_over_ranks(time.perf_counter() - ts)
     wire = 2 if grid_dtype is not None else 4
+    # bf16 engine: the ranks gather the backbone's operand copies (low-res row-major AND tile order, hi-res row-major)
+    lowres_copies = 2 if grid_dtype is not None else 1
     sharded = dict(ms_per_step=round(tsh / args.steps * 1e3, 3),
                    value=round(Q / (tsh / args.steps), 2), unit='points/s', scaling='strong',
-                   exchange=f'all_gather_into_tensor of lowres+hires grids along T ({"bf16" if wire == 2 else "f32"} '
-                            f'on the wire), outputs gathered',
-                   exchange_bytes=int(T * ((S // 8) ** 2 * 256 + (S // 4) ** 2 * 128) * wire))
+                   exchange=(f'all_gather_into_tensor along T of the bf16 operand copies the backbone wrote (low-res row-major + '
+                             f'tile order, hi-res row-major: bf16 on the wire, no re-cast on the ranks), outputs gathered'
+                             if wire == 2 else 'all_gather_into_tensor of lowres+hires grids along T (f32 on the wire), outputs gathered'),
+                   exchange_bytes=int(T * (lowres_copies * (S // 8) ** 2 * 256 + (S // 4) ** 2 * 128) * wire))
 
   # hot path only (feature grids precomputed): R8 + R1
   fg = model.get_feature_grids(video)

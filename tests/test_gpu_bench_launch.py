@@ -38,3 +38,23 @@ def test_bench_gpus_2_self_launch():
     assert line['config']['backend'] == 'nccl' and line['rccl_ranks'] == 2
   else:
     assert line['config']['backend'] == 'gloo' and line['rccl_ranks'] == 0
+
+
+def test_bench_line_carries_per_class_rooflines_and_the_rank_projection():
+  """One GPU: the line of `bench.py --emulate-rank 2` has `roofline_all` (one roofline entry per kernel class, backbone
+  classes from the eager profiling pass) and `emulated_ranks` (one rank's measured share + the priced exchange,
+  labelled a projection), next to the contract's fields."""
+  line = _run(['--steps', '3', '--warmup', '1', '--no-accuracy', '--no-cpu-baseline', '--emulate-rank', '2'])
+  assert line['n_gpus'] == 1 and line['dtype'] == 'bf16' and line['value'] > 0 and line['vs_baseline'] is None
+  ra = line['roofline_all']
+  assert {'mixer_fused', 'cv_rows', 'patch_corr', 'conv3x3_c64', 'conv3x3_c128', 'conv3x3_c256', 'conv_other', 'stem',
+          'l2norm'} <= set(ra)
+  for k, v in ra.items():
+    assert v['bound'] in ('mfma', 'hbm') and 0 < v['frac'] < 1.2 and v['launches'] > 0, (k, v)
+  assert ra['conv3x3_c256']['launches'] == 7 and ra['conv_other']['launches'] == 2      # dual launches: 19 per frame group
+  er = line['emulated_ranks']
+  assert 'PROJECTION' in er['what'] and er['exchange']['wire'].startswith('bf16') and len(er['ranks']) == 1
+  r = er['ranks'][0]
+  assert r['world'] == 2 and r['frames_per_rank'] == 24 and r['queries_per_rank'] == 128
+  assert abs(r['per_rank_ms'] - (r['backbone_ms'] + r['hot_path_ms'] + r['exchange_ms_priced'])) < 2e-3
+  assert 'roofline' in line and line['roofline']['frac'] > 0.2 and 'box' in line
