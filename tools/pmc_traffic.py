@@ -65,6 +65,22 @@ def per_kernel(d, counter):
   return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+BACKBONE = ('conv_fused_kernel', 'stem_conv_kernel', 'l2norm_kernel', 'inorm_', 'xconv_kernel', 'ln_affine_kernel')
+
+
+def backbone_totals(d, counter):
+  """sum of `counter` over every backbone dispatch of the run, and the number of clips (stem launches / 4 frame groups)"""
+  tot, stems, by = 0.0, 0, collections.defaultdict(float)
+  for name, cname, value in rows_of(d):
+    if cname != counter or not any(b in name for b in BACKBONE):
+      continue
+    tot += value
+    stems += 'stem_conv_kernel' in name
+    fam = 'dual conv_0 + proj_conv' if ', false, false, true>' in name else next(b for b in BACKBONE if b in name)
+    by[fam] += value
+  return tot, stems, dict(by)
+
+
 def main():
   fetch, nf = per_kernel(sys.argv[1], 'FETCH_SIZE')
   write, nw = per_kernel(sys.argv[2], 'WRITE_SIZE')
@@ -79,6 +95,18 @@ def main():
     out['kernels'][k] = dict(fetch_bytes=round(fb), write_bytes=round(wb), hbm_bytes=round(fb + wb),
                              fetch_kib_raw=round(fetch[k], 1), write_kib_raw=round(write.get(k, 0.0), 1),
                              launches=nf[k])
+  # the backbone of ONE clip (all of its launches; graph off: four frame groups of 12 frames -> clips = stem launches / 4)
+  ft, fs, fby = backbone_totals(sys.argv[1], 'FETCH_SIZE')
+  wt, ws, wby = backbone_totals(sys.argv[2], 'WRITE_SIZE')
+  if fs and ws:
+    groups = int(os.environ.get('PMC_FRAME_GROUPS', '4'))
+    cf, cw = fs / groups, ws / groups
+    out['backbone_per_clip'] = dict(
+        fetch_bytes=round(ft * 1024 * 2 / cf), write_bytes=round(wt * 1024 / cw),
+        hbm_bytes=round(ft * 1024 * 2 / cf + wt * 1024 / cw), clips_fetch_pass=cf, clips_write_pass=cw,
+        by_family_fetch_MB={k: round(v * 1024 * 2 / cf / 1e6, 1) for k, v in fby.items()},
+        by_family_write_MB={k: round(v * 1024 / cw / 1e6, 1) for k, v in wby.items()},
+        note='every backbone dispatch of the run summed (FETCH_SIZE x 2, WRITE_SIZE), divided by the clips of that pass')
   if 'gemm_up' in out['kernels']:
     out['gemm_up_hbm_bytes_per_launch'] = out['kernels']['gemm_up']['hbm_bytes']
   json.dump(out, sys.stdout, indent=1)

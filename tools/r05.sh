@@ -69,6 +69,17 @@ if [ "$PART" == "c5" ]; then
   TAPIR_HIP_LIB=$R/tools/bin/libtapir_hip_exp.so timeout 300 python tools/kbench.py --what convtrace --out $OUT/kbench_convtrace.json > $OUT/convtrace.txt 2>&1; grep -v amdgpu.ids $OUT/convtrace.txt | tail -30
   timeout 300 python tools/kbench.py --what conv --reps 20 --out $OUT/kbench_conv.json 2>&1 | grep '"kernel"' > $OUT/kbench_conv.txt; cut -c1-300 $OUT/kbench_conv.txt
 fi
+if [ "$PART" == "pmcbb" ]; then
+  # backbone HBM traffic per clip, one launch and two launches for conv_0 + proj_conv (separate --pmc passes)
+  for fp in 1 0; do
+    cd /tmp
+    TAPIR_FUSE_PROJ=$fp TAPIR_BACKBONE_GRAPH=0 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch_$fp -o f -- python $R/bench.py --steps 3 --warmup 1 --no-accuracy --no-cpu-baseline > /dev/null 2> $R/$OUT/pmc_fetch_$fp.err
+    TAPIR_FUSE_PROJ=$fp TAPIR_BACKBONE_GRAPH=0 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/pmc_write_$fp -o w -- python $R/bench.py --steps 3 --warmup 1 --no-accuracy --no-cpu-baseline > /dev/null 2> $R/$OUT/pmc_write_$fp.err
+    cd $R; python tools/pmc_traffic.py $OUT/pmc_fetch_$fp $OUT/pmc_write_$fp > $OUT/pmc_traffic_fuse_proj_$fp.json 2> $OUT/pmc_traffic_$fp.err
+    python -c "import json; d=json.load(open('$OUT/pmc_traffic_fuse_proj_$fp.json')); print('FUSE_PROJ=$fp', json.dumps(d.get('backbone_per_clip')))"
+    find $OUT/pmc_fetch_$fp $OUT/pmc_write_$fp -size +8M -delete
+  done
+fi
 if [ "$PART" == "abproj" ]; then
   # conv_0 + proj_conv in one launch (TAPIR_FUSE_PROJ) on / off, alternated on the same box
   for rep in 1 2 3; do
