@@ -341,7 +341,9 @@ int tapir_stem_conv_nn(tapir_ctx* ctx, const float* x, const void* wstream, void
  * tapir_layernorm_affine: hk.LayerNorm(axis=-1, create_scale=True, create_offset=True) per pixel (:176),
  *   eps 1e-5; C / (8 bf16 | 4 f32) a power of two <= 64.
  * tapir_xconv_plan : output rows per workgroup tile, tiles per image and input channels per LDS chunk for
- *   an [H, W, cin] map (W <= 64; cin, cout multiples of 256), TAPIR_ERR_UNSUPPORTED otherwise.
+ *   an [H, W, cin] map (W <= 94: a one-row tile of the wide form has to fit LDS; cin, cout multiples of 256),
+ *   TAPIR_ERR_UNSUPPORTED otherwise.  Two forms of the kernel: 64 or 128 pixels per workgroup (the latter wherever
+ *   it gives a tile more rows; TAPIR_XCONV_NT=4|8 in the environment of tapir_create forces one, for A/B runs).
  * tapir_xconv_pack : w = the reference's [cout, cin, 3, 3] f32 kernel (torch OIHW, host memory) -> packed
  *   fragment streams for chunks of `cch` input channels (the value tapir_xconv_plan returned for the map it will
  *   be used on: tapir_xconv returns TAPIR_ERR_INVALID for a pack built with another chunk width); owned like

@@ -88,6 +88,7 @@ struct tapir_ctx {
   int cv_stream_out = 0;                          // cost-volume workspace GEMM: non-temporal stores of the f32 volume (TAPIR_CV_STREAM_OUT=1; measured
                                                   // SLOWER at the production chunk: 101 against 84 us at M = 682, profiles/r05_kbench_contraction.txt -- off)
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
+  int xconv_nt = 0;                               // ExtraConvs convolutions: 0 = xconv_plan chooses, 4 / 8 = pixel tiles per wave forced (TAPIR_XCONV_NT: tests, A/B)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
   // workspaces
@@ -1169,6 +1170,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_STREAM_OUT")) c->cv_stream_out = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));
+  if (const char* e = getenv("TAPIR_XCONV_NT")) { const int v = atoi(e); c->xconv_nt = (v == XC_NT || v == XC_NT_WIDE) ? v : 0; }
   *out = c;
   return TAPIR_OK;
 }
@@ -1686,7 +1688,7 @@ int tapir_layernorm_affine(tapir_ctx* c, const void* x, const float* gamma, cons
 
 int tapir_xconv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch) {
   if (!c || !rows || !tiles || !cch) return TAPIR_ERR_INVALID;
-  if (!xconv_plan(H, W, cin, cout, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles, cch))
+  if (!xconv_plan(H, W, cin, cout, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles, cch, nullptr, c->xconv_nt))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
   return TAPIR_OK;
 }
@@ -1736,8 +1738,8 @@ int tapir_xconv(tapir_ctx* c, const void* x, const void* wstream, const float* b
   if (!x || !wstream || !bias || !y || N < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (gelu && skip) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: gelu and skip together");
   const bool bf = c->cfg.dtype == TAPIR_BF16;
-  int rows = 0, tiles = 0, cch = 0;
-  if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  int rows = 0, tiles = 0, cch = 0, nt = 0;
+  if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch, &nt, c->xconv_nt)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
   {
     // the stream is packed for ONE chunk width ([chunk][tap][k-step][row tile]): a pack made for another map
     // width would be multiplied in the wrong order
@@ -1751,7 +1753,7 @@ int tapir_xconv(tapir_ctx* c, const void* x, const void* wstream, const float* b
   xa.x = x; xa.wstream = (const uint4*)wstream; xa.frags_per_cg = xconv_frags_per_cg(cin, bf ? 32 : 16);
   xa.bias = bias; xa.skip = skip; xa.y = y;
   xa.N = N; xa.H = H; xa.W = W; xa.cin = cin; xa.cout = cout;
-  xa.TH = rows; xa.tiles = tiles; xa.passes = cout / 256;
+  xa.TH = rows; xa.tiles = tiles; xa.passes = cout / 256; xa.nt = nt;
   const bool ok = bf ? launch_xconv<bf16_t>(xa, cch, gelu != 0, (hipStream_t)stream)
                      : launch_xconv<float>(xa, cch, gelu != 0, (hipStream_t)stream);
   if (!ok) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: no kernel for this chunking");

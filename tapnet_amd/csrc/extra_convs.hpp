@@ -73,7 +73,9 @@ __global__ __launch_bounds__(NORM_THREADS) void ln_affine_kernel(LnAffineArgs a)
 }
 
 constexpr int XC_WAVES = 4;
-constexpr int XC_NT = 4;                       // pixel tiles (16 pixels) per wave: 64 pixels per workgroup
+constexpr int XC_NT = 4;                       // pixel tiles (16 pixels) per wave: 64 pixels per workgroup (the small form)
+constexpr int XC_NT_WIDE = 8;                  // the wide form: 128 pixels per workgroup -- every weight fragment a wave loads
+                                               // feeds twice the pixels (see xconv_kernel)
 constexpr int XC_RING = 12;                    // A fragments in flight per wave (3 k-steps)
 constexpr int XC_LDS_BYTES = 72 * 1024;        // two workgroups per CU
 
@@ -87,31 +89,51 @@ struct XConvArgs {
   int N, H, W, cin, cout;
   int TH, tiles;          // output rows per tile, tiles per image
   int passes;             // COUT / 256
+  int nt;                 // pixel tiles per wave: XC_NT or XC_NT_WIDE (xconv_plan)
 };
 
 // fragments of one 64-channel group's stream: chunks x 9 taps x k-steps per chunk x 4 row tiles (+ one ring
 // of padding: prefetched, never used)
 inline long xconv_frags_per_cg(int cin, int kstep) { return 9L * (cin / kstep) * 4 + XC_RING; }
 
-// rows per tile / tiles per image / input channels per chunk for an [H, W, cin] map; false: not covered
-inline bool xconv_plan(int H, int W, int cin, int cout, int esize, int* rows, int* tiles, int* cch) {
-  if (H < 1 || W < 1 || W > XC_NT * 16 || cin % 256 || cout % 256 || cin < 256 || cout < 256) return false;
-  int th = (XC_NT * 16) / W;
-  if (th > H) th = H;
-  for (int cc = esize == 2 ? 256 : 128; cc >= (esize == 2 ? 128 : 64); cc >>= 1) {   // (the instantiated chunk widths)
-    if ((long)(th + 2) * (W + 2) * cc * esize <= XC_LDS_BYTES) {
-      *rows = th; *tiles = (H + th - 1) / th; *cch = cc;
-      return true;
+// rows per tile / tiles per image / input channels per chunk / pixel tiles per wave for an [H, W, cin] map; false: not
+// covered.  The wide form (128 pixels per workgroup) is taken whenever it gives a tile more rows than the small one and
+// the tile fits LDS with one of the instantiated chunk widths: a workgroup then streams the SAME weight fragments for
+// twice the pixels -- with 64 pixels the fragments of two co-resident workgroups (2 x 1.18 MB per 256-channel chunk) need
+// as long on the L2 -> CU path as their products on the matrix pipe and the kernel sat at 0.46 of the MFMA peak -- and
+// stages 6 rows per 4 rows of output instead of 4 per 2 (64-wide maps: 4 per 2 instead of 3 per 1).
+// force_nt (tests, A/B): 0 = choose, XC_NT / XC_NT_WIDE = that form only.
+inline bool xconv_plan(int H, int W, int cin, int cout, int esize, int* rows, int* tiles, int* cch, int* nt = nullptr,
+                       int force_nt = 0) {
+  if (H < 1 || W < 1 || cin % 256 || cout % 256 || cin < 256 || cout < 256) return false;
+  auto fit = [&](int ntile, int* th_out, int* cc_out) {
+    if (W > ntile * 16) return false;
+    int th = (ntile * 16) / W;
+    if (th > H) th = H;
+    for (int cc = esize == 2 ? 256 : 128; cc >= (esize == 2 ? 128 : 64); cc >>= 1) {   // (the instantiated chunk widths)
+      if ((long)(th + 2) * (W + 2) * cc * esize <= XC_LDS_BYTES) { *th_out = th; *cc_out = cc; return true; }
     }
-  }
-  return false;
+    return false;
+  };
+  int th4 = 0, cc4 = 0, th8 = 0, cc8 = 0;
+  const bool ok4 = force_nt != XC_NT_WIDE && fit(XC_NT, &th4, &cc4);
+  const bool ok8 = force_nt != XC_NT && fit(XC_NT_WIDE, &th8, &cc8);
+  const bool wide = ok8 && (!ok4 || th8 > th4);
+  if (!wide && !ok4) return false;
+  const int th = wide ? th8 : th4;
+  *rows = th; *tiles = (H + th - 1) / th; *cch = wide ? cc8 : cc4;
+  if (nt) *nt = wide ? XC_NT_WIDE : XC_NT;
+  return true;
 }
 
-template <typename T, int CCH, bool GELU, bool SKIP>
+template <typename T, int CCH, bool GELU, bool SKIP, int NT = XC_NT>
 __global__ __launch_bounds__(XC_WAVES * 64, 2) void xconv_kernel(XConvArgs a) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int EPC = CvT<T>::EPC, KSTEP = CvT<T>::KSTEP;
-  constexpr int WAVES = XC_WAVES, NT = XC_NT, THREADS = WAVES * 64, RING = XC_RING;
+  constexpr int WAVES = XC_WAVES, THREADS = WAVES * 64;
+  constexpr int RING = NT == 8 ? 8 : XC_RING;      // (a k-step of the wide form is 32 MFMAs: two k-steps of fragments in flight cover it)
+  constexpr int NH = NT / 4;                       // groups of 4 pixel tiles: the B fragments are double-buffered per group
+  static_assert(NT == 4 || NT == 8, "4 or 8 pixel tiles per wave");
   constexpr int CB = CCH * (int)sizeof(T);         // bytes per tile pixel (one chunk of input channels)
   constexpr int CPP = CCH / EPC;                   // 16-byte pieces per tile pixel
   constexpr int SWZ = (CPP < 16 ? CPP : 16) - 1;
@@ -163,12 +185,12 @@ __global__ __launch_bounds__(XC_WAVES * 64, 2) void xconv_kernel(XConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto read_b = [&](int tap, int ks, uint4 (&fb)[NT]) {
+  auto read_b = [&](int tap, int ks, int h, uint4 (&fb)[4]) {   // pixel tiles 4 h .. 4 h + 3
     const int dy = (tap * 11) >> 5;                // tap / 3 for tap < 9
     const int toff = dy * PW + (tap - 3 * dy);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int P = Pc[i] + toff;
+    for (int i = 0; i < 4; ++i) {
+      const int P = Pc[4 * h + i] + toff;
       fb[i] = *reinterpret_cast<const uint4*>(tile + P * CB + (((4 * ks + g) ^ (P & SWZ)) << 4));
     }
   };
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(XC_WAVES * 64, 2) void xconv_kernel(XConvArgs a) {
     // clamped address, the mask applied on use (conv_fused.hpp)
     {
       constexpr int PPS = THREADS / CPP;           // pixels per sweep
-      constexpr int U = 18;                        // loads in flight per thread
+      constexpr int U = NT == 8 ? 9 : 18;          // loads in flight per thread (the wide form's accumulators leave room for 9)
       const int piece = tid % CPP, pl = tid / CPP;
       const T* xin = reinterpret_cast<const T*>(a.x) + (long)n * H * W * CIN + ch * CCH + EPC * piece;
       const int dq = PPS / PW, dr = PPS - dq * PW;
@@ -208,11 +230,12 @@ __global__ __launch_bounds__(XC_WAVES * 64, 2) void xconv_kernel(XConvArgs a) {
     }
     lds_barrier();
 
-    // ---- 9 taps x KPT k-steps on this chunk; B fragments one k-step ahead, A fragments refilled right
-    // after their last MFMA (the ring keeps running into the next chunk's fragments)
+    // ---- 9 taps x KPT k-steps on this chunk; B fragments one group of 4 pixel tiles ahead (the next k-step's first
+    // group behind the last group of this one), A fragments refilled right after their last MFMA (the ring keeps
+    // running into the next chunk's fragments).  NT = 8: every A fragment multiplies two groups of B fragments.
     {
-      uint4 fb0[NT], fb1[NT];
-      read_b(0, 0, fb0);
+      uint4 fb0[4], fb1[4];
+      read_b(0, 0, 0, fb0);
       int tap = 0, ks = 0;
       for (int grp = 0; grp < 9 * KPT / UNR; ++grp) {
 #pragma unroll
@@ -220,18 +243,25 @@ __global__ __launch_bounds__(XC_WAVES * 64, 2) void xconv_kernel(XConvArgs a) {
           int ks1 = ks + 1, tap1 = tap;
           if (ks1 == KPT) { ks1 = 0; tap1 = tap + 1; }
           if (tap1 == 9) tap1 = 0;                 // past the end: any valid address (not used)
-          uint4 (&nxt)[NT] = (kk & 1) ? fb0 : fb1;
-          uint4 (&cur)[NT] = (kk & 1) ? fb1 : fb0;
-          read_b(tap1, ks1, nxt);
-          sched_fence();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint4 fa = ring[(kk % G) * 4 + r];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) MfmaStep<T>::run(fa, cur[i], acc[r][i]);
-            ring[(kk % G) * 4 + r] = *wp;
-            wp += 64;
+          for (int h = 0; h < NH; ++h) {
+            const int step = kk * NH + h;          // (static under the unrolls: buffer parity)
+            uint4 (&nxt)[4] = (step & 1) ? fb0 : fb1;
+            uint4 (&cur)[4] = (step & 1) ? fb1 : fb0;
+            if (h + 1 < NH) read_b(tap, ks, h + 1, nxt);
+            else read_b(tap1, ks1, 0, nxt);
             sched_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint4 fa = ring[(kk % G) * 4 + r];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) MfmaStep<T>::run(fa, cur[i], acc[r][4 * h + i]);
+              if (h == NH - 1) {
+                ring[(kk % G) * 4 + r] = *wp;
+                wp += 64;
+              }
+              sched_fence();
+            }
           }
           tap = tap1; ks = ks1;
         }
@@ -293,13 +323,18 @@ template <typename T>
 inline bool launch_xconv(const XConvArgs& a, int cch, bool gelu, hipStream_t s) {
   const dim3 grid((unsigned)(8 * ((a.N * a.tiles * a.passes + 7) / 8))), block(XC_WAVES * 64);
   const bool skip = a.skip != nullptr;
-#define TAPIR_XC(CCH_)                                                                        \
-  do {                                                                                        \
-    if (gelu && !skip) TAPIR_LAUNCH((xconv_kernel<T, CCH_, true, false>), grid, block, s, a);  \
-    else if (!gelu && skip) TAPIR_LAUNCH((xconv_kernel<T, CCH_, false, true>), grid, block, s, a); \
-    else if (!gelu && !skip) TAPIR_LAUNCH((xconv_kernel<T, CCH_, false, false>), grid, block, s, a); \
-    else return false;                                                                        \
+  if (gelu && skip) return false;
+#define TAPIR_XC_NT(CCH_, NT_)                                                                         \
+  do {                                                                                                 \
+    if (gelu) TAPIR_LAUNCH((xconv_kernel<T, CCH_, true, false, NT_>), grid, block, s, a);              \
+    else if (skip) TAPIR_LAUNCH((xconv_kernel<T, CCH_, false, true, NT_>), grid, block, s, a);         \
+    else TAPIR_LAUNCH((xconv_kernel<T, CCH_, false, false, NT_>), grid, block, s, a);                  \
   } while (0)
+#define TAPIR_XC(CCH_)                                                                                 \
+  do {                                                                                                 \
+    if (a.nt == XC_NT_WIDE) TAPIR_XC_NT(CCH_, XC_NT_WIDE); else TAPIR_XC_NT(CCH_, XC_NT);              \
+  } while (0)
+  if (a.nt != XC_NT && a.nt != XC_NT_WIDE) return false;
   if (cch == 256) {
     if constexpr (sizeof(T) == 2) TAPIR_XC(256);
     else return false;                             // (f32: 256 channels x 136 pixels do not fit the tile)
@@ -312,6 +347,7 @@ inline bool launch_xconv(const XConvArgs& a, int cch, bool gelu, hipStream_t s) 
     return false;
   }
 #undef TAPIR_XC
+#undef TAPIR_XC_NT
   return true;
 }
 

@@ -64,13 +64,20 @@ def _xconv(lib, ctx, bf, x, w, bias, skip, gelu):
 
 # (H, W): 2 rows x 32 (the 256x256 model), ragged last tile, one row of 64 (512x512 inputs), 8x8 (one tile),
 # a narrow map with unused pixel columns
-@pytest.mark.parametrize('dtype,H,W', [('bf16', 4, 32), ('bf16', 5, 32), ('bf16', 2, 64), ('bf16', 8, 8),
-                                       ('bf16', 3, 24), ('f32', 3, 32), ('f32', 2, 64), ('f32', 4, 8)])
-def test_xconv_up_gelu_and_down_skip(dtype, H, W):
+# nt: pixel tiles per wave -- 0 = xconv_plan chooses (the wide form, 128 pixels per workgroup, wherever it gives a tile more
+# rows), 4 / 8 = that form only (TAPIR_XCONV_NT)
+@pytest.mark.parametrize('dtype,H,W,nt', [('bf16', 4, 32, 4), ('bf16', 5, 32, 4), ('bf16', 2, 64, 4), ('bf16', 8, 8, 4),
+                                          ('bf16', 3, 24, 4), ('f32', 3, 32, 4), ('f32', 2, 64, 4), ('f32', 4, 8, 4),
+                                          ('bf16', 4, 32, 0), ('bf16', 9, 32, 0), ('bf16', 3, 64, 0), ('bf16', 6, 6, 8),
+                                          ('bf16', 7, 24, 0), ('bf16', 2, 80, 0), ('f32', 5, 32, 0), ('f32', 2, 64, 8),
+                                          ('f32', 9, 12, 0)])
+def test_xconv_up_gelu_and_down_skip(dtype, H, W, nt, monkeypatch):
   """conv 256 -> 1024 (+ bias, GELU: 4 output-channel passes) and conv 1024 -> 256 (+ bias + skip: input
-  channels in 4-16 LDS chunks), asymmetric random operands."""
+  channels in 4-16 LDS chunks), asymmetric random operands; both forms of the kernel (64 / 128 pixels per workgroup):
+  ragged last tiles, tiles of one row, unused pixel columns, maps wider than 64 cells (wide form only)."""
   lib = emu_lib()
   bf = dtype == 'bf16'
+  monkeypatch.setenv('TAPIR_XCONV_NT', str(nt))        # read by tapir_create
   ctx = _ctx(lib, _ffi.TAPIR_BF16 if bf else _ffi.TAPIR_F32)
   rng = np.random.default_rng(H * 100 + W)
   N, C = 2, 256
@@ -79,7 +86,8 @@ def test_xconv_up_gelu_and_down_skip(dtype, H, W):
   w1 = (rng.standard_normal((4 * C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
   b1 = (rng.standard_normal(4 * C) * 0.1).astype(np.float32)
   got, rows, tiles, cch = _xconv(lib, ctx, bf, x, w1, b1, None, True)
-  assert rows == min(H, 64 // W) and tiles == -(-H // rows)
+  r4, r8 = min(H, 64 // W), min(H, 128 // W)
+  assert rows == (r4 if nt == 4 else r8 if nt == 8 else (r8 if r8 > r4 else r4)) and tiles == -(-H // rows)
   ref = _gelu(_conv_ref(x, rd(w1)) + b1)
   if bf:
     np.testing.assert_allclose(got, ref, atol=1.5e-2, rtol=1e-2)
@@ -105,10 +113,12 @@ def test_xconv_rejects_unsupported_shapes():
   lib = emu_lib()
   ctx = _ctx(lib)
   r, t, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-  assert lib.tapir_xconv_plan(ctx, 8, 80, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_xconv_plan(ctx, 8, 136, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == _ffi.TAPIR_ERR_UNSUPPORTED
+  assert lib.tapir_xconv_plan(ctx, 8, 80, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == 0   # (wide form: one row of 80)
+  assert (r.value, t.value, c.value) == (1, 8, 128)
   assert lib.tapir_xconv_plan(ctx, 8, 32, 128, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == _ffi.TAPIR_ERR_UNSUPPORTED
   assert lib.tapir_xconv_plan(ctx, 32, 32, 256, 1024, ctypes.byref(r), ctypes.byref(t), ctypes.byref(c)) == 0
-  assert (r.value, t.value, c.value) == (2, 16, 256)
+  assert (r.value, t.value, c.value) == (4, 8, 128)      # the wide form: 4 rows x 32 per workgroup, chunks of 128 channels
   lib.tapir_destroy(ctx)
 
 

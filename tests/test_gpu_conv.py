@@ -391,12 +391,13 @@ def test_chunked_feature_extraction_is_eager_and_identical():
   assert set(bb._graphs) == keys                       # chunked calls never enter the graph cache
 
 
-@pytest.mark.parametrize('size,expect_hip', [(512, True), (576, False)])
+@pytest.mark.parametrize('size,expect_hip', [(512, True), (576, True), (1040, False)])
 def test_extra_convs_map_widths(size, expect_hip):
-  """ExtraConvs on larger frames (f32 build): 512 x 512 -> a 64-wide low-res map (one output row per tile, input
-  channels in chunks of 64: BASELINE configs[4]) runs the HIP kernels and agrees with the MIOpen + torch path to
-  2e-5; 576 x 576 -> 72 cells per row is beyond the kernels (tapir_xconv_plan: TAPIR_ERR_UNSUPPORTED) and takes
-  the library path -- silently equal, never wrong."""
+  """ExtraConvs on larger frames (f32 build): 512 x 512 -> a 64-wide low-res map (two output rows per tile in the wide
+  form, input channels in chunks of 64: BASELINE configs[4]) and 576 x 576 -> 72 cells per row (one row per tile, wide
+  form only) run the HIP kernels and agree with the MIOpen + torch path to 2e-5; 1040 x 1040 -> 130 cells per row is
+  beyond the kernels (tapir_xconv_plan: TAPIR_ERR_UNSUPPORTED) and takes the library path -- silently equal, never
+  wrong."""
   from tapnet_amd import tapir_model
   w = synthetic.make_weights(21, 1, True)
   m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='float32')
