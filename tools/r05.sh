@@ -90,6 +90,19 @@ if [ "$PART" == "abproj" ]; then
   TAPIR_BACKBONE_STREAMS=3 timeout 300 python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_proj_on_streams3.json
   summ $OUT/ab_proj_*.json | tee $OUT/ab_proj_summary.txt
 fi
+if [ "$PART" == "abx" ]; then
+  # ExtraConvs: 64 pixels per workgroup (TAPIR_XCONV_NT=4) against the default (128 where it gives more rows), same box
+  for rep in 1 2; do
+    for nt in 4 0; do
+      TAPIR_XCONV_NT=$nt timeout 300 python bench.py --model bootstapir --queries 1024 --steps 10 --warmup 4 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/ab_xconv_boots_nt${nt}_$rep.json
+    done
+  done
+  for nt in 4 0; do
+    TAPIR_XCONV_NT=$nt timeout 600 python tools/run_config5.py > $OUT/ab_xconv_config5_nt${nt}.json 2>/dev/null
+  done
+  summ $OUT/ab_xconv_boots_*.json | tee $OUT/ab_xconv_summary.txt
+  cat $OUT/ab_xconv_config5_nt4.json $OUT/ab_xconv_config5_nt0.json | cut -c1-330 | tee -a $OUT/ab_xconv_summary.txt
+fi
 if [ "$PART" == "more" ]; then
   timeout 600 python bench.py --steps 10 --warmup 3 --dtype fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp32.json; cut -c1-200 $OUT/bench_fp32.json
   timeout 600 python bench.py --model bootstapir --queries 1024 --no-accuracy --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_boots_q1024.json; cut -c1-200 $OUT/bench_boots_q1024.json
