@@ -384,6 +384,17 @@ def roofline_all(prof, bbprof, T, Q, S, es, dtype, pyramid_level, dual=True):
 
   z = (0.0, 0)
   mfma('mixer_fused', prof.get('mixer_fused', z), 2.0 * R * (in_dim * 512 + 12 * 2 * 512 * 2048 + 512 * 388))
+  if 'mixer_fused' in out and Q <= 256 and T <= 48:
+    # the track-resident form: every workgroup (= CU) streams the whole packed weight set through its L2 -> CU path once per
+    # launch; ceiling = this access pattern alone on the chip (tools/micro/l2_stream_bench.hip, 53.5 B per 2.4-GHz clock
+    # and CU of the nominal 64)
+    k0_pad = -(-in_dim // 128) * 128 if es == 2 else -(-in_dim // 64) * 64
+    wbytes = (k0_pad * 512 + 12 * 2 * 512 * 2048 + 512 * 512) * es
+    per_cu = wbytes / (out['mixer_fused']['avg_us'] * 1e-6) / 1e9
+    out['mixer_fused']['weight_stream'] = dict(bytes_per_workgroup=int(wbytes), achieved=round(per_cu, 1), peak=128.4, unit='GB/s per CU',
+                                               frac=round(per_cu / 128.4, 4),
+                                               note='peak = 53.5 B/clk/CU x 2.4 GHz measured for this pattern (profiles/r05_l2_stream_bench.txt); '
+                                                    'the stream stalls during the token-mixing phases, which is why neither bound is reached')
   # cost volume: einsum (operand type) + hid1 / hid2 3x3 convolutions (exact f32 in both builds) + hid3 3x3 / stride 2
   # (operand type); the composite floor prices each part at its own matrix peak
   cells = R * h * h

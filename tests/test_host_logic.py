@@ -221,6 +221,11 @@ def test_bench_roofline_all_prices_every_kernel_class():
   R = Q * T
   assert ra['mixer_fused']['flops'] == 2.0 * R * (486 * 512 + 12 * 2 * 512 * 2048 + 512 * 388)      # 629.5 GFLOP
   np.testing.assert_allclose(ra['mixer_fused']['frac'], 629.47e9 / 700e-6 / 2.5e15, rtol=1e-3)
+  # the track-resident form's second bound: the packed weight set once per workgroup through the L2 -> CU path
+  ws = ra['mixer_fused']['weight_stream']
+  assert ws['bytes_per_workgroup'] == (512 * 512 + 12 * 2 * 512 * 2048 + 512 * 512) * 2                 # 50.9 MB (486 -> 512)
+  np.testing.assert_allclose(ws['frac'], ws['bytes_per_workgroup'] / 700e-6 / 1e9 / 128.4, rtol=1e-3)   # 0.566
+  assert 'weight_stream' not in bench.roofline_all(prof, bbprof, T, 1024, S, 2, 'bfloat16', 0)['mixer_fused']   # (wide form: shared)
   cells = R * 32 * 32
   np.testing.assert_allclose(ra['cv_rows']['flops'], 2.0 * cells * 256 + 2.0 * 144 * 32 * cells / 4 + 2.0 * 2 * 144 * cells)
   np.testing.assert_allclose(ra['cv_rows']['composite_floor_us'], 60.2, atol=0.1)                      # 35.4 GF bf16 + 7.2 GF f32
