@@ -354,9 +354,18 @@ int tapir_stem_conv_nn(tapir_ctx* ctx, const float* x, const void* wstream, void
 int tapir_layernorm_affine(tapir_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y,
                            long pixels, int C, void* stream);
 int tapir_xconv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch);
+/* The same with the frame count of the WHOLE clip (never of one launch or shard: the forms add the input channels in
+ * different orders): short clips take the 64-pixel form even where the 128-pixel one fits (all their workgroups are
+ * resident at once and the smaller ones finish first; frames x tiles < 512).  *form = 4 | 8, to be handed to
+ * tapir_xconv_nt together with a pack built for *cch. */
+int tapir_xconv_plan_frames(tapir_ctx* ctx, int frames, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch,
+                            int* form);
 int tapir_xconv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int cch, void** wstream);
 int tapir_xconv(tapir_ctx* ctx, const void* x, const void* wstream, const float* bias, const void* skip,
                 void* y, int N, int H, int W, int cin, int cout, int gelu, void* stream);
+/* tapir_xconv with the kernel form named (form = 4 | 8 from tapir_xconv_plan_frames; 0 = as tapir_xconv chooses) */
+int tapir_xconv_nt(tapir_ctx* ctx, const void* x, const void* wstream, const float* bias, const void* skip,
+                   void* y, int N, int H, int W, int cin, int cout, int gelu, int form, void* stream);
 
 /* Kernel-level hooks for the micro-benchmarks (tools/kbench.py) and the tile-shape tests; no
  * reference counterpart.  One launch of the engine's MFMA GEMM  C = epi(A . W^T + bias):

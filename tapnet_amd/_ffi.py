@@ -103,9 +103,13 @@ PROTOTYPES = {
     'tapir_conv_free': (c_int, [c_void_p, c_void_p]),
     'tapir_layernorm_affine': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     'tapir_xconv_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    'tapir_xconv_plan_frames': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                        POINTER(c_int)]),
     'tapir_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     'tapir_xconv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_void_p]),
+    'tapir_xconv_nt': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p]),
     'tapir_stem_conv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'tapir_stem_conv_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    POINTER(TapirNextNorm), c_void_p]),

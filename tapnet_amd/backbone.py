@@ -90,6 +90,7 @@ class Backbone:
     self.conv_mode = 'auto'     # 'auto' | 'hip' (any number of frames) | 'miopen'
     self.hip_min_frames = 4 if dtype == torch.bfloat16 else 1   # (f32 = the parity build: nothing is timed)
     self._hip_now = False
+    self._clip_frames = 0       # frames of the whole clip of the current features() call (kernel choices follow it, never a shard)
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
     self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
     # clips of at least this many frames replay their launches from a hipGraph from the third call with
@@ -236,13 +237,18 @@ class Backbone:
 
   # -- ExtraConvs as HIP kernels (csrc/extra_convs.hpp) ----------------------
   def _xplan(self, h, w, cin, cout):
-    key = ('x', h, w, cin, cout)
+    """(input channels per LDS chunk, kernel form) for an ExtraConvs convolution on an [h, w] map, or None.  The form
+    (64 / 128 pixels per workgroup) follows the frame count of the WHOLE clip (csrc/extra_convs.hpp xconv_plan): the two
+    forms add the input channels in different orders, so a chunk or a rank's shard must run what the whole clip runs."""
+    frames = int(self._clip_frames)
+    key = ('x', h, w, cin, cout, frames)
     if key not in self._plans:
       import ctypes
       lib, ctx = self.engine
-      rows, tiles, cch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-      ok = lib.tapir_xconv_plan(ctx, h, w, cin, cout, ctypes.byref(rows), ctypes.byref(tiles), ctypes.byref(cch)) == 0
-      self._plans[key] = cch.value if ok else None
+      rows, tiles, cch, form = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+      ok = lib.tapir_xconv_plan_frames(ctx, frames, h, w, cin, cout, ctypes.byref(rows), ctypes.byref(tiles),
+                                       ctypes.byref(cch), ctypes.byref(form)) == 0
+      self._plans[key] = (cch.value, form.value) if ok else None
     return self._plans[key]
 
   def _xpack(self, name, cch):
@@ -273,11 +279,11 @@ class Backbone:
                                              self.w[p + 'layer_norm.bias'].data_ptr(), y.data_ptr(), n * h * w, c, st),
                   'tapir_layernorm_affine')
       r = self._buf(('xhid', n, h, w, 4 * c), (n, h, w, 4 * c), self.dtype)
-      self._check(lib.tapir_xconv(ctx, y.data_ptr(), self._xpack(p + 'conv', c1), self.w[p + 'conv.bias'].data_ptr(),
-                                  None, r.data_ptr(), n, h, w, c, 4 * c, 1, st), 'tapir_xconv')
+      self._check(lib.tapir_xconv_nt(ctx, y.data_ptr(), self._xpack(p + 'conv', c1[0]), self.w[p + 'conv.bias'].data_ptr(),
+                                     None, r.data_ptr(), n, h, w, c, 4 * c, 1, c1[1], st), 'tapir_xconv_nt')
       out = self._buf(('xout', blk & 1, n, h, w, c), (n, h, w, c), self.dtype)
-      self._check(lib.tapir_xconv(ctx, r.data_ptr(), self._xpack(p + 'conv_1', c2), self.w[p + 'conv_1.bias'].data_ptr(),
-                                  y.data_ptr(), out.data_ptr(), n, h, w, 4 * c, c, 0, st), 'tapir_xconv')
+      self._check(lib.tapir_xconv_nt(ctx, r.data_ptr(), self._xpack(p + 'conv_1', c2[0]), self.w[p + 'conv_1.bias'].data_ptr(),
+                                     y.data_ptr(), out.data_ptr(), n, h, w, 4 * c, c, 0, c2[1], st), 'tapir_xconv_nt')
       x = out
     return x
 
@@ -546,7 +552,8 @@ class Backbone:
     global_frames: frame count of the whole clip when this call sees one rank's shard of it."""
     n, H, W = frames_nhwc.shape[:3]
     self.last_staged = None   # borrow=True, bf16 engine: (low16, low_tiled, hi16) written next to the returned f32 grids
-    self._hip_now = self._use_hip_convs(max(n, int(global_frames or 0)))
+    self._clip_frames = max(n, int(global_frames or 0))
+    self._hip_now = self._use_hip_convs(self._clip_frames)
     half = lambda v: -(-v // 2)
     last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
     c_low = self.w[last(3)].shape[0]
@@ -571,7 +578,7 @@ class Backbone:
       groups = max(streams, int(os.environ.get('TAPIR_BACKBONE_GROUPS', '0') or 0))
       per = -(-n // groups)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
-    key = (n, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds))
+    key = (n, self._clip_frames, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds))
     if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need
       key = None                                                       #  every dispatch on its own)
     if (key is not None and self.graph_min_frames and n >= self.graph_min_frames

@@ -1686,11 +1686,17 @@ int tapir_layernorm_affine(tapir_ctx* c, const void* x, const float* gamma, cons
   return TAPIR_OK;
 }
 
-int tapir_xconv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch) {
-  if (!c || !rows || !tiles || !cch) return TAPIR_ERR_INVALID;
-  if (!xconv_plan(H, W, cin, cout, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles, cch, nullptr, c->xconv_nt))
+int tapir_xconv_plan_frames(tapir_ctx* c, int frames, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch, int* nt) {
+  if (!c || !rows || !tiles || !cch || !nt || frames < 0) return TAPIR_ERR_INVALID;
+  if (!xconv_plan(H, W, cin, cout, c->cfg.dtype == TAPIR_BF16 ? 2 : 4, rows, tiles, cch, nt, c->xconv_nt, frames))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
   return TAPIR_OK;
+}
+
+int tapir_xconv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch) {
+  int nt = 0;
+  if (!c || !rows || !tiles || !cch) return TAPIR_ERR_INVALID;
+  return tapir_xconv_plan_frames(c, 0, H, W, cin, cout, rows, tiles, cch, &nt);
 }
 
 int tapir_xconv_pack(tapir_ctx* c, const float* w, int cout, int cin, int cch, void** wstream) {
@@ -1733,13 +1739,19 @@ int tapir_xconv_pack(tapir_ctx* c, const float* w, int cout, int cin, int cch, v
 
 int tapir_xconv(tapir_ctx* c, const void* x, const void* wstream, const float* bias, const void* skip, void* y,
                 int N, int H, int W, int cin, int cout, int gelu, void* stream) {
+  return tapir_xconv_nt(c, x, wstream, bias, skip, y, N, H, W, cin, cout, gelu, 0, stream);
+}
+
+int tapir_xconv_nt(tapir_ctx* c, const void* x, const void* wstream, const float* bias, const void* skip, void* y,
+                   int N, int H, int W, int cin, int cout, int gelu, int form, void* stream) {
   if (!c) return TAPIR_ERR_INVALID;
+  if (form != 0 && form != XC_NT && form != XC_NT_WIDE) return fail(c, TAPIR_ERR_INVALID, "xconv: form is 0, 4 or 8 pixel tiles per wave");
   HIP_TRY(c, hipSetDevice(c->device));
   if (!x || !wstream || !bias || !y || N < 1) return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (gelu && skip) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: gelu and skip together");
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0, cch = 0, nt = 0;
-  if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch, &nt, c->xconv_nt)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch, &nt, form ? form : c->xconv_nt)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
   {
     // the stream is packed for ONE chunk width ([chunk][tap][k-step][row tile]): a pack made for another map
     // width would be multiplied in the wrong order

@@ -102,9 +102,14 @@ inline long xconv_frags_per_cg(int cin, int kstep) { return 9L * (cin / kstep) *
 // twice the pixels -- with 64 pixels the fragments of two co-resident workgroups (2 x 1.18 MB per 256-channel chunk) need
 // as long on the L2 -> CU path as their products on the matrix pipe and the kernel sat at 0.46 of the MFMA peak -- and
 // stages 6 rows per 4 rows of output instead of 4 per 2 (64-wide maps: 4 per 2 instead of 3 per 1).
+// It needs enough work to pay: a wide workgroup runs ~1.6 x as long as a small one, so while ALL small workgroups of a
+// clip's launches are resident at once (frames x small tiles < 2 workgroups x 256 CUs) the small form finishes first --
+// measured on BootsTAPIR clips of 4 .. 48 frames (profiles/r05_ab_xconv_wide.txt): small wins up to 24 frames, equal at
+// 32, wide from there.  n_frames = frames of the WHOLE clip (0: unknown, taken as many), never of one launch or shard:
+// the two forms add the input channels in different orders, and a clip must not change form with how it is cut up.
 // force_nt (tests, A/B): 0 = choose, XC_NT / XC_NT_WIDE = that form only.
 inline bool xconv_plan(int H, int W, int cin, int cout, int esize, int* rows, int* tiles, int* cch, int* nt = nullptr,
-                       int force_nt = 0) {
+                       int force_nt = 0, int n_frames = 0) {
   if (H < 1 || W < 1 || cin % 256 || cout % 256 || cin < 256 || cout < 256) return false;
   auto fit = [&](int ntile, int* th_out, int* cc_out) {
     if (W > ntile * 16) return false;
@@ -118,7 +123,8 @@ inline bool xconv_plan(int H, int W, int cin, int cout, int esize, int* rows, in
   int th4 = 0, cc4 = 0, th8 = 0, cc8 = 0;
   const bool ok4 = force_nt != XC_NT_WIDE && fit(XC_NT, &th4, &cc4);
   const bool ok8 = force_nt != XC_NT && fit(XC_NT_WIDE, &th8, &cc8);
-  const bool wide = ok8 && (!ok4 || th8 > th4);
+  bool wide = ok8 && (!ok4 || th8 > th4);
+  if (wide && ok4 && force_nt == 0 && n_frames > 0 && (long)n_frames * ((H + th4 - 1) / th4) < 512) wide = false;
   if (!wide && !ok4) return false;
   const int th = wide ? th8 : th4;
   *rows = th; *tiles = (H + th - 1) / th; *cch = wide ? cc8 : cc4;

@@ -135,3 +135,40 @@ def test_xconv_rejects_a_pack_built_for_another_chunk_width():
   assert rc == _ffi.TAPIR_ERR_INVALID and b'chunks of 256' in lib.tapir_last_error(ctx)
   assert lib.tapir_xconv(ctx, _p(x), _p(w), _p(b), None, _p(y), 1, 2, 64, 256, 256, 0, None) == _ffi.TAPIR_ERR_INVALID
   lib.tapir_destroy(ctx)
+
+
+def test_xconv_form_follows_the_clip_length():
+  """tapir_xconv_plan_frames: the 128-pixel form only where the clip gives it enough workgroups (frames x small tiles >=
+  512: a 32-wide map from 32 frames on, a 64-wide one from 8), the 64-pixel form below; frames = 0 (unknown) is taken as
+  many; maps only the wide form covers stay wide; and tapir_xconv_nt runs the form it is told to, refusing a pack built
+  for the other one's chunk width."""
+  lib = emu_lib()
+  ctx = _ctx(lib)
+  r, t, c, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  plan = lambda frames, H, W: (lib.tapir_xconv_plan_frames(ctx, frames, H, W, 1024, 256, ctypes.byref(r), ctypes.byref(t),
+                                                           ctypes.byref(c), ctypes.byref(f)), r.value, t.value, c.value, f.value)
+  assert plan(0, 32, 32) == (0, 4, 8, 128, 8) and plan(48, 32, 32) == (0, 4, 8, 128, 8) and plan(32, 32, 32)[4] == 8
+  assert plan(31, 32, 32) == (0, 2, 16, 256, 4) and plan(4, 32, 32)[4] == 4
+  assert plan(8, 64, 64) == (0, 2, 32, 128, 8) and plan(7, 64, 64) == (0, 1, 64, 128, 4)
+  assert plan(1, 9, 72) == (0, 1, 9, 128, 8)                       # 72 cells per row: only the wide form
+  assert plan(-1, 32, 32)[0] == _ffi.TAPIR_ERR_INVALID
+  # the same convolution through both forms, named explicitly
+  rng = np.random.default_rng(5)
+  N, H, W, C = 1, 4, 32, 256
+  x = to_bf16_bits(_r(rng.standard_normal((N, H, W, C))))
+  w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  b = (rng.standard_normal(C) * 0.1).astype(np.float32)
+  ys = {}
+  for form, cch in ((4, 256), (8, 128)):
+    ws = ctypes.c_void_p()
+    assert lib.tapir_xconv_pack(ctx, _p(w), C, C, cch, ctypes.byref(ws)) == 0
+    y = np.zeros((N, H, W, C), np.uint16)
+    assert lib.tapir_xconv_nt(ctx, _p(x), ws, _p(b), None, _p(y), N, H, W, C, C, 0, form, None) == 0, lib.tapir_last_error(ctx)
+    other = 12 - form
+    assert lib.tapir_xconv_nt(ctx, _p(x), ws, _p(b), None, _p(y), N, H, W, C, C, 0, other, None) == _ffi.TAPIR_ERR_INVALID
+    ys[form] = from_bf16_bits(y)
+    assert lib.tapir_conv_free(ctx, ws) == 0
+  assert lib.tapir_xconv_nt(ctx, _p(x), None, _p(b), None, _p(x), N, H, W, C, C, 0, 5, None) == _ffi.TAPIR_ERR_INVALID
+  np.testing.assert_allclose(ys[4], ys[8], atol=1.6e-2, rtol=1e-2)   # (different summation orders, bf16 outputs)
+  assert np.abs(ys[4] - ys[8]).mean() < 1e-3 and np.abs(ys[8]).max() > 0.5
+  lib.tapir_destroy(ctx)
