@@ -356,7 +356,7 @@ int tapir_layernorm_affine(tapir_ctx* ctx, const void* x, const float* gamma, co
 int tapir_xconv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch);
 /* The same with the frame count of the WHOLE clip (never of one launch or shard: the forms add the input channels in
  * different orders): short clips take the 64-pixel form even where the 128-pixel one fits (all their workgroups are
- * resident at once and the smaller ones finish first; frames x tiles < 512).  *form = 4 | 8, to be handed to
+ * resident at once and the smaller ones finish first; frames x tiles x (cout / 256) < 512).  *form = 4 | 8, to be handed to
  * tapir_xconv_nt together with a pack built for *cch. */
 int tapir_xconv_plan_frames(tapir_ctx* ctx, int frames, int H, int W, int cin, int cout, int* rows, int* tiles, int* cch,
                             int* form);

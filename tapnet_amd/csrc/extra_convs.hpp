@@ -103,7 +103,8 @@ inline long xconv_frags_per_cg(int cin, int kstep) { return 9L * (cin / kstep) *
 // as long on the L2 -> CU path as their products on the matrix pipe and the kernel sat at 0.46 of the MFMA peak -- and
 // stages 6 rows per 4 rows of output instead of 4 per 2 (64-wide maps: 4 per 2 instead of 3 per 1).
 // It needs enough work to pay: a wide workgroup runs ~1.6 x as long as a small one, so while ALL small workgroups of a
-// clip's launches are resident at once (frames x small tiles < 2 workgroups x 256 CUs) the small form finishes first --
+// clip's launches are resident at once (frames x small tiles x output-channel passes < 2 workgroups x 256 CUs) the small
+// form finishes first --
 // measured on BootsTAPIR clips of 4 .. 48 frames (profiles/r05_ab_xconv_wide.txt): small wins up to 24 frames, equal at
 // 32, wide from there.  n_frames = frames of the WHOLE clip (0: unknown, taken as many), never of one launch or shard:
 // the two forms add the input channels in different orders, and a clip must not change form with how it is cut up.
@@ -124,7 +125,7 @@ inline bool xconv_plan(int H, int W, int cin, int cout, int esize, int* rows, in
   const bool ok4 = force_nt != XC_NT_WIDE && fit(XC_NT, &th4, &cc4);
   const bool ok8 = force_nt != XC_NT && fit(XC_NT_WIDE, &th8, &cc8);
   bool wide = ok8 && (!ok4 || th8 > th4);
-  if (wide && ok4 && force_nt == 0 && n_frames > 0 && (long)n_frames * ((H + th4 - 1) / th4) < 512) wide = false;
+  if (wide && ok4 && force_nt == 0 && n_frames > 0 && (long)n_frames * ((H + th4 - 1) / th4) * (cout / 256) < 512) wide = false;
   if (!wide && !ok4) return false;
   const int th = wide ? th8 : th4;
   *rows = th; *tiles = (H + th - 1) / th; *cch = wide ? cc8 : cc4;

@@ -138,8 +138,8 @@ def test_xconv_rejects_a_pack_built_for_another_chunk_width():
 
 
 def test_xconv_form_follows_the_clip_length():
-  """tapir_xconv_plan_frames: the 128-pixel form only where the clip gives it enough workgroups (frames x small tiles >=
-  512: a 32-wide map from 32 frames on, a 64-wide one from 8), the 64-pixel form below; frames = 0 (unknown) is taken as
+  """tapir_xconv_plan_frames: the 128-pixel form only where the clip gives it enough workgroups (frames x small tiles x
+  output-channel passes >= 512: the 1024 -> 256 convolution on a 32-wide map from 32 frames on, on a 64-wide one from 8), the 64-pixel form below; frames = 0 (unknown) is taken as
   many; maps only the wide form covers stay wide; and tapir_xconv_nt runs the form it is told to, refusing a pack built
   for the other one's chunk width."""
   lib = emu_lib()
@@ -151,6 +151,10 @@ def test_xconv_form_follows_the_clip_length():
   assert plan(31, 32, 32) == (0, 2, 16, 256, 4) and plan(4, 32, 32)[4] == 4
   assert plan(8, 64, 64) == (0, 2, 32, 128, 8) and plan(7, 64, 64) == (0, 1, 64, 128, 4)
   assert plan(1, 9, 72) == (0, 1, 9, 128, 8)                       # 72 cells per row: only the wide form
+  # the 256 -> 1024 convolution runs four output-channel passes per tile: four times the workgroups, wide from 8 frames
+  plan1 = lambda frames: (lib.tapir_xconv_plan_frames(ctx, frames, 32, 32, 256, 1024, ctypes.byref(r), ctypes.byref(t),
+                                                      ctypes.byref(c), ctypes.byref(f)), f.value)
+  assert plan1(8) == (0, 8) and plan1(7) == (0, 4)
   assert plan(-1, 32, 32)[0] == _ffi.TAPIR_ERR_INVALID
   # the same convolution through both forms, named explicitly
   rng = np.random.default_rng(5)
