@@ -372,16 +372,20 @@ def test_reloading_hot_path_weights_keeps_the_backbone():
   assert not torch.equal(other[0], ref[0]) and torch.isfinite(other[0]).all()
 
 
-def test_chunked_feature_extraction_is_eager_and_identical():
+@pytest.mark.parametrize('extra,size', [(False, 128), (True, 256)])
+def test_chunked_feature_extraction_is_eager_and_identical(extra, size):
   """feature_extractor_chunk_size (tapir_model.py:689-703) bounds the backbone's scratch: chunked calls are launched
   eagerly (a captured graph would keep full-clip static buffers) and give the bits of the unchunked call, whatever
   the chunk length (every kernel is independent of the number of frames per launch; the convolution implementation is
-  chosen from the whole clip, so a short last chunk runs the same kernels)."""
+  chosen from the whole clip, so a short last chunk runs the same kernels).  BootsTAPIR at 256 x 256: the 18-frame clip
+  runs the 128-pixel form of the 256 -> 1024 ExtraConvs convolution (from 8 frames on, extra_convs.hpp) -- chunks of 5
+  or 7 frames and a rank's frame shard (global_frames) must run it too, or their bits differ (the forms add the input
+  channels in different orders)."""
   from tapnet_amd import tapir_model
-  w = synthetic.make_weights(21, 1, False)
-  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=w, device='cuda:0', dtype='bfloat16')
+  w = synthetic.make_weights(21, 1, extra)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=extra, weights=w, device='cuda:0', dtype='bfloat16')
   bb = m._backbone
-  frames = torch.as_tensor(synthetic.make_video(4, 18, 128, 128), device='cuda:0').reshape(-1, 128, 128, 3).float()
+  frames = torch.as_tensor(synthetic.make_video(4, 18, size, size), device='cuda:0').reshape(-1, size, size, 3).float()
   ref = [t.clone() for t in bb.features(frames)]
   keys = set(bb._graphs)
   for chunk in (16, 5, 7):                             # 16 + 2 frames: the last chunk is below hip_min_frames
@@ -389,6 +393,14 @@ def test_chunked_feature_extraction_is_eager_and_identical():
       out = bb.features(frames, chunk)
     assert all(torch.equal(a, b) for a, b in zip(out, ref)), chunk
   assert set(bb._graphs) == keys                       # chunked calls never enter the graph cache
+  if extra:
+    assert bb._xplan(size // 8, size // 8, 256, 1024)[1] == 8 and bb._xplan(size // 8, size // 8, 1024, 256)[1] == 4
+  for lo, hi in ((0, 9), (9, 18), (16, 18)):           # frame shards of the clip (tapnet_amd.distributed)
+    part = bb.features(frames[lo:hi], global_frames=18)
+    assert all(torch.equal(a, b[lo:hi]) for a, b in zip(part, ref)), (lo, hi)
+  if extra:                                            # ... and on its own a 5-frame clip takes the small form
+    bb.features(frames[:5])
+    assert bb._xplan(size // 8, size // 8, 256, 1024)[1] == 4
 
 
 @pytest.mark.parametrize('size,expect_hip', [(512, True), (576, True), (1040, False)])
