@@ -63,6 +63,8 @@ def parse():
   ap.add_argument('--shard', default='clips', choices=['clips', 'queries'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-accuracy', action='store_true')
+  ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (f32 build vs the reference golden, '
+                  'BootsTAPIR Q = 1024, config 5 on one GPU, online step)')
   ap.add_argument('--cpu-sample-queries', type=int, default=48)
   ap.add_argument('--cpu-sample-frames', type=int, default=12)
   ap.add_argument('--emulate-rank', type=int, nargs='*', default=None, metavar='N',
@@ -511,6 +513,100 @@ def emulate_ranks(model, video, qpts, worlds, steps, es):
               ranks=rows)
 
 
+def secondary_legs(dev, steps):
+  """The other configurations README / DESIGN quote, each a handful of steps AFTER the timed region, so that the driver's
+  own record (BENCH_rNN.json) carries them next to the headline instead of builder-run files under profiles/:
+    f32_build         the parity build (exact-f32 MFMA) on the benchmarked shape, timed, and its video -> tracks outputs
+                      held in-run to the reference torch twin's (tests/golden/headline_tapir.npz: outputs of
+                      tapnet/torch/tapir_model.py TAPIR.forward, generated by oracle/make_golden.py) -- parity of a timed build
+    bootstapir_q1024  BASELINE.json configs[2], one rank's share: BootsTAPIR kwargs, one 48-frame clip, 1024 queries
+    config5_1gpu      BASELINE.json configs[4] on ONE GPU: 512x512x96, 4096 queries, 8 refinement iterations
+    online            BASELINE.json configs[3]: causal model, one 256x256 frame per step, 256 points, hipGraph replay
+  Every leg is bounded and never fails the bench."""
+  from tapnet_amd import online, synthetic, tapir_model
+  out = {}
+
+  def timed(fn, warm, n):
+    for _ in range(warm):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+      r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, r
+
+  def leg(name, fn):
+    try:
+      out[name] = fn()
+    except Exception as e:
+      out[name] = dict(error=f'{type(e).__name__}: {e}')
+    torch.cuda.empty_cache()
+
+  def f32_build():
+    gdir = os.path.join(ROOT, 'tests', 'golden')
+    g = np.load(os.path.join(gdir, 'headline_tapir.npz'))
+    gap = np.load(os.path.join(gdir, 'headline_masks.npz'))['headline_tapir_min_top2_rel_gap']
+    wseed, T, Q, S = 31, 48, 256, 256       # tests/golden_util.py HEADLINE['headline_tapir']
+    w = synthetic.make_weights(wseed, 0, False)
+    m = tapir_model.TAPIR(pyramid_level=0, extra_convs=False, softmax_temperature=20.0, weights=w, dtype='float32', device=dev)
+    v = torch.as_tensor(synthetic.make_video(wseed + 100, T, S, S), device=dev)
+    q = torch.as_tensor(synthetic.make_queries(wseed + 200, Q, T, S, S), device=dev)
+    s, r = timed(lambda: m(v, False, q), 2, max(2, min(steps, 5)))
+    d = np.linalg.norm(r['tracks'].cpu().numpy() - g['tracks'], axis=-1)[0]
+    keep = gap >= 1e-4
+    do = np.abs(r['occlusion'].cpu().numpy() - g['occlusion'])[0]
+    return dict(ms_per_step=round(s * 1e3, 3), points_per_s=round(Q / s, 1),
+                max_err_vs_headline_golden_px=float(d.max()), queries_above_1e_3=int((d.max(-1) > 1e-3).sum()),
+                max_err_px_without_near_ties=float(d[keep].max()), queries_with_a_near_tie=int((~keep).sum()),
+                max_occlusion_logit_err=float(do.max()),
+                golden='tests/golden/headline_tapir.npz: outputs of the reference torch twin at 256x256x48, Q = 256 (TAPIR kwargs, seeded weights)')
+
+  def boots():
+    T, Q, S = 48, 1024, 256
+    w = synthetic.make_weights(0, 1, True)
+    m = tapir_model.TAPIR(**MODELS['bootstapir'], weights=w, dtype='bfloat16', device=dev)
+    v = torch.as_tensor(synthetic.make_video(1, T, S, S), device=dev)
+    q = torch.as_tensor(synthetic.make_queries(101, Q, T, S, S), device=dev)
+    s, _ = timed(lambda: m(v, False, q), 4, max(3, min(steps, 10)))
+    return dict(ms_per_clip=round(s * 1e3, 3), points_per_s=round(Q / s, 1), workload='BootsTAPIR kwargs, 256x256x48, Q = 1024, bf16')
+
+  def config5():
+    T, S, Q = 96, 512, 4096
+    w = synthetic.make_weights(0, 1, True)
+    m = tapir_model.TAPIR(**MODELS['bootstapir'], weights=w, dtype='bfloat16', device=dev)
+    v = torch.as_tensor(synthetic.make_video(3, T, S, S), device=dev)
+    q = torch.as_tensor(synthetic.make_queries(4, Q, T, S, S), device=dev)
+    s, r = timed(lambda: m(v, False, q), 1, 2)
+    assert len(r['unrefined_tracks']) == 8 and torch.isfinite(r['tracks']).all()
+    return dict(s_per_clip=round(s, 4), points_per_s=round(Q / s, 1),
+                workload='BootsTAPIR kwargs, 512x512x96, Q = 4096, resolutions (256, 512) -> 8 refinement iterations, bf16, ONE GPU')
+
+  def online_leg():
+    S, Q = 256, 256
+    w = synthetic.make_weights(0, pyramid_level=1, extra_convs=True)
+    m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, use_causal_conv=True, weights=w, dtype='bfloat16', device=dev)
+    v = torch.as_tensor(synthetic.make_video(1, 8, S, S), device=dev)
+    q = torch.as_tensor(synthetic.make_queries(2, Q, 1, S, S), device=dev)
+    trk = online.OnlineTracker(m, Q, (S, S), use_graph=True)
+    trk.init(v[:, :1], q)
+    k = [0]
+    def step():
+      k[0] += 1
+      return trk.step(v[:, k[0] % 8:k[0] % 8 + 1])
+    s, r = timed(step, 5, 40)
+    assert torch.isfinite(r['tracks']).all()
+    return dict(ms_per_frame=round(s * 1e3, 3), frames_per_s=round(1.0 / s, 1),
+                workload='causal model (BootsTAPIR kwargs + use_causal_conv), 256x256 frames, 256 points, 4 iterations per frame, '
+                         'bf16, hipGraph replay', backbone=m._backbone.describe(1))
+
+  leg('f32_build', f32_build)
+  leg('bootstapir_q1024', boots)
+  leg('config5_1gpu', config5)
+  leg('online', online_leg)
+  return out
+
+
 def main():
   args = parse()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -766,6 +862,9 @@ def main():
       line['batch_of_2_clips'] = batch2
     if world == 1 and dtype == 'bfloat16' and not args.no_accuracy:
       line['accuracy'] = accuracy_vs_f32(kw, weights, dev, video, qpts, out)
+    default_workload = (args.model, T, Q, S, args.dtype, args.shard) == ('tapir', 48, 256, 256, 'bf16', 'clips')
+    if world == 1 and default_workload and not args.no_secondary:
+      line['secondary'] = secondary_legs(dev, args.steps)
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args, kw, weights, video_np, qpts_np)
     print(json.dumps(line))

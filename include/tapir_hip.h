@@ -363,7 +363,16 @@ int tapir_xconv_plan_frames(tapir_ctx* ctx, int frames, int H, int W, int cin, i
 int tapir_xconv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int cch, void** wstream);
 int tapir_xconv(tapir_ctx* ctx, const void* x, const void* wstream, const float* bias, const void* skip,
                 void* y, int N, int H, int W, int cin, int cout, int gelu, void* stream);
-/* tapir_xconv with the kernel form named (form = 4 | 8 from tapir_xconv_plan_frames; 0 = as tapir_xconv chooses) */
+/* tapir_xconv with the kernel form named (form = 4 | 8; 0 = as tapir_xconv chooses: the many-frames choice of
+ * tapir_xconv_plan).  CONTRACT: `form` must be the value tapir_xconv_plan_frames returned for the WHOLE clip's frame count
+ * (batch x frames of the call, or the global frame count of a sharded clip), the same for every launch, chunk and shard
+ * of that clip, with a pack built for the *cch of that same plan call.  The call only checks that the pack's chunk width
+ * fits the form; the two forms add the input channels in different orders, so mixing them still computes the
+ * convolution but the results of chunks / shards are then no longer bit-identical to the whole clip's.  Consequently
+ * BootsTAPIR features are bit-stable for a given (batch x frames) only: one 16-frame clip and two batched 16-frame
+ * clips may take different forms (tapnet_amd.backbone passes max(B x T, global frames)); a C caller that follows
+ * plan -> pack -> tapir_xconv (form 0) gets the many-frames form whatever its clip length, i.e. other last bits than the
+ * Python backbone on short clips -- use tapir_xconv_plan_frames + tapir_xconv_nt to match it. */
 int tapir_xconv_nt(tapir_ctx* ctx, const void* x, const void* wstream, const float* bias, const void* skip,
                    void* y, int N, int H, int W, int cin, int cout, int gelu, int form, void* stream);
 
@@ -418,6 +427,21 @@ int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* gri
 /* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
  * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
+/* The 3x3 256 -> 256 block convolutions (tapir_conv_fused*): 1 = always the flat tiling of the whole launch
+ * (csrc/conv_flat.hpp: three consecutive 64-pixel slabs of the (image, row) space per workgroup) where the shape allows it,
+ * 0 (default) = never, -1 = from 96 slabs per launch on.  The forms are bit-identical (tests); the flat form is faster as one
+ * 48-frame launch and slower inside the 4-stream backbone (profiles/r06_ab_flat_v1.txt), hence off. */
+int tapir_debug_set_conv_flat(tapir_ctx* ctx, int mode);
+/* TAPIR_OK and the number of workgroups if a tapir_conv_fused* launch of N images of this shape takes the flat tiling under
+ * the current mode, TAPIR_ERR_UNSUPPORTED if it takes the per-image tiling (no error message is set). */
+int tapir_conv_flat_plan(tapir_ctx* ctx, int N, int H, int W, int cin, int cout, int ks, int stride, int* workgroups);
+/* Defect hunting (tools/probe_two_process.py): the separate-launch mixer returns after `stages` launch groups (1 = the
+ * input Linear, then per block: token mixing, up-projection, down-projection; 0 = off); the engine's workspaces
+ * (which: 0 mlp_in, 1 xa, 2 xb, 3 xn, 4 hid, 5 res, 6 split-K partials) as device pointer + capacity; a launch that fills
+ * every CU's LDS with a pattern. */
+int tapir_debug_mixer_stop(tapir_ctx* ctx, int stages);
+int tapir_debug_workspace(tapir_ctx* ctx, int which, void** p, unsigned long long* bytes);
+int tapir_debug_poison_lds(tapir_ctx* ctx, unsigned pattern, void* stream);
 /* refine_pips's state update (tapir_model.py:613-623): 1 (default) = applied by the output stage of the track-resident
  * mixer kernels, 0 = always the separate update kernel on the mixer's [R,388] output (A/B, tests; bit-identical). */
 int tapir_debug_set_update_mode(tapir_ctx* ctx, int mode);

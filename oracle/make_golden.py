@@ -32,6 +32,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file
 # path, which is reproducible to float noise only: observed 0.0 for tapir / causal / multires / causal_update /
 # headline_tapir and 3.8e-6 px for bootstapir (the ExtraConvs convolutions), against the 1e-3 parity bar.
 CHECK_ATOL = 1e-5
+# Per case: the cases that regenerate at exactly 0.0 must keep doing so (a regression of up to 1e-5 in their generation would
+# otherwise pass unseen); only the ExtraConvs cases (oneDNN's summation order follows the day's thread / shape heuristics)
+# get the float-noise tolerance.
+CHECK_ATOL_BY_CASE = {'bootstapir': CHECK_ATOL, 'headline_bootstapir': CHECK_ATOL}
+
+
+def check_atol(name):
+  return CHECK_ATOL_BY_CASE.get(name, 0.0)
 
 # name -> dict(kwargs for the reference ctor, clip, queries)
 CASES = {
@@ -231,8 +239,8 @@ def make_headline_case(tm, name, cfg, check=False):
   if check:
     old = np.load(path)
     worst = max(float(np.abs(old[k] - v).max()) for k, v in res.items())
-    print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {CHECK_ATOL:g})')
-    assert set(old.files) == set(res) and worst <= CHECK_ATOL, name
+    print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {check_atol(name):g})')
+    assert set(old.files) == set(res) and worst <= check_atol(name), name
     return
   np.savez_compressed(path, **res)
   print(name, {k: v.shape for k, v in res.items() if k == 'tracks'}, f'{os.path.getsize(path) / 1e6:.2f} MB')
@@ -256,8 +264,8 @@ def check_case(tm, name, cfg):
     GOLDEN_DIR = keep
   assert set(old) == set(new), (name, set(old) ^ set(new))
   worst = max(float(np.abs(old[k].astype(np.float64) - new[k].astype(np.float64)).max()) for k in old)
-  print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {CHECK_ATOL:g})')
-  assert worst <= CHECK_ATOL, name
+  print(f'[{name}] committed vs regenerated from the reference: max |diff| {worst:.3e} (atol {check_atol(name):g})')
+  assert worst <= check_atol(name), name
 
 
 def main():

@@ -130,6 +130,11 @@ PROTOTYPES = {
     'tapir_debug_contraction': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tapir_debug_set_gemm_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_set_update_mode': (c_int, [c_void_p, c_int]),
+    'tapir_debug_set_conv_flat': (c_int, [c_void_p, c_int]),
+    'tapir_conv_flat_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    'tapir_debug_mixer_stop': (c_int, [c_void_p, c_int]),
+    'tapir_debug_workspace': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(ctypes.c_ulonglong)]),
+    'tapir_debug_poison_lds': (c_int, [c_void_p, ctypes.c_uint, c_void_p]),
     'tapir_debug_mix': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p]),
     'tapir_profile_enable': (c_int, [c_void_p, c_int]),

@@ -89,6 +89,8 @@ class Backbone:
     # contexts); 'miopen': every convolution through MIOpen (the A/B switch, and the f32 path).
     self.conv_mode = 'auto'     # 'auto' | 'hip' (any number of frames) | 'miopen'
     self.hip_min_frames = 4 if dtype == torch.bfloat16 else 1   # (f32 = the parity build: nothing is timed)
+    if os.environ.get('TAPIR_HIP_MIN_FRAMES'):   # (A/B measurements of the online step: 1 = the HIP convolutions for a single frame too)
+      self.hip_min_frames = int(os.environ['TAPIR_HIP_MIN_FRAMES'])
     self._hip_now = False
     self._clip_frames = 0       # frames of the whole clip of the current features() call (kernel choices follow it, never a shard)
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
@@ -578,7 +580,8 @@ class Backbone:
       groups = max(streams, int(os.environ.get('TAPIR_BACKBONE_GROUPS', '0') or 0))
       per = -(-n // groups)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
-    key = (n, self._clip_frames, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds))
+    key = (n, self._clip_frames, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds),
+           bool(self.fuse_proj), bool(self.fuse_finalize), self.conv_mode)   # (everything that changes WHICH kernels a pass launches)
     if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need
       key = None                                                       #  every dispatch on its own)
     if (key is not None and self.graph_min_frames and n >= self.graph_min_frames
@@ -649,7 +652,8 @@ class Backbone:
         if lane and i < streams:
           st.wait_event(fork)
         self._lane = lane
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st):   # (issuing / capturing the groups' launches block by block round-robin instead of group after
+          #  group measures the same: profiles/r06_ab_interleave.txt)
           self._features_hip(frames_nhwc[s:e], low[s:e], hi[s:e],
                              None if staged is None else tuple(t[s:e] for t in staged))
       for st in self._side_streams[:streams - 1]:

@@ -74,7 +74,8 @@ struct Conv3Args {
 inline long conv3_frags_per_cg(int cin, int ks, int kstep) { return (long)ks * ks * (cin / kstep) * 4 + cv3_ring(ks); }
 // DUAL streams (conv_0 + proj_conv of a block in one launch): the projection's k-steps come first, padded with zero
 // fragments to whole ring turns (3 k-steps), so that the 3x3 loop behind them starts at ring phase 0
-inline int conv3_proj_ksteps(int cin, int kstep) { const int g = cv3_ring(3) / 4; return (cin / kstep + g - 1) / g * g; }
+constexpr int conv3_proj_ksteps_c(int cin, int kstep) { return (cin / kstep + cv3_ring(3) / 4 - 1) / (cv3_ring(3) / 4) * (cv3_ring(3) / 4); }
+inline int conv3_proj_ksteps(int cin, int kstep) { return conv3_proj_ksteps_c(cin, kstep); }
 inline long conv3_dual_frags_per_cg(int cin, int kstep) { return conv3_frags_per_cg(cin, 3, kstep) + 4L * conv3_proj_ksteps(cin, kstep); }
 
 // XLA SAME: total = max((ceil(n / s) - 1) * s + k - n, 0), low = total / 2

@@ -139,7 +139,9 @@ __device__ __forceinline__ float relu_f32(float x) {
 // logits of the soft-arg-max pass are streamed from LDS twice instead of held in registers, an occlusion row is two tiles).
 template <typename TA, int QPW, int NTX, bool TRACE = false, int HEADS = 1, bool RAGW = true, int WAVES = CVR_WAVES,
           int PW = CVR_PW>
-__global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : (QPW == 16 && WAVES == 8) ? 2 : 4) void cv_rows_kernel(CvFusedArgs a) {
+// (waves per SIMD asked of the register allocator: the f32 instantiations -- the parity build, nothing timed -- need more
+// than 128 VGPRs for the exact-f32 fragments and get two)
+__global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : ((QPW == 16 && WAVES == 8) || sizeof(TA) == 4) ? 2 : 4) void cv_rows_kernel(CvFusedArgs a) {
   constexpr int THREADS = WAVES * 64;
   // floats per cost map incl. the halo.  Rows of <= 32 cells: 34 x 34 = 1156 rounded up to 1163 = 11 (mod 32): the contraction
   // stores cell 4 g + r of map c from lane (c, g) -- with a map stride of 4 (mod 32) the 16 active lanes of a half wave hit 8

@@ -14,6 +14,7 @@
 #include "backbone.hpp"
 #include "common.hpp"
 #include "conv_fused.hpp"
+#include "conv_flat.hpp"
 #include "costvol.hpp"
 #include "costvol_fused.hpp"
 #include "costvol_rows.hpp"
@@ -72,6 +73,7 @@ struct tapir_ctx {
   uint4* fused_stream = nullptr; long fused_fpw = 0;
   uint4* fused_wide_stream = nullptr; long fused_wide_fpw = 0;   // bf16: the 6-tile kernel's chunking (mixer_fused_wide.hpp)
   std::vector<FusedBlockParams> fused_blocks;     // per-block vectors (passed in the kernel arguments)
+  int dbg_mixer_stop = 0;                         // tapir_debug_mixer_stop: the separate-launch mixer returns after this many launch groups (0: off)
   int mixer_mode = 0;                             // 0 auto, 1 separate launches, 2 fused (tapir_debug_set_mixer_mode)
   bool cv_tiled = true;                           // row-streamed cost volume, bf16: contraction operand in tile order (TAPIR_CV_TILED=0: row-major, A/B)
   bool fuse_patch = false;                        // refine_pips's front half in the track-resident mixer's prologue (TAPIR_FUSE_PATCH=1; measured: the
@@ -89,6 +91,10 @@ struct tapir_ctx {
                                                   // SLOWER at the production chunk: 101 against 84 us at M = 682, profiles/r05_kbench_contraction.txt -- off)
   int fuse_update = 1;                            // track-resident mixers apply refine_pips's state update themselves (0: update_kernel; A/B, tests)
   int xconv_nt = 0;                               // ExtraConvs convolutions: 0 = xconv_plan chooses, 4 / 8 = pixel tiles per wave forced (TAPIR_XCONV_NT: tests, A/B)
+  int conv_flat = 0;                              // 3x3 256 -> 256 block convolutions: 1 = the flat tiling (conv_flat.hpp) wherever it applies, 0 = never (default:
+                                                  // faster as a single 48-frame launch, 74 vs 87 us, slower inside the 4-stream backbone, 4.60 vs 4.51 ms per step:
+                                                  // profiles/r06_ab_flat_v1.txt), -1 = from conv_flat_min_slabs slabs per launch on (TAPIR_CONV_FLAT / tapir_debug_set_conv_flat)
+  int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
   // workspaces
@@ -838,6 +844,9 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     g.C = c->xa.p; g.ldc = kHidden; g.M = (int)R; g.N = kHidden; g.K = c->k0_pad;
     TRY((mixer_gemm<TA, float, EPI_BIAS>(c, g, s)));
   }
+  int stage = 0;                                   // (tools/probe_two_process.py: stop behind a launch group and dump the workspaces)
+  auto stop_here = [&]() { return c->dbg_mixer_stop > 0 && ++stage >= c->dbg_mixer_stop; };
+  if (stop_here()) return TAPIR_OK;
   const int TC = pick_time_chunk(N, T);
   const int nch = (T + TC - 1) / TC;
   for (int i = 0; i < nb; ++i) {
@@ -852,17 +861,20 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     m.T = T; m.TC = TC; m.causal = c->cfg.use_causal_conv;
     { ProfScope ps(c, TAPIR_PROF_MIX, s);
       launch_mix<TA>(m, N, s); }
+    if (stop_here()) return TAPIR_OK;
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
     { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s, (c->small_gemm && gemm_small_supported<TA>(g1.M, g1.N, g1.K)) || gemm_splits<TA>(g1.M, g1.K) <= 1);
       TRY((mixer_gemm<TA, TA, EPI_BIAS_GELU>(c, g1, s))); }
+    if (stop_here()) return TAPIR_OK;
     GemmArgs g2{};
     g2.A = c->hid.p; g2.lda = kHidden4; g2.W = bw.Wdn; g2.ldw = kHidden4; g2.bias = bw.bdn;
     g2.resid = (const float*)c->xb.p; g2.ldr = kHidden;
     g2.C = c->xa.p; g2.ldc = kHidden; g2.M = (int)R; g2.N = kHidden; g2.K = kHidden4;
     { ProfScope ps(c, TAPIR_PROF_GEMM_DOWN, s, (c->small_gemm && gemm_small_supported<TA>(g2.M, g2.N, g2.K)) || gemm_splits<TA>(g2.M, g2.K) <= 1);
       TRY((mixer_gemm<TA, float, EPI_BIAS_RESID>(c, g2, s))); }
+    if (stop_here()) return TAPIR_OK;
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
@@ -1161,7 +1173,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   // the LDS image of the fused mixer kernel (128 bf16 / 64 f32 elements)
   const int kq = cfg->dtype == TAPIR_BF16 ? 128 : 64;
   c->k0_pad = (c->in_dim + kq - 1) / kq * kq;
-  // (same-box A/B of builds from outside the process: tools/ab_env.sh)
+  // (same-box A/B of builds from outside the process: environment switches)
   if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
@@ -1170,6 +1182,8 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_STREAM_OUT")) c->cv_stream_out = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));
+  if (const char* e = getenv("TAPIR_CONV_FLAT")) c->conv_flat = atoi(e) < 0 ? -1 : (atoi(e) != 0);
+  if (const char* e = getenv("TAPIR_CONV_FLAT_MIN_SLABS")) c->conv_flat_min_slabs = std::max(1, atoi(e));
   if (const char* e = getenv("TAPIR_XCONV_NT")) { const int v = atoi(e); c->xconv_nt = (v == XC_NT || v == XC_NT_WIDE) ? v : 0; }
   *out = c;
   return TAPIR_OK;
@@ -1628,6 +1642,23 @@ int tapir_conv_fused_dual_nn(tapir_ctx* c, const void* x, const float* part_in, 
                          cin, cout, 3, stride, next, stream);
 }
 
+// true: this launch takes the flat tiling (conv_flat.hpp) under the context's current mode
+static bool conv_use_flat(tapir_ctx* c, int N, int H, int W, int cin, int cout, int ks, int stride) {
+  if (c->cfg.dtype != TAPIR_BF16 || c->conv_flat == 0 || !conv_flat_supported(H, W, cin, cout, ks, stride, 2)) return false;
+  int rows = 0, tiles = 0, waves = 0;
+  conv3_plan(H, W, cin, cout, ks, stride, 2, &rows, &tiles, &waves);
+  return c->conv_flat == 1 || N * tiles >= c->conv_flat_min_slabs;
+}
+
+int tapir_conv_flat_plan(tapir_ctx* c, int N, int H, int W, int cin, int cout, int ks, int stride, int* workgroups) {
+  if (!c || !workgroups || N < 1) return TAPIR_ERR_INVALID;
+  if (!conv_use_flat(c, N, H, W, cin, cout, ks, stride)) return TAPIR_ERR_UNSUPPORTED;
+  int rows = 0, tiles = 0, waves = 0;
+  conv3_plan(H, W, cin, cout, ks, stride, 2, &rows, &tiles, &waves);
+  *workgroups = (N * tiles + CVL_SLABS - 1) / CVL_SLABS;
+  return TAPIR_OK;
+}
+
 static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, int slabs_in, int per_s_in,
                            const float* gamma, const float* beta, float* ss, const void* wstream,
                            const void* shortcut, void* y, void* y_proj, float* part_out, int N, int H, int W, int cin,
@@ -1661,7 +1692,10 @@ static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, in
     const int kind = (ks == 3 && stride == 1) ? (cin == 64 ? TAPIR_PROF_CONV3_C64 : cin == 128 ? TAPIR_PROF_CONV3_C128 : TAPIR_PROF_CONV3_C256)
                                               : TAPIR_PROF_CONV_OTHER;
     ProfScope ps(c, kind, (hipStream_t)stream);
-    if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
+    // the flat tiling of the whole launch (conv_flat.hpp) where it applies: same bits, a third of the weight traffic
+    const bool flat = conv_use_flat(c, N, H, W, cin, cout, ks, stride);
+    if (flat) launch_conv_flat(ca, (hipStream_t)stream);
+    else if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
     else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   }
   HIP_TRY(c, hipGetLastError());
@@ -1883,6 +1917,42 @@ int tapir_debug_set_mixer_mode(tapir_ctx* c, int mode) {
 #endif
   if (!c || !ok) return TAPIR_ERR_INVALID;
   c->mixer_mode = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_set_conv_flat(tapir_ctx* c, int mode) {
+  if (!c || mode < -1 || mode > 1) return TAPIR_ERR_INVALID;
+  c->conv_flat = mode;
+  return TAPIR_OK;
+}
+
+int tapir_debug_mixer_stop(tapir_ctx* c, int stages) {
+  if (!c || stages < 0) return TAPIR_ERR_INVALID;
+  c->dbg_mixer_stop = stages;
+  return TAPIR_OK;
+}
+
+int tapir_debug_workspace(tapir_ctx* c, int which, void** p, unsigned long long* bytes) {
+  if (!c || !p || !bytes) return TAPIR_ERR_INVALID;
+  DevBuf* b[] = {&c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->splitk};
+  if (which < 0 || which >= (int)(sizeof(b) / sizeof(b[0]))) return TAPIR_ERR_INVALID;
+  *p = b[which]->p; *bytes = b[which]->cap;
+  return TAPIR_OK;
+}
+
+// Fills the LDS of every CU with `pattern` (workgroups of the full 160 KiB, several per CU one after the other): what a
+// kernel reads from LDS before writing it is then the pattern, not whatever the previous workgroup on that CU left.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+  __shared__ unsigned s_all[160 * 1024 / 4];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) s_all[i] = pattern;
+  __syncthreads();
+  if (s_all[(threadIdx.x * 97 + blockIdx.x) % (160 * 1024 / 4)] != pattern) *sink = 1;   // keeps the stores alive
+}
+int tapir_debug_poison_lds(tapir_ctx* c, unsigned pattern, void* stream) {
+  if (!c) return TAPIR_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(ensure(c, c->warm_sink, 4));
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, pattern, (unsigned*)c->warm_sink.p);
   return TAPIR_OK;
 }
 

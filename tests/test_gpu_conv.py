@@ -477,3 +477,80 @@ def test_conv0_and_projection_in_one_launch_is_bit_identical(dtype, size, monkey
   for i in range(5):                                                   # (from the third call on: the captured graph, bf16)
     fg = m.get_feature_grids(video, False)
     assert torch.equal(fg.lowres[0], low0) and torch.equal(fg.hires[0], hi0), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w,shortcut', [(12, 32, 32, True), (48, 32, 32, False), (5, 32, 32, True), (7, 16, 16, True),
+                                            (3, 24, 24, False)])
+def test_flat_tiling_of_the_256_channel_convs_is_bit_identical(model, n, h, w, shortcut):
+  """csrc/conv_flat.hpp (three consecutive 64-pixel slabs of the launch's (image, row) space per workgroup) against the
+  per-image tiling (csrc/conv_fused.hpp) on the GPU: outputs, slab summaries and the in-launch merged (a, b) pairs of
+  the next norm, bit for bit -- a frame group of the headline clip (12 x 32 x 32: 64 workgroups, every fifth or sixth
+  straddling two images), the whole clip (256 workgroups), a ragged slab count, 16 x 16 maps (4-row slabs) and 24-wide
+  rows (48-pixel slabs).  resnet.py:241-256; the per-image form is held to torch above."""
+  lib, ctx = model._lib, model._ctx
+  dev, stream, c = model.device, model._stream(), 256
+  g = torch.Generator(device='cpu').manual_seed(n * 100 + h)
+  x = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.5).to(torch.bfloat16).to(dev)
+  sc = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).to(dev) if shortcut else None
+  wt = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).contiguous()
+  g0, b0 = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.3).to(dev)
+  g1, b1 = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.3).to(dev)
+  rows, tiles = ctypes.c_int(), ctypes.c_int()
+  assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+  part_in = torch.empty(n, 4, c, 2, device=dev)
+  assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, 4, stream) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
+  from tapnet_amd import _ffi
+  outs = []
+  try:
+    for mode in (0, 1):
+      assert lib.tapir_debug_set_conv_flat(ctx, mode) == 0
+      wgs = ctypes.c_int()
+      rc = lib.tapir_conv_flat_plan(ctx, n, h, w, c, c, 3, 1, ctypes.byref(wgs))
+      assert (rc == 0 and wgs.value == -(-n * tiles.value // 3)) if mode else rc == _ffi.TAPIR_ERR_UNSUPPORTED
+      for rep in range(3):     # (repeats: a torn or stale summary would change a pair)
+        y = torch.zeros(n, h, w, c, device=dev, dtype=torch.bfloat16)
+        part = torch.full((n, tiles.value, c, 2), float('nan'), device=dev)
+        ss = torch.empty(n, c, 2, device=dev)
+        ssn = torch.full((n, c, 2), float('nan'), device=dev)
+        arrive = torch.zeros(n, dtype=torch.int32, device=dev)
+        nn = _ffi.TapirNextNorm(g1.data_ptr(), b1.data_ptr(), ssn.data_ptr(), arrive.data_ptr())
+        rc = lib.tapir_conv_fused_nn(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, g0.data_ptr(), b0.data_ptr(), ss.data_ptr(),
+                                     ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(), n, h, w, c, c,
+                                     3, 1, ctypes.byref(nn), stream)
+        assert rc == 0, lib.tapir_last_error(ctx)
+        torch.cuda.synchronize()
+        assert int(arrive.abs().sum()) == 0
+        assert torch.isfinite(part).all() and torch.isfinite(ssn).all()
+        outs.append((y, part, ssn))
+  finally:
+    assert lib.tapir_debug_set_conv_flat(ctx, 0) == 0   # (the default)
+    lib.tapir_conv_free(ctx, ws)
+  for y, part, ssn in outs[1:]:
+    assert torch.equal(y, outs[0][0]) and torch.equal(part, outs[0][1]) and torch.equal(ssn, outs[0][2])
+
+
+@pytest.mark.gpu
+def test_backbone_with_the_flat_tiling_is_bit_identical(monkeypatch):
+  """A whole backbone pass (eager and the replayed hipGraph, four frame groups on four streams) with the 256-channel
+  convolutions of ResNet groups 2 and 3 in the flat tiling (incl. the dual conv_0 + proj_conv launch of group 3) against
+  TAPIR_CONV_FLAT=0: bit-identical feature grids, and a 5-frame shard of the clip equals the clip's first 5 frames."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(9, 0, False)
+  video = synthetic.make_video(10, 24, 256, 256)
+  kw = dict(pyramid_level=0, weights=w, dtype='bfloat16', device='cuda:0')
+  monkeypatch.setenv('TAPIR_CONV_FLAT', '0')
+  ref_model = tapir_model.TAPIR(**kw)
+  fg0 = ref_model.get_feature_grids(video, False)
+  low0, hi0 = fg0.lowres[0].clone(), fg0.hires[0].clone()
+  monkeypatch.setenv('TAPIR_CONV_FLAT', '1')
+  m = tapir_model.TAPIR(**kw)
+  wgs = ctypes.c_int()
+  assert m._lib.tapir_conv_flat_plan(m._ctx, 6, 32, 32, 256, 256, 3, 1, ctypes.byref(wgs)) == 0 and wgs.value == 32
+  for i in range(5):
+    fg = m.get_feature_grids(video, False)
+    assert torch.equal(fg.lowres[0], low0) and torch.equal(fg.hires[0], hi0), i
+  fg5 = m.get_feature_grids(video[:, :5], False)
+  assert torch.equal(fg5.lowres[0], low0[:, :5]) and torch.equal(fg5.hires[0], hi0[:, :5])

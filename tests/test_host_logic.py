@@ -237,3 +237,23 @@ def test_bench_roofline_all_prices_every_kernel_class():
   for k, v in ra.items():
     assert v['bound'] in ('mfma', 'hbm') and 0 < v['frac'] < 1.2 and v['peak'] in (2500.0, 8000.0), (k, v)
   assert ra['stem']['bytes'] == T * S * S * 3 * 4 + T * 128 * 128 * 64 * 2
+
+
+def test_the_built_library_has_no_high_half_selects_on_packed_f32_arithmetic():
+  """csrc/check_packed_forms.py on the shipped library: no `v_pk_{fma,mul,add}_f32 ... op_sel:[` in the gfx950 code object.
+  On MI355X that form loses its low result in lanes 48-63 next to another wave's MFMAs (tools/micro/run_cotenant_repro.py,
+  profiles/r06_cotenant_repro.txt); the build drops hipcc's SLP pass, the only source of it."""
+  import importlib.util
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  lib = os.path.join(root, 'tapnet_amd', 'csrc', 'libtapir_hip.so')
+  if not os.path.exists(lib):
+    pytest.skip('library not built')
+  spec = importlib.util.spec_from_file_location('check_packed_forms', os.path.join(root, 'tapnet_amd', 'csrc', 'check_packed_forms.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  res = mod.scan(lib)
+  if res is None:
+    pytest.skip('llvm-objdump not installed')
+  packed, bad = res
+  assert packed > 10000, packed          # (the hand-packed kernels are there)
+  assert not bad, bad

@@ -601,6 +601,46 @@ def trace_conv(model):
       print(f'  {nm:32s} {t[:, :, k].mean():9.0f} cycles {100 * t[:, :, k].mean() / tot:5.1f} %   waves min/max {pw.min():.0f}/{pw.max():.0f}')
 
 
+def trace_conv_flat(model):
+  """per-phase shader-cycle totals of the flat-tiled 256-channel convolution (conv_flat.hpp; -DTAPIR_EXPERIMENTS library)"""
+  lib, ctx = model._lib, model._ctx
+  dev, stream, c, h, w = model.device, model._stream(), 256, 32, 32
+  names = ['stage tile (norm+relu -> LDS)', 'barrier (tile visible)', 'k loop (9 taps)', 'barrier (tile free)', 'epilogue (store, stats, merge)']
+  assert lib.tapir_debug_set_conv_flat(ctx, 1) == 0
+  for n in (6, 12, 48):
+    rows, tiles = ctypes.c_int(), ctypes.c_int()
+    assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    x = (torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16)
+    sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+    wh = (torch.randn(c, c, 3, 3) / (9 * c) ** 0.5).contiguous()
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+    part_in = torch.empty(n, 4, c, 2, device=dev)
+    part_out = torch.empty(n, tiles.value, c, 2, device=dev)
+    ss = torch.empty(n, c, 2, device=dev)
+    y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    ws = ctypes.c_void_p()
+    assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wh.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
+    assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, 4, stream) == 0
+    nwg = -(-n * tiles.value // 3)
+    buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+    for it in range(3):
+      buf.zero_()
+      assert lib.tapir_debug_set_trace(ctx, ctypes.c_void_p(buf.data_ptr())) == 0
+      assert lib.tapir_conv_fused(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(), ss.data_ptr(), ws,
+                                  sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c, c, 3, 1, stream) == 0
+      torch.cuda.synchronize()
+    lib.tapir_debug_set_trace(ctx, None)
+    t = buf.view(nwg, 8, 8).double().cpu().numpy()
+    tot = t.sum(-1).mean()
+    print(f'conv3x3 FLAT phase trace, [{n},{h},{w},{c}] ({nwg} workgroups of 3 slabs = 192 pixels, 8 waves): mean shader cycles per wave '
+          f'{tot:.0f}; MFMA floor {2.0 * 192 * 9 * c * c / 4069:.0f} cycles per workgroup')
+    for k, nm in enumerate(names):
+      pw = t[:, :, k].mean(0)
+      print(f'  {nm:32s} {t[:, :, k].mean():9.0f} cycles {100 * t[:, :, k].mean() / tot:5.1f} %   waves min/max {pw.min():.0f}/{pw.max():.0f}')
+    lib.tapir_conv_free(ctx, ws)
+  assert lib.tapir_debug_set_conv_flat(ctx, -1) == 0
+
+
 def bench_conv(model, reps, results):
   """the fused 3x3 backbone convolution (conv_fused.hpp) against the launches it replaces: finalize +
   normalise/ReLU kernel, the MIOpen convolution, the statistics (+ residual add) kernel"""
@@ -659,6 +699,59 @@ def bench_conv(model, reps, results):
       print(json.dumps(row), flush=True)
 
 
+def bench_conv_flat(model, reps, results):
+  """the flat tiling of the 3x3 256 -> 256 block convolutions (conv_flat.hpp) against the per-image tiling
+  (conv_fused.hpp), alternated in one process: a frame group (12 frames), half a clip, the whole clip, and the dual
+  conv_0 + proj_conv launch; bit-identity of the two outputs is checked on the way"""
+  lib, ctx = model._lib, model._ctx
+  dev, stream, c, h, w = model.device, model._stream(), 256, 32, 32
+  for n in (6, 12, 24, 48, 96):
+    rows, tiles = ctypes.c_int(), ctypes.c_int()
+    assert lib.tapir_conv_plan(ctx, h, w, c, c, 3, 1, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+    x = [(torch.randn(n, h, w, c, device=dev) * 1.5 + 0.5).to(torch.bfloat16) for _ in range(3)]
+    sc = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+    wt = (torch.randn(c, c, 3, 3) / (9 * c) ** 0.5).contiguous()
+    w1 = (torch.randn(c, c, 1, 1) / c ** 0.5).contiguous()
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+    part_in = torch.empty(n, 4, c, 2, device=dev)
+    part_out = torch.empty(n, tiles.value, c, 2, device=dev)
+    ss, ssn = torch.empty(n, c, 2, device=dev), torch.empty(n, c, 2, device=dev)
+    arrive = torch.zeros(n, dtype=torch.int32, device=dev)
+    y = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    yp = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    ws, wsd = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), c, c, 3, ctypes.byref(ws)) == 0
+    assert lib.tapir_conv_pack_dual(ctx, ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(w1.data_ptr()), c, c, 1, ctypes.byref(wsd)) == 0
+    assert lib.tapir_inorm_stats(ctx, x[0].data_ptr(), None, None, part_in.data_ptr(), n, h * w, c, 4, stream) == 0
+    nn = _ffi.TapirNextNorm(gamma.data_ptr(), beta.data_ptr(), ssn.data_ptr(), arrive.data_ptr())
+    def plain(i):
+      assert lib.tapir_conv_fused_nn(ctx, x[i % 3].data_ptr(), None, 4, 0, gamma.data_ptr(), beta.data_ptr(), ss.data_ptr(), ws,
+                                     sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c, c, 3, 1, ctypes.byref(nn), stream) == 0
+    def dual(i):
+      assert lib.tapir_conv_fused_dual_nn(ctx, x[i % 3].data_ptr(), None, 4, 0, gamma.data_ptr(), beta.data_ptr(), ss.data_ptr(), wsd,
+                                          y.data_ptr(), yp.data_ptr(), part_out.data_ptr(), n, h, w, c, c, 1, ctypes.byref(nn), stream) == 0
+    # (a, b) pairs once (part_in NULL afterwards: the launch alone is timed)
+    assert lib.tapir_conv_fused_nn(ctx, x[0].data_ptr(), part_in.data_ptr(), 4, 0, gamma.data_ptr(), beta.data_ptr(), ss.data_ptr(), ws,
+                                   sc.data_ptr(), y.data_ptr(), part_out.data_ptr(), n, h, w, c, c, 3, 1, ctypes.byref(nn), stream) == 0
+    flops = 2.0 * n * h * w * c * c * 9
+    for name, fn, fl in (('conv3x3_c256+shortcut', plain, flops), ('conv3x3_c256+proj (dual)', dual, flops * 10 / 9)):
+      ref = None
+      for rep in range(2):
+        for mode, form in ((0, 'per-image tiles'), (1, 'flat')):
+          assert lib.tapir_debug_set_conv_flat(ctx, mode) == 0
+          fn(0); torch.cuda.synchronize()
+          if ref is None:
+            ref = (y.clone(), part_out.clone(), ssn.clone())
+          same = bool(torch.equal(y, ref[0]) and torch.equal(part_out, ref[1]) and torch.equal(ssn, ref[2]))
+          t = timeit(fn, reps)
+          row = dict(kernel=name, form=form, shape=[n, h, w, c], rep=rep, **t, tflops=round(fl / (t['med_us'] * 1e-6) / 1e12, 1),
+                     frac_of_bf16_peak=round(fl / (t['med_us'] * 1e-6) / 2.5e15, 3), bit_identical_to_first=same)
+          results.append(row)
+          print(json.dumps(row), flush=True)
+    assert lib.tapir_debug_set_conv_flat(ctx, -1) == 0
+    lib.tapir_conv_free(ctx, ws); lib.tapir_conv_free(ctx, wsd)
+
+
 def bench_backbone(model, reps, results):
   if os.environ.get('TAPIR_CUDNN_BENCHMARK'):
     torch.backends.cudnn.benchmark = os.environ['TAPIR_CUDNN_BENCHMARK'] == '1'
@@ -704,6 +797,10 @@ def main():
       bench_norm(model, args.reps, results)
     if 'cv' in what:
       bench_cv(model, args.reps, results)
+    if 'convflattrace' in what:
+      trace_conv_flat(model)
+    if 'convflat' in what:
+      bench_conv_flat(model, args.reps, results)
     if 'conv' in what:
       bench_conv(model, args.reps, results)
     if 'convtrace' in what:
