@@ -711,6 +711,7 @@ def main():
   # over xGMI -> query-sharded hot path), the strong-scaling view of the same workload
   sharded = None
   if world > 1 and args.shard == 'clips':
+   try:   # (an extra view: a failure here -- the RCCL data path has never met hardware -- must not cost the headline line)
     import torch.distributed as dist
     v1 = torch.as_tensor(synthetic.make_video(1, T, S, S), device=dev)
     q1 = torch.as_tensor(synthetic.make_queries(101, Q, T, S, S), device=dev)
@@ -731,6 +732,9 @@ def main():
                              f'tile order, hi-res row-major: bf16 on the wire, no re-cast on the ranks), outputs gathered'
                              if wire == 2 else 'all_gather_into_tensor of lowres+hires grids along T (f32 on the wire), outputs gathered'),
                    exchange_bytes=int(T * (lowres_copies * (S // 8) ** 2 * 256 + (S // 4) ** 2 * 128) * wire))
+   except Exception as e:
+    sharded = dict(error=f'{type(e).__name__}: {e}')
+    print(f'bench: the sharded (strong-scaling) leg failed on rank {rank}: {sharded["error"]}', file=sys.stderr)
 
   # hot path only (feature grids precomputed): R8 + R1
   fg = model.get_feature_grids(video)
@@ -811,7 +815,7 @@ def main():
     # the committed counter passes of THIS workload and names the artefact
     traffic, traffic_src = None, None
     if (args.model, T, Q, S, args.dtype, world) == ('tapir', 48, 256, 256, 'bf16', 1):
-      for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+      for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
           try:

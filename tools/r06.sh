@@ -129,6 +129,15 @@ if [ "$PART" == "abslp" ]; then
   TAPIR_HIP_LIB=$R/tools/libtapir_hip_slp.so timeout 300 python tools/bench_online.py --frames 60 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/slp   /' | tee -a $OUT/ab_slp_summary.txt
   timeout 300 python tools/bench_online.py --frames 60 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/noslp /' | tee -a $OUT/ab_slp_summary.txt
 fi
+if [ "$PART" == "fusepatch" ]; then
+  timeout 300 python -m pytest tests/test_gpu_distributed.py -q -x -k "staged" 2>&1 | tail -3 | tee $OUT/pytest_staged.log
+  B="python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline --no-secondary"
+  for rep in 1 2 3; do
+    TAPIR_FUSE_PATCH=0 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_fp_off_$rep.json
+    TAPIR_FUSE_PATCH=1 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_fp_on_$rep.json
+  done
+  summ $OUT/ab_fp_*.json | tee $OUT/ab_fusepatch_summary.txt
+fi
 if [ "$PART" == "timeline" ]; then
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace -d $R/$OUT/prof_tl -o bench -- python $R/bench.py --steps 12 --warmup 4 --no-accuracy --no-cpu-baseline --no-secondary > $R/$OUT/bench_under_trace.json 2> $R/$OUT/rocprof_tl.err
