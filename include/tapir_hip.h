@@ -301,6 +301,14 @@ typedef struct tapir_next_norm {
   int* arrive;          /* [N] arrival counters */
 } tapir_next_norm;
 int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles);
+/* Few-frame clips (the online model's single frame: tapnet/live_demo.py:51-77, tapir_model.py:1156-1203; bf16 contexts):
+ * on = 1 makes tapir_conv_fused* take the K-split form of csrc/conv_small.hpp -- a workgroup per (tile of whole rows <= 128
+ * pixels, group of 64 output channels), its four waves splitting the taps -- and tapir_conv_plan answer with THAT form's tile
+ * geometry, for every shape the form covers (output rows of <= 128 pixels); 0 (default) = the many-frame kernels.  The forms
+ * differ in summation order (not bit-identical): set it from the frame count of the WHOLE clip (tapnet_amd.backbone: clips of
+ * fewer than 4 frames), never per shard or chunk, and plan / allocate the summaries after setting it.  The dual launch
+ * (tapir_conv_fused_dual_nn) has no few-frame form and returns TAPIR_ERR_UNSUPPORTED while the mode is on. */
+int tapir_conv_set_small(tapir_ctx* ctx, int on);
 int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);
 int tapir_conv_free(tapir_ctx* ctx, void* wstream);
 int tapir_conv_fused(tapir_ctx* ctx, const void* x, const float* part_in, int slabs_in, int per_s_in,

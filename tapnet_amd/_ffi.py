@@ -94,6 +94,7 @@ PROTOTYPES = {
     'tapir_set_staged_grid': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'tapir_clear_staged_grids': (c_int, [c_void_p]),
     'tapir_conv_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tapir_conv_set_small': (c_int, [c_void_p, c_int]),
     'tapir_conv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     'tapir_conv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

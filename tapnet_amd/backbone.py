@@ -92,6 +92,12 @@ class Backbone:
     if os.environ.get('TAPIR_HIP_MIN_FRAMES'):   # (A/B measurements of the online step: 1 = the HIP convolutions for a single frame too)
       self.hip_min_frames = int(os.environ['TAPIR_HIP_MIN_FRAMES'])
     self._hip_now = False
+    # clips of fewer than `small_max_frames` frames (the online model's single frame): the K-split form of the block
+    # convolutions (csrc/conv_small.hpp) instead of the library's kernels + glue; decided per features() call from the
+    # WHOLE clip like _hip_now (the two HIP forms differ in summation order).  TAPIR_CONV_SMALL=0: off (A/B)
+    self.small_convs = dtype == torch.bfloat16 and os.environ.get('TAPIR_CONV_SMALL', '1') != '0'
+    self.small_max_frames = 4
+    self._small_now = False
     self._clip_frames = 0       # frames of the whole clip of the current features() call (kernel choices follow it, never a shard)
     # which kinds of block convolution take the HIP kernel in 'auto' mode (the others stay on MIOpen)
     self.hip_convs = {'stem', 'conv_0', 'conv_1', 'conv_0_s2', 'proj_conv', 'proj_conv_s2'}
@@ -188,19 +194,22 @@ class Backbone:
            'kernels (InstanceNorm+ReLU in the operand load, residual add + next-norm statistics in the epilogue' +
            (', the next norm\'s (a, b) pairs merged by the last-arriving workgroup of each image), HIP L2-normalise kernel'
             if self.fuse_finalize else '), HIP finalize / L2-normalise kernels') +
-           ('; conv_0 + proj_conv of a group\'s first block in one launch' if (self.fuse_proj and self._wdual) else ''))
+           ('; conv_0 + proj_conv of a group\'s first block in one launch'
+            if (self.fuse_proj and self._wdual and not self._small_ok(frames)) else '') +
+           ('; few-frame form of the block convolutions: a workgroup per (row tile, 64 output channels), the waves split the taps'
+            if self._small_ok(frames) else ''))
     elif hip:
       s = 'HIP fused convolutions except ' + ', '.join(missing or ['(unpacked shapes)']) + ' (MIOpen) + HIP norm kernels'
     else:
       s = 'MIOpen convolutions + HIP InstanceNorm / add / L2 kernels'
     if self.extra_convs:
-      s += '; ExtraConvs: ' + self._extra_convs_impl()
+      s += '; ExtraConvs: ' + self._extra_convs_impl(hip)
     if self.graph_min_frames and frames >= self.graph_min_frames:
       s += f'; {max(1, min(int(self.streams), frames // 8))} streams, hipGraph replay'
     return s
 
-  def _extra_convs_impl(self) -> str:
-    if self.extra_convs_mode == 'hip' and self._xhost:
+  def _extra_convs_impl(self, hip=True) -> str:
+    if hip and self.extra_convs_mode == 'hip' and self._xhost:
       return ('HIP: LayerNorm kernel + 3x3 implicit-GEMM MFMA kernels (256 -> 1024 with bias + GELU, 1024 -> 256 '
               'with bias + skip in the epilogue)')
     return 'PyTorch-ROCm / MIOpen convolutions + torch LayerNorm / GELU'
@@ -349,7 +358,7 @@ class Backbone:
   # -- the block convolutions: one HIP kernel each (csrc/conv_fused.hpp) ------------------------------
   def _plan(self, h, w, cin, cout, ks, stride):
     """(rows per tile, tiles per image) of the fused convolution, or None: that shape stays on MIOpen."""
-    key = (h, w, cin, cout, ks, stride)
+    key = (self._small_now, h, w, cin, cout, ks, stride)   # (the few-frame form has its own tile geometry)
     if key not in self._plans:
       import ctypes
       lib, ctx = self.engine
@@ -364,7 +373,10 @@ class Backbone:
     once per features() call from the whole clip (`global_frames` when the clip is sharded over ranks,
     tapnet_amd.distributed), never per group of frames: a short last chunk or a small frame shard must
     run the same kernels as the rest of the clip, or sharded and unsharded results differ by rounding."""
-    return self.conv_mode == 'hip' or (self.conv_mode == 'auto' and n >= self.hip_min_frames)
+    return self.conv_mode == 'hip' or (self.conv_mode == 'auto' and (n >= self.hip_min_frames or self._small_ok(n)))
+
+  def _small_ok(self, n):
+    return bool(self.small_convs and self.engine is not None and n < self.small_max_frames and self.conv_mode != 'miopen')
 
   def _fusable(self, conv_name, h, w, stride):
     kind = conv_name.rsplit('.', 1)[-1] + ('_s2' if stride == 2 else '')
@@ -444,7 +456,7 @@ class Backbone:
     if not f0 or (use_projection and not fp):
       y, ysub = self._hip_norm_relu(x, st, p + 'bn_0', tag + 'a', pad=strided, sub=strided)
     shortcut = x
-    if (use_projection and f0 and fp and self.fuse_proj and p in self._wdual and self._wdual[p][3] == stride
+    if (use_projection and f0 and fp and self.fuse_proj and not self._small_now and p in self._wdual and self._wdual[p][3] == stride
         and self._fusable(p + 'conv_1', -(-h // stride), -(-w // stride), 1)):
       y0, shortcut, st0 = self._fused_conv_dual(x, st, p, tag, stride, next_norm=p + 'bn_1')
       return self._fused_conv(y0, st0, p + 'bn_1', p + 'conv_1', shortcut, tag + f'r{parity}', next_norm=next_norm)
@@ -532,6 +544,7 @@ class Backbone:
     if self.extra_convs:
       # (like the ResNet convolutions: a single frame -- the online model -- gives the HIP kernels 16-64
       # workgroups per launch; the library's split-K kernels win there)
+      # (few-frame clips: the 256 -> 1024 convolution takes the few-frame form inside tapir_xconv_nt, csrc/conv_small.hpp)
       xe = self._extra_convs_hip(x) if (self.extra_convs_mode == 'hip' and self._hip_now) else None
       x = xe if xe is not None else self._extra_convs(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
     if staged is not None:
@@ -556,6 +569,10 @@ class Backbone:
     self.last_staged = None   # borrow=True, bf16 engine: (low16, low_tiled, hi16) written next to the returned f32 grids
     self._clip_frames = max(n, int(global_frames or 0))
     self._hip_now = self._use_hip_convs(self._clip_frames)
+    small = self._hip_now and self._small_ok(self._clip_frames)
+    if self.engine is not None and (small or self._small_now):
+      self._check(self.engine[0].tapir_conv_set_small(self.engine[1], int(small)), 'tapir_conv_set_small')
+    self._small_now = small
     half = lambda v: -(-v // 2)
     last = lambda g: f'resnet_torch.block_groups.{g}.blocks.{self.blocks_per_group[g] - 1}.conv_1.weight'
     c_low = self.w[last(3)].shape[0]
@@ -581,7 +598,7 @@ class Backbone:
       per = -(-n // groups)
       bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
     key = (n, self._clip_frames, H, W, self._hip_now, tuple(sorted(self.hip_convs)), self.extra_convs_mode, streams, tuple(bounds),
-           bool(self.fuse_proj), bool(self.fuse_finalize), self.conv_mode)   # (everything that changes WHICH kernels a pass launches)
+           bool(self.fuse_proj), bool(self.fuse_finalize), self.conv_mode, self._small_now)   # (everything that changes WHICH kernels a pass launches)
     if chunk or os.environ.get('TAPIR_BACKBONE_GRAPH', '1') == '0':   # (chunked: see above; profilers that need
       key = None                                                       #  every dispatch on its own)
     if (key is not None and self.graph_min_frames and n >= self.graph_min_frames

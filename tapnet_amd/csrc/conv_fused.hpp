@@ -67,6 +67,7 @@ struct Conv3Args {
   int pad_y, pad_x;       // SAME padding on the low side
   int TH, tiles;          // output rows per tile, tiles per image = ceil(Ho / TH)
   int waves;              // 4 or 8 (conv3_plan)
+  int cin_total;          // conv_small.hpp MODE 2 only: input channels in memory (chunks of CIN); 0 elsewhere
   long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
   FinArgs fin;
 };

@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "conv_fused.hpp"
 #include "conv_flat.hpp"
+#include "conv_small.hpp"
 #include "costvol.hpp"
 #include "costvol_fused.hpp"
 #include "costvol_rows.hpp"
@@ -94,6 +95,8 @@ struct tapir_ctx {
   int conv_flat = 0;                              // 3x3 256 -> 256 block convolutions: 1 = the flat tiling (conv_flat.hpp) wherever it applies, 0 = never (default:
                                                   // faster as a single 48-frame launch, 74 vs 87 us, slower inside the 4-stream backbone, 4.60 vs 4.51 ms per step:
                                                   // profiles/r06_ab_flat_v1.txt), -1 = from conv_flat_min_slabs slabs per launch on (TAPIR_CONV_FLAT / tapir_debug_set_conv_flat)
+  int conv_small = 0;                             // block convolutions of FEW-frame clips (the online model): 1 = conv_small_kernel (conv_small.hpp) where the shape
+                                                  // allows it; set per clip by the caller's backbone (tapir_conv_set_small), follows the WHOLE clip's frame count
   int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
   int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
 
@@ -1528,7 +1531,15 @@ int tapir_l2_normalize_staged(tapir_ctx* c, const void* x, float* out, void* out
 int tapir_conv_plan(tapir_ctx* c, int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles) {
   if (!c || !rows || !tiles) return TAPIR_ERR_INVALID;
   const int es = c->cfg.dtype == TAPIR_BF16 ? 2 : 4;
+  int nt = 0;
+  if (c->conv_small && es == 2 && conv_small_plan(H, W, cin, cout, ks, stride, rows, tiles, &nt)) return TAPIR_OK;   // (few-frame form)
   if (!conv3_plan(H, W, cin, cout, ks, stride, es, rows, tiles)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
+  return TAPIR_OK;
+}
+
+int tapir_conv_set_small(tapir_ctx* c, int on) {
+  if (!c || on < 0 || on > 1) return TAPIR_ERR_INVALID;
+  c->conv_small = on;
   return TAPIR_OK;
 }
 
@@ -1672,8 +1683,12 @@ static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, in
     return fail(c, TAPIR_ERR_INVALID, "bad argument");
   if (shortcut && !(ks == 3 && stride == 1)) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shortcut on a 3x3 stride-1 convolution only");
   const bool bf = c->cfg.dtype == TAPIR_BF16;
-  int rows = 0, tiles = 0, waves = 0;
-  if (!conv3_plan(H, W, cin, cout, ks, stride, bf ? 2 : 4, &rows, &tiles, &waves))
+  int rows = 0, tiles = 0, waves = 0, nt_small = 0;
+  // few-frame clips (tapir_conv_set_small): the K-split form of conv_small.hpp, with ITS tile geometry (tapir_conv_plan
+  // answers accordingly while the mode is on)
+  const bool small = bf && c->conv_small && conv_small_plan(H, W, cin, cout, ks, stride, &rows, &tiles, &nt_small);
+  if (small && y_proj) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: the dual launch has no few-frame form (launch conv_0 and proj_conv separately)");
+  if (!small && !conv3_plan(H, W, cin, cout, ks, stride, bf ? 2 : 4, &rows, &tiles, &waves))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
   if (part_in != nullptr) {
     NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, bf ? 8 : 4};
@@ -1693,8 +1708,9 @@ static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, in
                                               : TAPIR_PROF_CONV_OTHER;
     ProfScope ps(c, kind, (hipStream_t)stream);
     // the flat tiling of the whole launch (conv_flat.hpp) where it applies: same bits, a third of the weight traffic
-    const bool flat = conv_use_flat(c, N, H, W, cin, cout, ks, stride);
-    if (flat) launch_conv_flat(ca, (hipStream_t)stream);
+    const bool flat = !small && conv_use_flat(c, N, H, W, cin, cout, ks, stride);
+    if (small) launch_conv_small(ca, cin, cout, ks, stride, nt_small, (hipStream_t)stream);
+    else if (flat) launch_conv_flat(ca, (hipStream_t)stream);
     else if (bf) launch_conv_fused<bf16_t>(ca, cin, cout, ks, stride, (hipStream_t)stream);
     else launch_conv_fused<float>(ca, cin, cout, ks, stride, (hipStream_t)stream);
   }
@@ -1786,6 +1802,31 @@ int tapir_xconv_nt(tapir_ctx* c, const void* x, const void* wstream, const float
   const bool bf = c->cfg.dtype == TAPIR_BF16;
   int rows = 0, tiles = 0, cch = 0, nt = 0;
   if (!xconv_plan(H, W, cin, cout, bf ? 2 : 4, &rows, &tiles, &cch, &nt, form ? form : c->xconv_nt)) return fail(c, TAPIR_ERR_UNSUPPORTED, "xconv: shape");
+  // few-frame clips (tapir_conv_set_small): both convolutions of a block in the K-split form of conv_small.hpp -- a workgroup
+  // per (row tile, 16 output channels): one frame gives xconv_kernel 64 / 16 workgroups that each stream 1.18 / 4.7 MB of cold
+  // weights through a 12-fragment ring, 28 / 93 us per launch (profiles/r06_online_timeline_v1.txt).  Needs packs for
+  // 256-channel chunks (the fragment order is then the block convolutions': [chunk] tap, k-step, row tile)
+  if (bf && c->conv_small && cch == 256 && ((gelu && !skip && cin == 256 && cout == 1024) || (!gelu && skip && cin == 1024 && cout == 256))) {
+    auto it = c->xconv_cch.find(wstream);
+    int srows = 0, stiles = 0, snt = 0;
+    if (it != c->xconv_cch.end() && it->second == 256 && W <= 128 && H >= 1) {
+      // conv_small_plan's geometry for a 3x3 / stride-1 map (it checks the channel counts of the BLOCK convolutions: restated)
+      int th = W <= 64 ? 64 / W : 1;
+      if (th > H) th = H;
+      while (th >= 1 && (long)(th + 2) * (W + 2) * 256 * 2 > CVS_LDS_BYTES) --th;
+      if (th >= 1) { srows = th; stiles = (H + th - 1) / th; snt = th * W <= 64 ? 4 : 8; }
+    }
+    if (srows > 0) {
+      Conv3Args ca{};
+      ca.x = x; ca.ss = bias; ca.wstream = (const uint4*)wstream; ca.frags_per_cg = xconv_frags_per_cg(cin, 32);
+      ca.y = y; ca.N = N; ca.H = H; ca.W = W; ca.Ho = H; ca.Wo = W; ca.pad_y = 1; ca.pad_x = 1; ca.TH = srows; ca.tiles = stiles;
+      ca.shortcut = skip; ca.cin_total = cin;
+      if (launch_xconv_small(ca, cin, cout, snt, (hipStream_t)stream)) {
+        HIP_TRY(c, hipGetLastError());
+        return TAPIR_OK;
+      }
+    }
+  }
   {
     // the stream is packed for ONE chunk width ([chunk][tap][k-step][row tile]): a pack made for another map
     // width would be multiplied in the wrong order

@@ -109,6 +109,53 @@ def test_xconv_up_gelu_and_down_skip(dtype, H, W, nt, monkeypatch):
   lib.tapir_destroy(ctx)
 
 
+@pytest.mark.parametrize('H,W', [(4, 32), (5, 16), (2, 64), (3, 40)])
+def test_xconv_up_gelu_in_the_few_frame_form(H, W, monkeypatch):
+  """tapir_conv_set_small (clips of fewer than 4 frames: the online model): the 256 -> 1024 convolution with bias + GELU
+  in the form of csrc/conv_small.hpp (a workgroup per (row tile, 16 output channels), the waves split the taps) against
+  numpy and against xconv_kernel on the same operands (same values up to the summation order).  tapir_model.py:183-184."""
+  lib = emu_lib()
+  monkeypatch.setenv('TAPIR_XCONV_NT', '4')        # the form short clips take (tapir_xconv_plan_frames)
+  ctx = _ctx(lib, _ffi.TAPIR_BF16)
+  rng = np.random.default_rng(H * 100 + W + 1)
+  N, C = 2, 256
+  x = _r(rng.standard_normal((N, H, W, C)))
+  w1 = (rng.standard_normal((4 * C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+  b1 = (rng.standard_normal(4 * C) * 0.1).astype(np.float32)
+  big, _, _, cch = _xconv(lib, ctx, True, x, w1, b1, None, True)
+  assert cch == (256 if W <= 32 or W == 40 else 128)   # (64-wide maps: the 64-pixel tile holds 128-channel chunks only)
+  assert lib.tapir_conv_set_small(ctx, 1) == 0
+  try:
+    got, _, _, _ = _xconv(lib, ctx, True, x, w1, b1, None, True)
+  finally:
+    assert lib.tapir_conv_set_small(ctx, 0) == 0
+  ref = _gelu(_conv_ref(x, _r(w1)) + b1)
+  np.testing.assert_allclose(got, ref, atol=1.5e-2, rtol=1e-2)
+  assert np.abs(got - ref).mean() < 2e-3
+  d = np.abs(got - big)
+  if cch == 256:
+    assert d.max() <= 2e-2 and 0 < (d > 0).mean() < 0.05, (d.max(), (d > 0).mean())   # (> 0: the other kernel really ran)
+  else:
+    assert d.max() == 0      # packs for narrower chunks stay with xconv_kernel
+  # the block's second convolution (1024 -> 256, + bias + skip: four input-channel chunks) in the same form
+  hdn = _r(ref)
+  w2 = (rng.standard_normal((C, 4 * C, 3, 3)) / np.sqrt(9 * 4 * C)).astype(np.float32)
+  b2 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+  big2, _, _, cch2 = _xconv(lib, ctx, True, hdn, w2, b2, x, False)
+  ref2 = _conv_ref(hdn, _r(w2)) + b2 + x
+  if cch2 == 256:     # (maps whose 64-pixel tile holds 256-channel chunks: the few-frame form applies)
+    assert lib.tapir_conv_set_small(ctx, 1) == 0
+    try:
+      got2, _, _, _ = _xconv(lib, ctx, True, hdn, w2, b2, x, False)
+    finally:
+      assert lib.tapir_conv_set_small(ctx, 0) == 0
+    np.testing.assert_allclose(got2, ref2, atol=2e-2, rtol=1e-2)
+    assert np.abs(got2 - ref2).mean() < 3e-3
+    d2 = np.abs(got2 - big2)
+    assert d2.max() <= 4e-2 and 0 < (d2 > 0).mean() < 0.08, (d2.max(), (d2 > 0).mean())
+  lib.tapir_destroy(ctx)
+
+
 def test_xconv_rejects_unsupported_shapes():
   lib = emu_lib()
   ctx = _ctx(lib)

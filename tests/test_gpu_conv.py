@@ -268,9 +268,11 @@ def test_backbone_graph_replay_and_streams_match_eager(model):
     bb.graph_min_frames, bb.streams = saved
 
 
-@pytest.mark.parametrize('dtype,n,h,w', [('float32', 2, 32, 32), ('bfloat16', 3, 32, 32), ('float32', 1, 64, 64),
-                                         ('bfloat16', 2, 64, 64), ('bfloat16', 2, 24, 32)])
-def test_extra_convs_block_vs_torch(dtype, n, h, w):
+@pytest.mark.parametrize('dtype,n,h,w,small', [('float32', 2, 32, 32, 0), ('bfloat16', 3, 32, 32, 0), ('float32', 1, 64, 64, 0),
+                                               ('bfloat16', 2, 64, 64, 0), ('bfloat16', 2, 24, 32, 0),
+                                               # few-frame clips (tapir_conv_set_small): 256 -> 1024 in the form of csrc/conv_small.hpp
+                                               ('bfloat16', 1, 32, 32, 1), ('bfloat16', 2, 24, 40, 1), ('bfloat16', 1, 64, 64, 1)])
+def test_extra_convs_block_vs_torch(dtype, n, h, w, small):
   """One ExtraConvs block (tapir_model.py:159-186) through the C ABI -- tapir_layernorm_affine, tapir_xconv
   256 -> 1024 (+ bias + GELU), tapir_xconv 1024 -> 256 (+ bias + skip) -- against torch float64 on the same
   operands (bf16 build: operands and stored intermediates rounded to bf16 as the kernels round them)."""
@@ -279,6 +281,7 @@ def test_extra_convs_block_vs_torch(dtype, n, h, w):
   m = tapir_model.TAPIR(pyramid_level=1, extra_convs=False, weights=synthetic.make_weights(21, 1, False, backbone=False),
                         device='cuda:0', dtype=dtype)
   lib, ctx, dev, st = m._lib, m._ctx, m.device, m._stream()
+  assert lib.tapir_conv_set_small(ctx, small) == 0     # (a fresh context per case: nothing to restore)
   tt = torch.bfloat16 if bf else torch.float32
   g = torch.Generator(device='cpu').manual_seed(h + w + n)
   C = 256
@@ -531,6 +534,65 @@ def test_flat_tiling_of_the_256_channel_convs_is_bit_identical(model, n, h, w, s
   for y, part, ssn in outs[1:]:
     assert torch.equal(y, outs[0][0]) and torch.equal(part, outs[0][1]) and torch.equal(ssn, outs[0][2])
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w,cin,cout,ks,stride,shortcut', [
+    (1, 128, 128, 64, 64, 3, 1, True), (1, 64, 64, 128, 128, 3, 1, True), (1, 32, 32, 256, 256, 3, 1, True),
+    (3, 32, 32, 256, 256, 3, 1, False), (1, 128, 128, 64, 128, 3, 2, False), (1, 64, 64, 128, 256, 3, 2, False),
+    (1, 128, 128, 64, 128, 1, 2, False), (1, 32, 32, 256, 256, 1, 1, False), (2, 24, 40, 256, 256, 3, 1, True)])
+def test_few_frame_form_of_the_block_convs_matches_the_many_frame_kernel(model, n, h, w, cin, cout, ks, stride, shortcut):
+  """csrc/conv_small.hpp (a workgroup per (row tile, 64 output channels), the waves split the taps) against
+  csrc/conv_fused.hpp on the GPU, the layers of ONE 256 x 256 frame (the online model, tapnet/live_demo.py:51-77) and a
+  non-square map: outputs equal up to the summation order (a bf16 step on a few values), the in-launch merged (a, b) pairs
+  of the next norm agree to f32 noise, counters back at zero, repeatable bit for bit.  resnet.py:241-256."""
+  lib, ctx = model._lib, model._ctx
+  dev, stream = model.device, model._stream()
+  g = torch.Generator(device='cpu').manual_seed(n * 100 + h + cin + ks)
+  ho, wo = -(-h // stride), -(-w // stride)
+  x = (torch.randn(n, h, w, cin, generator=g) * 1.5 + 0.5).to(torch.bfloat16).to(dev)
+  sc = torch.randn(n, ho, wo, cout, generator=g).to(torch.bfloat16).to(dev) if shortcut else None
+  wt = (torch.randn(cout, cin, ks, ks, generator=g) / (ks * ks * cin) ** 0.5).contiguous()
+  g0, b0 = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+  g1, b1 = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.3).to(dev)
+  part_in = torch.empty(n, 4, cin, 2, device=dev)
+  assert lib.tapir_inorm_stats(ctx, x.data_ptr(), None, None, part_in.data_ptr(), n, h * w, cin, 4, stream) == 0
+  ws = ctypes.c_void_p()
+  assert lib.tapir_conv_pack(ctx, ctypes.c_void_p(wt.data_ptr()), cout, cin, ks, ctypes.byref(ws)) == 0
+  from tapnet_amd import _ffi
+  res = {}
+  try:
+    for small in (0, 1):
+      assert lib.tapir_conv_set_small(ctx, small) == 0
+      rows, tiles = ctypes.c_int(), ctypes.c_int()
+      assert lib.tapir_conv_plan(ctx, h, w, cin, cout, ks, stride, ctypes.byref(rows), ctypes.byref(tiles)) == 0
+      outs = []
+      for rep in range(3):
+        y = torch.zeros(n, ho, wo, cout, device=dev, dtype=torch.bfloat16)
+        part = torch.full((n, tiles.value, cout, 2), float('nan'), device=dev)
+        ss = torch.empty(n, cin, 2, device=dev)
+        ssn = torch.full((n, cout, 2), float('nan'), device=dev)
+        arrive = torch.zeros(n, dtype=torch.int32, device=dev)
+        nn = _ffi.TapirNextNorm(g1.data_ptr(), b1.data_ptr(), ssn.data_ptr(), arrive.data_ptr())
+        rc = lib.tapir_conv_fused_nn(ctx, x.data_ptr(), part_in.data_ptr(), 4, 0, g0.data_ptr(), b0.data_ptr(), ss.data_ptr(),
+                                     ws, sc.data_ptr() if shortcut else None, y.data_ptr(), part.data_ptr(), n, h, w, cin, cout,
+                                     ks, stride, ctypes.byref(nn), stream)
+        assert rc == 0, lib.tapir_last_error(ctx)
+        torch.cuda.synchronize()
+        assert int(arrive.abs().sum()) == 0 and torch.isfinite(part).all() and torch.isfinite(ssn).all()
+        outs.append((y, part, ssn))
+      for y, part, ssn in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(part, outs[0][1]) and torch.equal(ssn, outs[0][2])
+      res[small] = outs[0] + (rows.value * wo, tiles.value)
+  finally:
+    assert lib.tapir_conv_set_small(ctx, 0) == 0
+    lib.tapir_conv_free(ctx, ws)
+  assert res[1][3] <= 128 and res[1][4] >= res[0][4]
+  yb, ys = res[0][0].float(), res[1][0].float()
+  d = (yb - ys).abs()
+  assert float(d.max()) <= 2e-2 * max(1.0, float(yb.abs().max())) and float((d > 0).float().mean()) < 0.05, (float(d.max()), float((d > 0).float().mean()))
+  # the merged pairs: a = rstd * gamma, b = beta - mean * a of (nearly) the same stored tensor
+  torch.testing.assert_close(res[1][2], res[0][2], rtol=2e-3, atol=2e-3)
 
 @pytest.mark.gpu
 def test_backbone_with_the_flat_tiling_is_bit_identical(monkeypatch):

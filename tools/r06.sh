@@ -7,6 +7,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export OUT
 R=$PWD
+# library variants of the fault hunt (profiles/r06_cotenant_fault.txt).  At the time of the hunt the product WAS the SLP build; today:
+SLP=$R/tools/libtapir_hip_slp.so          # the same sources WITH hipcc's SLP pass (csrc/build.sh's flags minus -fno-slp-vectorize): the build that faults
+NOSLP=$R/tapnet_amd/csrc/libtapir_hip.so  # the product (-fno-slp-vectorize)
 summ() { python - "$@" <<'PY'
 import json,sys,os
 for f in sys.argv[1:]:
@@ -41,14 +44,16 @@ if [ "$PART" == "probe2" ]; then
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_two_process_2.txt | cut -c1-420 | tail -60
 fi
 if [ "$PART" == "mixfault" ]; then
+  export TAPIR_HIP_LIB=$SLP
   # the faulty kernel alone (mix_kernel through tapir_debug_mix): which settings produce the fault, its signature, and the
   # same probe with a build of the library without packed-f32 math (-fno-slp-vectorize)
   timeout 1200 python tools/probe_mix_fault.py --setting quiet,stream,procs-quiet,neighbour,procs --launches 6000 --tracks 64 > $OUT/probe_mix_fault.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_mix_fault.txt | cut -c1-260 | tail -60
-  TAPIR_HIP_LIB=$R/tools/libtapir_hip_noslp.so timeout 900 python tools/probe_mix_fault.py --setting procs --launches 6000 --tracks 64 > $OUT/probe_mix_fault_noslp.txt 2>&1
+  TAPIR_HIP_LIB=$NOSLP timeout 900 python tools/probe_mix_fault.py --setting procs --launches 6000 --tracks 64 > $OUT/probe_mix_fault_noslp.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_mix_fault_noslp.txt | cut -c1-260 | tail -30
 fi
 if [ "$PART" == "mixfault2" ]; then
+  export TAPIR_HIP_LIB=$SLP
   # the kernel in its context (the separate-launch mixer up to launch group k, 5 tracks x 9 frames as in probe_two_process.py), fast loop
   for k in 2 3 4; do
     timeout 600 python tools/probe_mix_fault.py --setting procs --launches 8000 --tracks 5 --stop $k > $OUT/probe_ctx_stop$k.txt 2>&1
@@ -56,12 +61,13 @@ if [ "$PART" == "mixfault2" ]; then
   done
   timeout 600 python tools/probe_mix_fault.py --setting procs --launches 8000 --tracks 5 > $OUT/probe_alone_n5.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_alone_n5.txt | cut -c1-220 | tail -8
-  TAPIR_HIP_LIB=$R/tools/libtapir_hip_noslp.so timeout 600 python tools/probe_mix_fault.py --setting procs --launches 8000 --tracks 5 --stop 4 > $OUT/probe_ctx_stop4_noslp.txt 2>&1
+  TAPIR_HIP_LIB=$NOSLP timeout 600 python tools/probe_mix_fault.py --setting procs --launches 8000 --tracks 5 --stop 4 > $OUT/probe_ctx_stop4_noslp.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_ctx_stop4_noslp.txt | cut -c1-220 | tail -24
   timeout 600 python tools/probe_mix_fault.py --setting stream --launches 8000 --tracks 5 --stop 4 > $OUT/probe_ctx_stop4_1proc.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $OUT/probe_ctx_stop4_1proc.txt | cut -c1-220 | tail -8
 fi
 if [ "$PART" == "mixfault3" ]; then
+  export TAPIR_HIP_LIB=$SLP
   # who has to run beside mix_kernel for it to fault: rank 0 probes mix_kernel ALONE, rank 1 runs (unchecked) what --aggr says
   run() { timeout 600 python tools/probe_mix_fault.py --setting pair --launches 8000 --tracks 5 "$@" 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" | cut -c1-230 | grep -v "^    launch" >> $OUT/probe_pairs.txt; }
   run --stop 0 --aggr 4,1,1
@@ -77,7 +83,7 @@ fi
 if [ "$PART" == "mixfault4" ]; then
   # whose packed-f32 code matters: the victim's (mix_kernel), the aggressor's (gemm_small_kernel), or both
   run() { timeout 600 python tools/probe_mix_fault.py --setting pair --launches 8000 --tracks 5 --stop 0 --victim-matmuls 0 "$@" 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" | cut -c1-230 | grep -v "^    " >> $OUT/probe_pairs_libs.txt; }
-  P=tapnet_amd/csrc/libtapir_hip.so; NS=tools/libtapir_hip_noslp.so
+  P=$SLP; NS=$NOSLP
   run --aggr 1,1,0 --victim-lib $P --aggr-lib $P
   run --aggr 1,1,0 --victim-lib $NS --aggr-lib $P
   run --aggr 1,1,0 --victim-lib $P --aggr-lib $NS
@@ -86,6 +92,7 @@ if [ "$PART" == "mixfault4" ]; then
   cat $OUT/probe_pairs_libs.txt
 fi
 if [ "$PART" == "mixfault5" ]; then
+  export TAPIR_HIP_LIB=$SLP
   # which ingredient of the neighbouring wave: one micro kernel (tools/micro/cotenant_aggressors.hip) per run beside mix_kernel
   run() { timeout 600 python tools/probe_mix_fault.py --setting pair --launches 8000 --tracks 5 --stop 0 --victim-matmuls 0 "$@" 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" | cut -c1-230 | grep -v "^    " >> $OUT/probe_pairs_micro.txt; }
   for k in 0 1 2 3 4 5 6; do run --aggr micro:$k; done
@@ -94,39 +101,26 @@ if [ "$PART" == "mixfault5" ]; then
   run --aggr 1,1,0
   cat $OUT/probe_pairs_micro.txt
 fi
-if [ "$PART" == "interleave" ]; then
-  # frame groups issued (and captured) group after group vs block by block round-robin: same-box A/B of the whole step
-  B="python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline --no-secondary"
-  for rep in 1 2 3; do
-    TAPIR_BACKBONE_INTERLEAVE=0 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_off_$rep.json
-    TAPIR_BACKBONE_INTERLEAVE=1 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_on_$rep.json
-  done
-  TAPIR_BACKBONE_INTERLEAVE=1 TAPIR_CONV_FLAT=-1 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_on_flatauto.json
-  TAPIR_BACKBONE_INTERLEAVE=1 TAPIR_BACKBONE_STREAMS=2 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_on_streams2.json
-  TAPIR_BACKBONE_INTERLEAVE=1 TAPIR_BACKBONE_STREAMS=6 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_on_streams6.json
-  TAPIR_BACKBONE_INTERLEAVE=0 TAPIR_BACKBONE_STREAMS=6 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_il_off_streams6.json
-  summ $OUT/ab_il_*.json | tee $OUT/ab_interleave_summary.txt
-fi
 if [ "$PART" == "repro" ]; then
   # the stand-alone reproducer (no engine): packed-f32 forms next to MFMA traffic, alone / second stream / second process
   timeout 900 python tools/micro/run_cotenant_repro.py --kinds 0,3,4 > $OUT/cotenant_repro.txt 2>&1
   grep -v "amdgpu.ids" $OUT/cotenant_repro.txt | cut -c1-200
   # and the engine: mix_kernel beside the engine's own few-row GEMM built WITHOUT and with accumulation registers; the no-SLP build as victim
   run() { timeout 600 python tools/probe_mix_fault.py --setting pair --launches 8000 --tracks 5 --stop 0 --victim-matmuls 0 "$@" 2>&1 | grep -v "amdgpu.ids\|Gloo\|socket.cpp" | cut -c1-230 | grep -v "^    " >> $OUT/probe_pairs_fix.txt; }
-  P=tapnet_amd/csrc/libtapir_hip.so
-  run --aggr 1,1,0 --victim-lib $P --aggr-lib tools/libtapir_hip_vgprform.so
-  run --aggr micro:3 --victim-lib tools/libtapir_hip_noslp.so
+  # (the hunt also ran an aggressor built with -mllvm -amdgpu-mfma-vgpr-form -- no AGPRs --: 58 faulty launches of 8000, i.e. it is the MFMAs)
+  run --aggr micro:3 --victim-lib $SLP
+  run --aggr micro:3 --victim-lib $NOSLP
   cat $OUT/probe_pairs_fix.txt
 fi
 if [ "$PART" == "abslp" ]; then
   # the product build (-fno-slp-vectorize) against the same sources with the SLP pass (tools/libtapir_hip_slp.so): whole step, BootsTAPIR, online
   B="python bench.py --steps 20 --warmup 5 --no-accuracy --no-cpu-baseline --no-secondary"
   for rep in 1 2 3; do
-    TAPIR_HIP_LIB=$R/tools/libtapir_hip_slp.so timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_slp_on_$rep.json
+    TAPIR_HIP_LIB=$SLP timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_slp_on_$rep.json
     timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_slp_off_$rep.json
   done
   summ $OUT/ab_slp_*.json | tee $OUT/ab_slp_summary.txt
-  TAPIR_HIP_LIB=$R/tools/libtapir_hip_slp.so timeout 300 python tools/bench_online.py --frames 60 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/slp   /' | tee -a $OUT/ab_slp_summary.txt
+  TAPIR_HIP_LIB=$SLP timeout 300 python tools/bench_online.py --frames 60 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/slp   /' | tee -a $OUT/ab_slp_summary.txt
   timeout 300 python tools/bench_online.py --frames 60 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/noslp /' | tee -a $OUT/ab_slp_summary.txt
 fi
 if [ "$PART" == "fusepatch" ]; then
@@ -137,6 +131,25 @@ if [ "$PART" == "fusepatch" ]; then
     TAPIR_FUSE_PATCH=1 timeout 300 $B 2>/dev/null | tail -1 > $OUT/ab_fp_on_$rep.json
   done
   summ $OUT/ab_fp_*.json | tee $OUT/ab_fusepatch_summary.txt
+fi
+if [ "$PART" == "small" ]; then
+  # the few-frame form of the block convolutions: parity on the GPU, the online step with and without it, the online tests
+  timeout 600 python -m pytest tests/test_gpu_conv.py -q -x -k "few_frame or extra_convs_block" 2>&1 | tail -5 | tee $OUT/pytest_small.log
+  for rep in 1 2; do
+    TAPIR_CONV_SMALL=0 timeout 300 python tools/bench_online.py --frames 120 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/small off /' | tee -a $OUT/ab_small_summary.txt
+    TAPIR_CONV_SMALL=1 timeout 300 python tools/bench_online.py --frames 120 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed 's/^/small on  /' | tee -a $OUT/ab_small_summary.txt
+  done
+  timeout 900 python -m pytest tests -m gpu -q -x -k "online or causal or jax" 2>&1 | tail -5 | tee $OUT/pytest_online.log
+fi
+if [ "$PART" == "onlinetl" ]; then
+  # one online frame launch by launch, with and without the few-frame convolutions
+  for m in 1 0; do
+    cd /tmp
+    TAPIR_CONV_SMALL=$m timeout 300 rocprofv3 --kernel-trace -d $R/$OUT/prof_online$m -o online -- python $R/tools/bench_online.py --frames 30 --eager-only > $R/$OUT/online_under_trace$m.json 2> $R/$OUT/rocprof_online$m.err
+    cd $R; for f in $(find $OUT/prof_online$m -name '*.db'); do python tools/online_timeline.py $f 3 > $OUT/online_timeline_small$m.txt 2>&1; done
+    find $OUT/prof_online$m -name '*.db' -size +20M -delete
+    head -40 $OUT/online_timeline_small$m.txt | cut -c1-150
+  done
 fi
 if [ "$PART" == "timeline" ]; then
   cd /tmp
