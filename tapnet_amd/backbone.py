@@ -387,7 +387,8 @@ class Backbone:
 
   def _next_norm(self, next_norm, n, cout, tag):
     """tapir_next_norm for the launch that produces the input of `next_norm` (None: no in-launch merge)."""
-    if not (self.fuse_finalize and next_norm is not None):
+    # (few-frame form: the CONSUMER merges the summaries in its prologue, csrc/conv_small.hpp -- nothing at the producer's tail)
+    if not (self.fuse_finalize and next_norm is not None) or self._small_now:
       return None, None
     from tapnet_amd import _ffi
     ssn = self._buf(('ssn', tag, n, cout), (n, cout, 2), torch.float32)
@@ -467,7 +468,8 @@ class Backbone:
         shortcut = self._hip_conv(ysub if strided else y, p + 'proj_conv')
     if f0:
       y0, st0 = self._fused_conv(x, st, p + 'bn_0', p + 'conv_0', None, tag + 'c', stride,
-                                 reuse_ss=bool(use_projection and fp),   # (proj_conv just merged bn_0's pairs into `ss`)
+                                 reuse_ss=bool(use_projection and fp) and not self._small_now,   # (proj_conv just merged bn_0's pairs into `ss`;
+                                 #  the few-frame form merges inside every consuming launch and writes no `ss`)
                                  next_norm=p + 'bn_1')
     else:
       y0 = self._hip_conv(y, p + 'conv_0', stride, 0 if strided else 1)

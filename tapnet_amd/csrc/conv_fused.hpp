@@ -68,6 +68,12 @@ struct Conv3Args {
   int TH, tiles;          // output rows per tile, tiles per image = ceil(Ho / TH)
   int waves;              // 4 or 8 (conv3_plan)
   int cin_total;          // conv_small.hpp MODE 2 only: input channels in memory (chunks of CIN); 0 elsewhere
+  // conv_small.hpp MODE 0 only: the input norm's pairs merged by the CONSUMER, in its prologue, from the producer's tile
+  // summaries (part_in != null: ss is not read) -- takes the producer's write-through + ticket + merge off the launch chain
+  const float* part_in;   // [N, slabs_in, C_in, 2]
+  const float* gamma_in;  // [C_in]
+  const float* beta_in;
+  int slabs_in, per_s_in;
   long long* dbg_times;   // TRACE build: [workgroups][waves][8] shader-cycle totals per phase
   FinArgs fin;
 };

@@ -27,7 +27,8 @@ namespace tapir {
 
 constexpr int CVS_WAVES = 4;
 constexpr int CVS_LDS_BYTES = 128 * 1024;     // the largest input tile (two kernel forms: tiles <= 80 KiB -- two workgroups per CU -- and <= 128 KiB)
-constexpr int CVS_LDS_SMALL = 80 * 1024;
+constexpr int CVS_LDS_SMALL = 76 * 1024;     // (+ 3 KiB of pair / reduction scratch: two workgroups per CU)
+constexpr int CVS_MERGE_MAXS = 32;            // tile summaries per lane the consumer-side merge holds in registers
 
 // output rows per tile / tiles per image / fragments per wave; false: the shape stays with conv_fused_kernel
 inline bool conv_small_plan(int H, int W, int cin, int cout, int ks, int stride, int* rows, int* tiles, int* nt) {
@@ -50,6 +51,56 @@ inline long conv_small_tile_bytes(int W, int cin, int ks, int stride, int rows) 
   return ((long)stride * (rows - 1) + ks) * ((long)stride * (Wo - 1) + ks) * cin * 2;
 }
 
+// (a, b) pairs of image n's input norm from the producer's tile summaries, by every consuming workgroup in its prologue:
+// inorm_finalize_kernel's arithmetic (backbone.hpp: weighted mean, then M2 about it, all summaries of a pass in flight at
+// once) with L = 256 / CIN lanes per channel; s_pairs[c] = (rstd * gamma, beta - mean * rstd * gamma).  Needs
+// slabs_in <= L * CVS_MERGE_MAXS (the host launches inorm_finalize_kernel otherwise).
+template <int CIN>
+__device__ __forceinline__ void cvs_merge_pairs(const Conv3Args& a, int n, float2* s_pairs, float* s_red /* [256] */) {
+  constexpr int L = 256 / CIN;
+  const int tid = threadIdx.x;
+  const int ch = tid % CIN, q = tid / CIN;
+  const int slabs = a.slabs_in, HW = a.H * a.W;
+  const int per_s = a.per_s_in > 0 ? a.per_s_in : (HW + slabs - 1) / slabs;
+  auto slab_n = [&](int s) { return s < slabs ? (float)max(0, min(HW, (s + 1) * per_s) - s * per_s) : 0.f; };
+  const float2* ps = reinterpret_cast<const float2*>(a.part_in) + (long)n * slabs * CIN + ch;
+  const float inv_hw = 1.0f / (float)HW;
+  float2 v[CVS_MERGE_MAXS];
+#pragma unroll
+  for (int k = 0; k < CVS_MERGE_MAXS; ++k) v[k] = ps[(long)min(q + k * L, slabs - 1) * CIN];
+  float s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CVS_MERGE_MAXS; ++k) s1 = fmaf(slab_n(q + k * L), v[k].x, s1);
+  if (L > 1) {
+    s_red[tid] = s1;
+    lds_barrier();
+    s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) s1 += s_red[j * CIN + ch];
+  }
+  const float mean = s1 * inv_hw;
+  float m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CVS_MERGE_MAXS; ++k) {
+    const float nk = slab_n(q + k * L);
+    const float d = v[k].x - mean;
+    m2 += nk > 0.f ? fmaf(nk * d, d, v[k].y) : 0.f;
+  }
+  if (L > 1) {
+    lds_barrier();        // every lane has read the first partial sums
+    s_red[tid] = m2;
+    lds_barrier();
+    m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) m2 += s_red[j * CIN + ch];
+  }
+  if (q == 0) {
+    const float sc = (1.0f / sqrtf(m2 * inv_hw + kInEps)) * a.gamma_in[ch];
+    s_pairs[ch] = make_float2(sc, a.beta_in[ch] - mean * sc);
+  }
+  lds_barrier();
+}
+
 // MODE 0: a block convolution (operand = relu(a x + b), epilogue = + shortcut, summaries, next norm's pairs);
 // MODE 1: the first convolution of an ExtraConvs block (tapir_model.py:183-184, extra_convs.hpp): operand = x as it is (the
 //         LayerNorm kernel's output), epilogue = + bias (a.ss = the bias vector [C_out]), gelu (tanh form), no summaries;
@@ -66,6 +117,8 @@ __global__ __launch_bounds__(CVS_WAVES * 64) void conv_small_kernel(Conv3Args a)
   constexpr int TAPS = KS * KS, KPT = CIN / 32, KT = TAPS * KPT;   // k-steps in all
   constexpr int KW = (KT + 3) / 4;                 // k-steps of a wave (at most)
   __shared__ uint4 s_buf[LDS_BYTES / 16];
+  __shared__ float2 s_pairs[MODE == 0 ? CIN : 1];   // the input norm's (a, b) when this workgroup merges them itself
+  __shared__ float s_red[MODE == 0 ? 256 : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,6 +177,7 @@ __global__ __launch_bounds__(CVS_WAVES * 64) void conv_small_kernel(Conv3Args a)
   uint4 wf[KW];
 #pragma unroll
   for (int j = 0; j < KW; ++j) wf[j] = wbase[(long)((ch * KT + min(wave + 4 * j, KT - 1)) * 4 + rsel) * 64];   // (past the end: valid, not used)
+  if (MODE == 0 && a.part_in != nullptr) cvs_merge_pairs<CIN>(a, n, s_pairs, s_red);   // (under the weight loads just issued)
   // ---- stage relu(a x + b) of the input tile (conv_fused_kernel's walk: a thread keeps one 8-channel chunk)
   {
     constexpr int PPS = THREADS / CPP;
@@ -131,9 +185,17 @@ __global__ __launch_bounds__(CVS_WAVES * 64) void conv_small_kernel(Conv3Args a)
     const int chunk = tid % CPP, pl = tid / CPP;
     f32x4 ssv[4];
     if (MODE == 0) {
-      const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * CIN + EPC * chunk) * 2);
+      if (a.part_in != nullptr) {
+        float2 pr[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ssv[k] = sp[k];
+        for (int e = 0; e < 8; ++e) pr[e] = s_pairs[EPC * chunk + e];
+        ssv[0] = f32x4{pr[0].x, pr[1].x, pr[2].x, pr[3].x}; ssv[1] = f32x4{pr[4].x, pr[5].x, pr[6].x, pr[7].x};
+        ssv[2] = f32x4{pr[0].y, pr[1].y, pr[2].y, pr[3].y}; ssv[3] = f32x4{pr[4].y, pr[5].y, pr[6].y, pr[7].y};
+      } else {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(a.ss + ((long)n * CIN + EPC * chunk) * 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ssv[k] = sp[k];
+      }
     }
     const T* xin = reinterpret_cast<const T*>(a.x) + (long)n * H * W * CT + ch * CIN + EPC * chunk;
     const int dq = PPS / PW, dr = PPS - dq * PW;

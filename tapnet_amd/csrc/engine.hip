@@ -1690,7 +1690,9 @@ static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, in
   if (small && y_proj) return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: the dual launch has no few-frame form (launch conv_0 and proj_conv separately)");
   if (!small && !conv3_plan(H, W, cin, cout, ks, stride, bf ? 2 : 4, &rows, &tiles, &waves))
     return fail(c, TAPIR_ERR_UNSUPPORTED, "conv_fused: shape");
-  if (part_in != nullptr) {
+  // few-frame form: the consuming workgroups merge the summaries themselves (conv_small.hpp cvs_merge_pairs) -- no launch
+  const bool merge_in_kernel = small && part_in != nullptr && slabs_in <= (256 / cin) * CVS_MERGE_MAXS;
+  if (part_in != nullptr && !merge_in_kernel) {
     NormFinalizeArgs nf{part_in, gamma, beta, ss, H * W, cin, slabs_in, per_s_in, bf ? 8 : 4};
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N, (nf.C + 63) / 64), dim3(NORM_THREADS), 0, (hipStream_t)stream, nf);
   }
@@ -1703,6 +1705,7 @@ static int conv_fused_impl(tapir_ctx* c, const void* x, const float* part_in, in
   ca.TH = rows; ca.tiles = tiles; ca.waves = waves;
   ca.dbg_times = (long long*)c->dbg_times;
   if (next != nullptr) ca.fin = FinArgs{next->gamma, next->beta, next->ss, next->arrive, bf ? 8 : 4};
+  if (merge_in_kernel) { ca.part_in = part_in; ca.gamma_in = gamma; ca.beta_in = beta; ca.slabs_in = slabs_in; ca.per_s_in = per_s_in; }
   {
     const int kind = (ks == 3 && stride == 1) ? (cin == 64 ? TAPIR_PROF_CONV3_C64 : cin == 128 ? TAPIR_PROF_CONV3_C128 : TAPIR_PROF_CONV3_C256)
                                               : TAPIR_PROF_CONV_OTHER;

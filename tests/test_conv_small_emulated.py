@@ -120,10 +120,22 @@ def test_few_frame_form_merges_the_next_norm_in_the_launch(C, H, W):
       return y, part
 
     y_ref, part_ref = call(None)
+    # the consuming call's own merge LAUNCH (the many-frame path: in the few-frame form the consumer merges the summaries in
+    # its prologue and writes no `ss`; both read the same summaries with the same arithmetic)
     ss_ref = np.zeros((N, C, 2), np.float32)
     y2 = np.zeros((N, H, W, C), np.uint16)
+    assert lib.tapir_conv_set_small(ctx, 0) == 0
     assert lib.tapir_conv_fused(ctx, _p(y_ref), _p(part_ref), tiles.value, rows.value * W, _p(g1), _p(b1), _p(ss_ref), ws,
                                 None, _p(y2), None, N, H, W, C, C, 3, 1, None) == 0
+    assert lib.tapir_conv_set_small(ctx, 1) == 0
+    # ... and the few-frame consumer on the same summaries: the same convolution up to the summation order
+    y3 = np.zeros((N, H, W, C), np.uint16)
+    ss_unused = np.full((N, C, 2), np.nan, np.float32)
+    assert lib.tapir_conv_fused(ctx, _p(y_ref), _p(part_ref), tiles.value, rows.value * W, _p(g1), _p(b1), _p(ss_unused), ws,
+                                None, _p(y3), None, N, H, W, C, C, 3, 1, None) == 0
+    d23 = np.abs(from_bf16_bits(y3) - from_bf16_bits(y2))
+    assert d23.max() <= 2e-2 * max(1.0, np.abs(from_bf16_bits(y2)).max()) and (d23 > 0).mean() < 0.05
+    assert np.isnan(ss_unused).all()       # (merged in the kernel's prologue: `ss` is not written)
     ssn = np.full((N, C, 2), np.nan, np.float32)
     arrive = np.zeros(N, np.int32)
     nn = _ffi.TapirNextNorm(g1.ctypes.data, b1.ctypes.data, ssn.ctypes.data, arrive.ctypes.data)
