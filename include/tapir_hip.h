@@ -307,7 +307,13 @@ int tapir_conv_plan(tapir_ctx* ctx, int H, int W, int cin, int cout, int ks, int
  * geometry, for every shape the form covers (output rows of <= 128 pixels); 0 (default) = the many-frame kernels.  The forms
  * differ in summation order (not bit-identical): set it from the frame count of the WHOLE clip (tapnet_amd.backbone: clips of
  * fewer than 4 frames), never per shard or chunk, and plan / allocate the summaries after setting it.  The dual launch
- * (tapir_conv_fused_dual_nn) has no few-frame form and returns TAPIR_ERR_UNSUPPORTED while the mode is on. */
+ * (tapir_conv_fused_dual_nn) has no few-frame form and returns TAPIR_ERR_UNSUPPORTED while the mode is on.
+ * While it is on, also: (1) tapir_xconv / tapir_xconv_nt run both convolutions of an ExtraConvs block (256 -> 1024 + bias +
+ * gelu, 1024 -> 256 + bias + skip) in the same form where the pack was built for 256-channel chunks; (2) a tapir_conv_fused*
+ * call that is handed summaries (part_in != NULL, slabs_in <= 32 * 256 / cin) merges them into the input norm's (a, b) pairs
+ * INSIDE the consuming launch, in every workgroup's prologue -- no inorm_finalize launch, `ss` is neither written nor read --
+ * which is cheaper on a one-frame launch than the producer-side merge of the _nn forms (still accepted): pass next = NULL to
+ * the producer and its part_out to the consumer (tapnet_amd.backbone does). */
 int tapir_conv_set_small(tapir_ctx* ctx, int on);
 int tapir_conv_pack(tapir_ctx* ctx, const float* w, int cout, int cin, int ks, void** wstream);
 int tapir_conv_free(tapir_ctx* ctx, void* wstream);

@@ -594,6 +594,38 @@ def test_few_frame_form_of_the_block_convs_matches_the_many_frame_kernel(model, 
   # the merged pairs: a = rstd * gamma, b = beta - mean * a of (nearly) the same stored tensor
   torch.testing.assert_close(res[1][2], res[0][2], rtol=2e-3, atol=2e-3)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size,frames', [(256, 1), (256, 3), (512, 1), (192, 2)])
+def test_few_frame_backbone_matches_the_library_path(size, frames):
+  """Backbone.features of a clip of fewer than 4 frames (the online model's launches, tapnet/live_demo.py:51-77) with the
+  few-frame HIP convolutions (csrc/conv_small.hpp: every ResNet block convolution and both ExtraConvs convolutions) against
+  the path of rounds 2-5 (MIOpen / CK convolutions + torch glue + HIP norm kernels): the L2-normalised bf16 grids agree
+  per cell (cosine >= 0.995: two bf16 implementations of 29 convolutions), also where single layers fall back to the
+  many-frame kernel (512 x 512: output rows longer than 128 pixels) and on maps that are no multiple of the tile."""
+  from tapnet_amd import tapir_model
+  w = synthetic.make_weights(23, 1, True)
+  m = tapir_model.TAPIR(pyramid_level=1, extra_convs=True, weights=w, device='cuda:0', dtype='bfloat16')
+  bb = m._backbone
+  fr = torch.as_tensor(synthetic.make_video(5, frames, size, size), device='cuda:0').reshape(-1, size, size, 3).float()
+  outs = {}
+  for small in (False, True):
+    bb.small_convs = small
+    low, hi = bb.features(fr)
+    torch.cuda.synchronize()
+    assert torch.isfinite(low).all() and torch.isfinite(hi).all()
+    assert bb._small_now == small
+    outs[small] = (low.clone(), hi.clone())
+    if small:                            # repeatable bit for bit (the library's convolutions accumulate with atomics and are not)
+      low2, hi2 = bb.features(fr)
+      assert torch.equal(low2, outs[small][0]) and torch.equal(hi2, outs[small][1])
+  for a, b in zip(outs[False], outs[True]):
+    cos = (a * b).sum(-1)                # both are unit vectors per cell
+    assert float(cos.min()) >= 0.995, float(cos.min())
+  # and a many-frame clip afterwards takes the many-frame kernels again
+  bb.features(torch.cat([fr] * 4)[:8] if frames * 4 >= 8 else torch.cat([fr] * 8)[:8])
+  assert not bb._small_now
+
 @pytest.mark.gpu
 def test_backbone_with_the_flat_tiling_is_bit_identical(monkeypatch):
   """A whole backbone pass (eager and the replayed hipGraph, four frame groups on four streams) with the 256-channel
