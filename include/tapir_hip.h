@@ -438,8 +438,10 @@ int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
  * LDS, no heads); scratch = B*T*ceil(Q/8) floats. */
 int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* grid, int B, int Q, int T, int h, int w,
                             float* scratch, void* stream);
-/* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 1 (default) = one launch of the
- * whole-K small-tile kernel, 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
+/* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 2 (default) = 1, and the channel MLP of a
+ * block (up-projection + gelu + down-projection, tapir_model.py:127-156) as ONE launch whose partial outputs the next
+ * consumer of the residual stream adds (csrc/gemm.hpp mlp_small_kernel); 1 = one launch of the whole-K small-tile kernel per
+ * GEMM; 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
 /* The 3x3 256 -> 256 block convolutions (tapir_conv_fused*): 1 = always the flat tiling of the whole launch
  * (csrc/conv_flat.hpp: three consecutive 64-pixel slabs of the (image, row) space per workgroup) where the shape allows it,

@@ -98,7 +98,7 @@ struct tapir_ctx {
   int conv_small = 0;                             // block convolutions of FEW-frame clips (the online model): 1 = conv_small_kernel (conv_small.hpp) where the shape
                                                   // allows it; set per clip by the caller's backbone (tapir_conv_set_small), follows the WHOLE clip's frame count
   int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
-  int small_gemm = 1;                             // few-row GEMMs: 1 = gemm_small_kernel (one launch), 0 = split-K + reduce
+  int small_gemm = 2;                             // few-row GEMMs: 2 = 1 + the channel MLP of a block in ONE launch (mlp_small_kernel), 1 = gemm_small_kernel (one launch each), 0 = split-K + reduce
 
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
@@ -852,10 +852,25 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   if (stop_here()) return TAPIR_OK;
   const int TC = pick_time_chunk(N, T);
   const int nch = (T + TC - 1) / TC;
+  // few rows (the online model, small query shards): the channel MLP of a block as ONE launch that leaves 2048 / 256 partial
+  // outputs; the next consumer of x (the next block's mix_kernel, the final LayerNorm) adds them, the bias and the residual
+  // while it stages its rows (gemm.hpp mlp_small_kernel).  mix_stream_kernel (plain clips of >= 12 frames) does not read pieces.
+  const bool mix_general = c->cfg.use_causal_conv || ctx1_in || ctx2_in || ctx1_out || ctx2_out || T < 12;
+  const bool mlp1 = c->small_gemm >= 2 && mlp_small_supported((int)R) && mix_general && c->dbg_mixer_stop == 0;
+  const int nparts = kHidden4 / MLP_HS;
+  if (mlp1) TRY(ensure(c, c->splitk, (size_t)nparts * R * kHidden * 4));
+  float* res_prev = nullptr;      // mlp1: the residual stream the previous block's MLP read (that block's x_out)
+  const float* bdn_prev = nullptr;
   for (int i = 0; i < nb; ++i) {
     const BlockW& bw = c->blocks[i];
     MixArgs m{};
     m.x_in = (const float*)c->xa.p; m.x_out = (float*)c->xb.p; m.xn2 = c->xn.p;
+    if (mlp1) {
+      // residual buffers alternate (x_out may not alias what this launch reads: block 0 reads xa, later blocks read the
+      // previous x_out as `presid`)
+      m.x_out = (float*)((i & 1) ? c->xa.p : c->xb.p);
+      if (i > 0) { m.parts = (const float*)c->splitk.p; m.nparts = nparts; m.pbias = bdn_prev; m.presid = res_prev; }
+    }
     m.ln1 = bw.ln1; m.w1 = bw.w1; m.b1 = bw.b1; m.w2 = bw.w2; m.b2 = bw.b2; m.ln2 = bw.ln2;
     m.ctx1_in = ctx1_in ? ctx1_in + (size_t)i * N * 2 * kHidden : nullptr;
     m.ctx2_in = ctx2_in ? ctx2_in + (size_t)i * N * 2 * kHidden4 : nullptr;
@@ -865,6 +880,13 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     { ProfScope ps(c, TAPIR_PROF_MIX, s);
       launch_mix<TA>(m, N, s); }
     if (stop_here()) return TAPIR_OK;
+    if (mlp1) {
+      MlpSmallArgs ma{c->xn.p, bw.Wup, bw.bup, bw.Wdn, (float*)c->splitk.p, (int)R};
+      { ProfScope ps(c, TAPIR_PROF_GEMM_UP, s);
+        if (sizeof(TA) == 2) launch_mlp_small<bf16_t>(ma, s); else launch_mlp_small<float>(ma, s); }
+      res_prev = m.x_out; bdn_prev = bw.bdn;
+      continue;
+    }
     GemmArgs g1{};
     g1.A = c->xn.p; g1.lda = kHidden; g1.W = bw.Wup; g1.ldw = kHidden; g1.bias = bw.bup;
     g1.C = c->hid.p; g1.ldc = kHidden4; g1.M = (int)R; g1.N = kHidden4; g1.K = kHidden;
@@ -880,6 +902,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     if (stop_here()) return TAPIR_OK;
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
+  if (mlp1 && nb > 0) { la.parts = (const float*)c->splitk.p; la.nparts = nparts; la.pbias = bdn_prev; la.presid = res_prev; }
   hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
   GemmArgs g{};
   g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
@@ -2001,7 +2024,7 @@ int tapir_debug_poison_lds(tapir_ctx* c, unsigned pattern, void* stream) {
 }
 
 int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 1) return TAPIR_ERR_INVALID;
+  if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
   c->small_gemm = mode;
   return TAPIR_OK;
 }

@@ -927,6 +927,139 @@ inline void launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
   }
 }
 
+// ---- the channel MLP of a PIPs block for FEW rows in ONE launch (the online model: M = tracked points x 1 frame).
+// tapir_model.py:127-156: x += W_dn gelu(W_up LN2(x) + b_up) + b_dn.  As two gemm_small_kernel launches (up: 8.3 us, down:
+// 11.0 us for 256 rows) the pair is 96 of the 148 dependent launches of an online frame's mixer
+// (profiles/r06_online_timeline.txt).  What such a launch costs beyond the ~5.5 us of a dependent launch with nothing in it is
+// the bytes ONE CU has to pull in cold (96 KB / 256 KB per workgroup for up / down; a first form of this kernel with 544 KB per
+// workgroup and four dependent round trips per phase took 33.8 us, profiles/r06_ab_mlp_small.txt) -- so the decomposition
+// minimises bytes per workgroup with every CU busy: a workgroup = (tile of 32 rows, slice of MLP_HS = 64 hidden units) pulls
+// 64 KB of W_up + 32 KB of LN2(x) + 64 KB of W_dn = 160 KB, ALL of it requested before the first MFMA (one round trip):
+//   phase 1: hid[32, 64] = gelu(xn_tile W_up[h0 .. h0 + 64]^T + b_up): the four waves split K = 512 (one quarter each, all of
+//            a wave's fragments in flight), meet in LDS, add in wave order, round to the operand type into LDS;
+//   phase 2: part[slice][32, 512] = hid W_dn[:, h0 .. h0 + 64]^T: wave w takes output columns 128 w .. 128 w + 127, its 16
+//            weight fragments were requested at the top of the kernel.
+// Nobody waits and nobody merges at the tail of the launch (the lesson of conv_small.hpp: a merge by the last arriver is ~6 us ON
+// the chain of a launch this small): the CONSUMER -- the next block's mix_kernel, or the final layernorm_kernel -- adds the
+// 2048 / 64 = 32 partials, b_dn and the residual in a fixed order while it stages its rows (mixer.hpp parts_sum2).  The hidden
+// tensor never exists in HBM.  M <= 512 rows: 16 x 32 = 512 workgroups at most.
+constexpr int MLP_HS = 64;           // hidden units per workgroup
+constexpr int MLP_PARTS = 2048 / MLP_HS;
+struct MlpSmallArgs {
+  const void* xn;      // [M, 512] LN2(x) in the operand type
+  const void* Wup;     // [2048, 512]
+  const float* bup;    // [2048]
+  const void* Wdn;     // [512, 2048]
+  float* part;         // [2048 / MLP_HS][M, 512] f32 partial outputs (no bias, no residual)
+  int M;
+};
+template <typename TA>
+__global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
+  constexpr int EPC = 16 / (int)sizeof(TA);          // elements per 16-byte chunk
+  constexpr int KS = 4 * EPC;                        // k per MFMA step
+  constexpr int K1 = 128 / KS;                       // k-steps of a wave's quarter of K = 512 (bf16: 4, f32: 8)
+  constexpr int K2 = MLP_HS / KS;                    // k-steps of the second product (bf16: 2, f32: 4)
+  constexpr int LDH = MLP_HS + EPC;                  // hidden row stride in LDS (+ one chunk: rows 16 lanes apart on different banks)
+  constexpr bool EARLY = sizeof(TA) == 2;            // W_dn's fragments requested before phase 1 (f32: too many registers; parity build)
+  __shared__ f32x4 s_part[4][8][64];                 // the four waves' partial hidden tiles (fragment layout)
+  __shared__ __attribute__((aligned(16))) TA s_hid[32 * LDH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  constexpr int slices = 2048 / MLP_HS;
+  const int tm = blockIdx.x / slices, sl = blockIdx.x - tm * slices;
+  const int m0 = tm * 32, h0 = sl * MLP_HS;
+  const TA* A = reinterpret_cast<const TA*>(g.xn);
+  const TA* Wu = reinterpret_cast<const TA*>(g.Wup);
+  const TA* Wd = reinterpret_cast<const TA*>(g.Wdn);
+  // ---- every operand of this wave, requested now: W_up rows h0 + 16 j + c and the tile's rows over k in [128 wave, 128 wave + 128),
+  // W_dn rows (output columns) 128 wave + 16 j + c over the slice's 64 hidden units
+  uint4 fw[K1][4], fa[K1][2], fd[K2][8];
+#pragma unroll
+  for (int ks = 0; ks < K1; ++ks) {
+    const int k = 128 * wave + ks * KS + EPC * gq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw[ks][j] = *reinterpret_cast<const uint4*>(Wu + (long)(h0 + 16 * j + c) * 512 + k);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[ks][i] = *reinterpret_cast<const uint4*>(A + (long)min(m0 + 16 * i + c, g.M - 1) * 512 + k);
+  }
+  auto load_dn = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < K2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        fd[ks][j] = *reinterpret_cast<const uint4*>(Wd + (long)(128 * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
+  };
+  if (EARLY) load_dn();
+  // ---- phase 1: this wave's quarter of K
+  {
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K1; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
+  }
+  if (!EARLY) load_dn();
+  __syncthreads();
+  // wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units h0 + 16 j + 4 gq + e of row 16 i + c
+#pragma unroll
+  for (int f0 = 0; f0 < 8; f0 += 4) {
+    const int f = f0 + wave;
+    const int j = f >> 1, i = f & 1;
+    f32x4 v = s_part[0][f][lane];
+    v = v + s_part[1][f][lane];
+    v = v + s_part[2][f][lane];
+    v = v + s_part[3][f][lane];
+    const int hl = 16 * j + 4 * gq;
+    v = v + *reinterpret_cast<const f32x4*>(g.bup + h0 + hl);
+    Store4<TA>::run(&s_hid[(16 * i + c) * LDH + hl], gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
+  }
+  __syncthreads();
+  // ---- phase 2: part[sl][rows, 128 wave .. 128 wave + 127]
+  {
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K2; ++ks) {
+      uint4 fh[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
+    }
+    float* out = g.part + (long)sl * g.M * 512;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + 16 * i + c;
+      if (m < g.M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
+      }
+    }
+  }
+}
+inline bool mlp_small_supported(int M) { return M >= 1 && M <= 512; }
+template <typename TA>
+inline void launch_mlp_small(const MlpSmallArgs& g, hipStream_t stream) {
+  TAPIR_LAUNCH((mlp_small_kernel<TA>), dim3((unsigned)(((g.M + 31) / 32) * (2048 / MLP_HS))), dim3(256), stream, g);
+}
+
 #ifdef TAPIR_EXPERIMENTS
 template <typename TA, typename TO, int EPI>
 inline void launch_gemm_traced(const GemmArgs& g, hipStream_t stream, int tile, int max_grid) {

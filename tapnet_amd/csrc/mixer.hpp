@@ -38,7 +38,28 @@ struct MixArgs {
   int TC;                 // frames per workgroup (<= MIX_MAX_TC)
   int causal;             // use_causal_conv
   long long* dbg_times;   // null, or [units][6] wall-clock stamps (tools/kbench.py --mix-trace)
+  // x_in given as the pieces the previous block's one-launch channel MLP left (gemm.hpp mlp_small_kernel): parts != null:
+  // x_in[r] = ((((p_0 + p_1) + ...) + p_{nparts-1}) + bias) + resid[r], added in that fixed order while the rows are staged
+  const float* parts;     // [nparts][N * T, 512] f32
+  const float* pbias;     // [512] the down-projection's bias
+  const float* presid;    // [N * T, 512] the residual stream the MLP read (the previous mix_kernel's x_out)
+  int nparts;
 };
+
+// one row-major value pair (columns 2 j, 2 j + 1 of row r) of the sum above; nparts == MLP_PARTS (gemm.hpp: 2048 / MLP_HS), a
+// compile-time count so that all of a thread's loads are in flight at once
+__device__ __forceinline__ float2 parts_sum2(const float* parts, int /*nparts*/, long rows, const float* bias, const float* resid,
+                                             long r, int col) {
+  float2 w[MLP_PARTS];
+#pragma unroll
+  for (int p = 0; p < MLP_PARTS; ++p) w[p] = *reinterpret_cast<const float2*>(parts + ((long)p * rows + r) * kHidden + col);
+  const float2 b = *reinterpret_cast<const float2*>(bias + col);
+  const float2 x = *reinterpret_cast<const float2*>(resid + r * kHidden + col);
+  float2 v = w[0];
+#pragma unroll
+  for (int p = 1; p < MLP_PARTS; ++p) { v.x += w[p].x; v.y += w[p].y; }
+  return make_float2((v.x + b.x) + x.x, (v.y + b.y) + x.y);
+}
 
 // Row statistics by ONE wave: the lane holds channels [4*lane, 4*lane+4) and
 // [256+4*lane, 256+4*lane+4) of the row.
@@ -101,7 +122,13 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a) {
   const int xlo = max(0, t0 + 2 * off0);
   const int xhi = min(T - 1, t1 - 1 + 2 * off0 + 4);
   const int nrows = xhi - xlo + 1;
-  {
+  if (a.parts != nullptr) {   // the rows are sums of the previous block's MLP pieces (few rows: the online model)
+    const long rows_all = (long)gridDim.y * T, rbase = (long)n * T + xlo;
+    for (int r = 0; r < nrows; ++r) {
+      const float2 v = parts_sum2(a.parts, a.nparts, rows_all, a.pbias, a.presid, rbase + r, 2 * tid);
+      *reinterpret_cast<float2*>(&s_x[r][2 * tid]) = v;
+    }
+  } else {
     const float* src = xin + (long)xlo * kHidden;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int k = wave_u; k < nrows * 2; k += MIX_THREADS / 64)
@@ -522,16 +549,28 @@ inline void launch_mix(const MixArgs& m_in, int N, hipStream_t s, int force_tc =
 }
 
 // Row-wise LayerNorm (scale only) -> operand type; one wave per row of 512.
-struct LnArgs { const float* x; const float* scale; void* out; long rows; };
+struct LnArgs {
+  const float* x; const float* scale; void* out; long rows;
+  const float* parts; const float* pbias; const float* presid; int nparts;   // parts != null: x as MixArgs::parts describes it
+};
 template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
-  const float* p = a.x + row * kHidden + lane * 8;
-  const float4 u = *reinterpret_cast<const float4*>(p);
-  const float4 v = *reinterpret_cast<const float4*>(p + 4);
-  float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  float e[8];
+  if (a.parts != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float2 t = parts_sum2(a.parts, a.nparts, a.rows, a.pbias, a.presid, row, lane * 8 + 2 * k);
+      e[2 * k] = t.x; e[2 * k + 1] = t.y;
+    }
+  } else {
+    const float* p = a.x + row * kHidden + lane * 8;
+    const float4 u = *reinterpret_cast<const float4*>(p);
+    const float4 v = *reinterpret_cast<const float4*>(p + 4);
+    e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = v.x; e[5] = v.y; e[6] = v.z; e[7] = v.w;
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += e[i];

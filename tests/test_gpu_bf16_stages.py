@@ -245,3 +245,52 @@ def test_wide_mixer_inside_the_call_bf16():
   assert v['argmax_flip_rate'] < 0.005, rec
   assert v['tracks_px']['median'] < 0.006 and v['tracks_px']['p99'] < 0.017 and v['tracks_px']['max'] < 0.04, rec
   assert v['occlusion_logit']['median'] < 0.004 and v['occlusion_logit']['p99'] < 0.015, rec
+
+
+@pytest.mark.parametrize('N,T,causal', [(256, 1, True), (70, 1, True), (512, 1, True), (1, 1, True), (40, 7, False),
+                                        (46, 11, False)])
+def test_few_row_one_launch_mlp_vs_oracle(N, T, causal):
+  """The few-row mixer of the online model and of small query shards (N x T <= 512 rows): the channel MLP of a block as
+  ONE launch (csrc/gemm.hpp mlp_small_kernel, tapir_debug_set_gemm_mode 2 = default) whose partial outputs the next
+  mix_kernel / the final LayerNorm add -- against the rounding oracle and against the two-launch form (mode 1), all 12
+  blocks, with causal context in and out for the single-frame case.  tapir_model.py:33-156."""
+  pyr = 1
+  w = synthetic.make_weights(80 + N, pyr, False, backbone=False)
+  m = _model(pyr, weights=w, use_causal_conv=causal)
+  rng = np.random.default_rng(100 * N + T)
+  x = rng.standard_normal((N, T, 388 + 49 * (2 + pyr))).astype(np.float32)
+  nb = 12
+  c1 = rng.standard_normal((nb, N, 2, 512)).astype(np.float32) if causal else None
+  c2 = rng.standard_normal((nb, N, 2, 2048)).astype(np.float32) if causal else None
+  outs = {}
+  for mode in (2, 1):
+    assert m._lib.tapir_debug_set_gemm_mode(m._ctx, mode) == 0
+    xt = torch.as_tensor(x, device='cuda').contiguous()
+    out = torch.empty((N, T, 388), device='cuda', dtype=torch.float32)
+    ci = [torch.as_tensor(c, device='cuda').contiguous() if causal else None for c in (c1, c2)]
+    co = [torch.zeros_like(c) if causal else None for c in ci]
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    m._check(m._lib.tapir_pips_mixer(m._ctx, xt.data_ptr(), N, T, out.data_ptr(), ptr(ci[0]), ptr(ci[1]), ptr(co[0]),
+                                     ptr(co[1]), m._stream()), 'tapir_pips_mixer')
+    torch.cuda.synchronize()
+    outs[mode] = (out.cpu().numpy(), [c.cpu().numpy() if c is not None else None for c in co])
+  assert m._lib.tapir_debug_set_gemm_mode(m._ctx, 2) == 0
+  ctx = None
+  if causal:
+    ctx = {}
+    for i in range(nb):
+      ctx[f'block_{i}_causal_1'] = c1[i]
+      ctx[f'block_{i}_causal_2'] = c2[i]
+  ref16, new_ctx = O.pips_mlp_mixer(w, x, use_causal_conv=causal, causal_context=ctx, get_causal_context=causal,
+                                    rnd=O.bf16_round)
+  s16, s12 = _dev_stats(outs[2][0], ref16), _dev_stats(outs[2][0], outs[1][0])
+  _record(f'mlp_small[N={N},T={T},causal={causal}]', vs_rounding_oracle=s16, vs_two_launches=s12)
+  assert s16['max'] < 8e-3 and s16['median'] < 8e-4, s16
+  assert s12['max'] < 9e-3 and s12['median'] < 8e-4, s12
+  if N * T > 8:
+    assert s12['max'] > 0        # another summation order: the one-launch kernel really ran
+  if causal:
+    for i in (0, nb - 1):
+      np.testing.assert_allclose(outs[2][1][0][i], new_ctx[f'block_{i}_causal_1'], atol=2e-2)
+      np.testing.assert_allclose(outs[2][1][1][i], new_ctx[f'block_{i}_causal_2'], atol=2e-2)
+      np.testing.assert_allclose(outs[2][1][0][i], outs[1][1][0][i], atol=2e-2)

@@ -141,6 +141,21 @@ if [ "$PART" == "small" ]; then
   done
   timeout 900 python -m pytest tests -m gpu -q -x -k "online or causal or jax" 2>&1 | tail -5 | tee $OUT/pytest_online.log
 fi
+if [ "$PART" == "mlp" ]; then
+  # the one-launch channel MLP of the few-row mixer (gemm.hpp mlp_small_kernel): parity, the online step with and without it, one frame launch by launch
+  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row" 2>&1 | tail -5 | tee $OUT/pytest_mlp.log
+  for rep in 1 2; do
+    for gm in 1 2; do
+      timeout 300 python tools/bench_online.py --frames 120 --gemm-mode $gm 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed "s/^/gemm_mode $gm /" | tee -a $OUT/ab_mlp_summary.txt
+    done
+  done
+  timeout 1200 python -m pytest tests -m gpu -q -x -k "online or causal or jax or distributed or sharded" 2>&1 | tail -5 | tee $OUT/pytest_online.log
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace -d $R/$OUT/prof_online -o online -- python $R/tools/bench_online.py --frames 30 --eager-only > $R/$OUT/online_under_trace.json 2> $R/$OUT/rocprof_online.err
+  cd $R; for f in $(find $OUT/prof_online -name '*.db'); do python tools/online_timeline.py $f 3 > $OUT/online_timeline_mlp.txt 2>&1; done
+  find $OUT/prof_online -name '*.db' -size +20M -delete
+  head -40 $OUT/online_timeline_mlp.txt | cut -c1-150
+fi
 if [ "$PART" == "onlinetl" ]; then
   # one online frame launch by launch, with and without the few-frame convolutions
   for m in 1 0; do
