@@ -438,11 +438,18 @@ int tapir_debug_set_cv_mode(tapir_ctx* ctx, int mode);
  * LDS, no heads); scratch = B*T*ceil(Q/8) floats. */
 int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* grid, int B, int Q, int T, int h, int w,
                             float* scratch, void* stream);
-/* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 2 (default) = 1, and the channel MLP of a
- * block (up-projection + gelu + down-projection, tapir_model.py:127-156) as ONE launch whose partial outputs the next
- * consumer of the residual stream adds (csrc/gemm.hpp mlp_small_kernel); 1 = one launch of the whole-K small-tile kernel per
- * GEMM; 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements). */
+/* Few-row GEMMs of the mixer (the online model, M = points x 1 frame <= 512 rows): 3 (default) = 2, and the online model's
+ * whole mixer (one frame, use_causal_conv, <= 256 points: every block and the final LayerNorm, tapir_model.py:33-156) as ONE
+ * persistent launch of 256 workgroups in 8 clusters that meet on bounded counters (csrc/mixer_online.hpp; devices with >= 256
+ * CUs, else 2); 2 = 1, and the channel MLP of a block (up-projection + gelu + down-projection, tapir_model.py:127-156) as ONE
+ * launch whose partial outputs the next consumer of the residual stream adds (csrc/gemm.hpp mlp_small_kernel); 1 = one launch
+ * of the whole-K small-tile kernel per GEMM; 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements).
+ * Modes 1-3 give the same bits (3 = 2 exactly; 1 differs from 2 by the summation order of the down-projection). */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
+/* The persistent launch above bounds every wait: a workgroup that waited ~2 s for its cluster (the device could not hold the 256
+ * workgroups at once) writes an error word, every member leaves, and the mixer's rows are NaN -- loud in the tracks.  Reads
+ * the word of the LAST such launch (0 = no error; synchronises the device).  Never set on an otherwise idle MI355X. */
+int tapir_online_sync_error(tapir_ctx* ctx, unsigned* word);
 /* The 3x3 256 -> 256 block convolutions (tapir_conv_fused*): 1 = always the flat tiling of the whole launch
  * (csrc/conv_flat.hpp: three consecutive 64-pixel slabs of the (image, row) space per workgroup) where the shape allows it,
  * 0 (default) = never, -1 = from 96 slabs per launch on.  The forms are bit-identical (tests); the flat form is faster as one

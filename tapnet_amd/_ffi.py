@@ -130,6 +130,7 @@ PROTOTYPES = {
     'tapir_debug_set_patch_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_contraction': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tapir_debug_set_gemm_mode': (c_int, [c_void_p, c_int]),
+    'tapir_online_sync_error': (c_int, [c_void_p, POINTER(ctypes.c_uint)]),
     'tapir_debug_set_update_mode': (c_int, [c_void_p, c_int]),
     'tapir_debug_set_conv_flat': (c_int, [c_void_p, c_int]),
     'tapir_conv_flat_plan': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),

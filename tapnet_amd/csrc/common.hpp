@@ -42,11 +42,36 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 };
 template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ void st2(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack_bf16x2(a, b); }
 };
+
+// Loads through pointers the compiler cannot prove global (read from a device table: mixer_online.hpp) are FLAT loads, which
+// count on the LDS counter as well: every LDS wait then waits for them.  These say "global" at the load.
+typedef unsigned tapir_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tapir_f32x4 __attribute__((ext_vector_type(4)));
+typedef float tapir_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef TAPIR_HIPEMU
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ tapir_f32x4 ldg_f4(const float* p) { return *reinterpret_cast<const tapir_f32x4*>(p); }
+__device__ __forceinline__ float2 ldg_f2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float ldg_f(const float* p) { return *p; }
+#else
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+  const tapir_u32x4 v = *(const __attribute__((address_space(1))) tapir_u32x4*)p;
+  return __builtin_bit_cast(uint4, v);
+}
+__device__ __forceinline__ tapir_f32x4 ldg_f4(const float* p) { return *(const __attribute__((address_space(1))) tapir_f32x4*)p; }
+__device__ __forceinline__ float2 ldg_f2(const float* p) {
+  const tapir_f32x2 v = *(const __attribute__((address_space(1))) tapir_f32x2*)p;
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float ldg_f(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
+#endif
 
 // Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The hardware writes lane
 // l's 16 bytes to M0 + l * 16, M0 = the FIRST lane's `lds` argument: pass the wave's base address

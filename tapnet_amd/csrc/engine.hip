@@ -24,6 +24,7 @@
 #include "mixer.hpp"
 #include "mixer_fused.hpp"
 #include "mixer_fused_wide.hpp"
+#include "mixer_online.hpp"
 #include "pips.hpp"
 
 using namespace tapir;
@@ -98,7 +99,9 @@ struct tapir_ctx {
   int conv_small = 0;                             // block convolutions of FEW-frame clips (the online model): 1 = conv_small_kernel (conv_small.hpp) where the shape
                                                   // allows it; set per clip by the caller's backbone (tapir_conv_set_small), follows the WHOLE clip's frame count
   int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
-  int small_gemm = 2;                             // few-row GEMMs: 2 = 1 + the channel MLP of a block in ONE launch (mlp_small_kernel), 1 = gemm_small_kernel (one launch each), 0 = split-K + reduce
+  int small_gemm = 3;                             // few-row GEMMs: 3 = 2 + the online model's mixer (one frame, causal, <= 256 rows) as ONE persistent launch over all blocks (mixer_online.hpp), 2 = 1 + the channel MLP of a block in ONE launch (mlp_small_kernel), 1 = gemm_small_kernel (one launch each), 0 = split-K + reduce
+  int online_form = 0;                            // (tests, TAPIR_ONLINE_FORM) bit 0: a cluster of the persistent launch on ONE XCD (default: the members that read the same weight slice on one XCD); bit 1: acquire + plain loads instead of sc1 loads
+  int n_cus = 0;                                  // compute units of the device (the persistent launch needs its 256 workgroups resident at once)
 
   // workspaces
   DevBuf cv, mlp_in, xa, xb, xn, hid, res, pos, occ, expd, occ0, expd0, feats, qpts;
@@ -109,6 +112,8 @@ struct tapir_ctx {
   DevBuf grid_tiled;                 // bf16 low-res grid in the cost-volume kernel's operand order (pips.hpp: PoolArgs::tiled)
   const float* tiled_src = nullptr;  // which grid it holds (valid together with cast_src[1])
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
+  DevBuf online_sync;               // mixer_online.hpp: cluster counters + error word (zeroed in-stream before every launch)
+  OnlineBlockW* online_blocks = nullptr;   // device table of the blocks' parameters
   int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
   void* dbg_times = nullptr;   // tools only: device buffer for kernel phase stamps (tapir_debug_set_trace)
   // which caller grid each cast slot currently holds (valid within one call)
@@ -861,7 +866,28 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   if (mlp1) TRY(ensure(c, c->splitk, (size_t)nparts * R * kHidden * 4));
   float* res_prev = nullptr;      // mlp1: the residual stream the previous block's MLP read (that block's x_out)
   const float* bdn_prev = nullptr;
-  for (int i = 0; i < nb; ++i) {
+  // the online model (one frame, causal, <= 256 rows): every block in ONE persistent launch (mixer_online.hpp), the final
+  // LayerNorm included
+  bool persistent = false;
+#ifndef TAPIR_HIPEMU
+  persistent = c->small_gemm >= 3 && mlp1 && mixer_online_supported(N, T, c->cfg.use_causal_conv != 0) &&
+               c->n_cus >= ONL_CLUSTERS * ONL_MEMBERS && (ctx1_out == nullptr) == (ctx2_out == nullptr);
+  if (persistent) {
+    TRY(ensure(c, c->online_sync, (size_t)ONL_SYNC_WORDS * 4));
+    HIP_TRY(c, hipMemsetAsync(c->online_sync.p, 0, (size_t)ONL_SYNC_WORDS * 4, s));
+    MixerOnlineArgs oa{};
+    oa.x_in = (const float*)c->xa.p; oa.xn = c->xn.p; oa.part = (float*)c->splitk.p;
+    oa.blocks = c->online_blocks; oa.lnF = c->lnF;
+    oa.ctx1_in = ctx1_in; oa.ctx2_in = ctx2_in; oa.ctx1_out = ctx1_out; oa.ctx2_out = ctx2_out;
+    oa.sync = (unsigned*)c->online_sync.p; oa.M = N; oa.nb = nb;
+    oa.by_xcd = (c->online_form & 1) ? 1 : 0;
+    oa.dbg_times = (long long*)c->dbg_times;
+    ProfScope ps(c, TAPIR_PROF_MIX, s);
+    if (sizeof(TA) == 2) launch_mixer_online<bf16_t>(oa, s, (c->online_form & 2) != 0);
+    else launch_mixer_online<float>(oa, s, (c->online_form & 2) != 0);
+  }
+#endif
+  for (int i = 0; i < nb && !persistent; ++i) {
     const BlockW& bw = c->blocks[i];
     MixArgs m{};
     m.x_in = (const float*)c->xa.p; m.x_out = (float*)c->xb.p; m.xn2 = c->xn.p;
@@ -903,7 +929,7 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   }
   LnArgs la{(const float*)c->xa.p, c->lnF, c->xn.p, R};
   if (mlp1 && nb > 0) { la.parts = (const float*)c->splitk.p; la.nparts = nparts; la.pbias = bdn_prev; la.presid = res_prev; }
-  hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
+  if (!persistent) hipLaunchKernelGGL((layernorm_kernel<TA>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, la);
   GemmArgs g{};
   g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
   g.C = c->res.p; g.ldc = kMixOut; g.M = (int)R; g.N = kMixOut; g.K = kHidden;
@@ -1201,7 +1227,11 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   c->k0_pad = (c->in_dim + kq - 1) / kq * kq;
   // (same-box A/B of builds from outside the process: environment switches)
   if (const char* e = getenv("TAPIR_FUSE_UPDATE")) c->fuse_update = atoi(e) != 0;
-  if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_ONLINE_FORM")) c->online_form = atoi(e) & 3;
+  if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = std::min(3, std::max(0, atoi(e)));
+#ifndef TAPIR_HIPEMU
+  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->n_cus = n; }
+#endif
   if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
@@ -1309,6 +1339,14 @@ static int finalize_tapir(tapir_ctx* c) {
     TRY(upload_matrix(c, t->data.data(), kHidden, kHidden4, kHidden4, &b.Wdn));
     TRY(get_w(c, p + "conv_channels_mixer.mlp2_down.bias", {kHidden}, &t)); TRY(upload_f32(c, t->data.data(), kHidden, &b.bdn));
     c->blocks.push_back(b);
+  }
+  {
+    std::vector<OnlineBlockW> tab;
+    for (const BlockW& b : c->blocks) tab.push_back(OnlineBlockW{b.ln1, b.w1, b.b1, b.w2, b.b2, b.ln2, b.Wup, b.bup, b.Wdn, b.bdn});
+    float* d = nullptr;
+    static_assert(sizeof(OnlineBlockW) % 4 == 0, "table uploaded as words");
+    TRY(upload_f32(c, reinterpret_cast<const float*>(tab.data()), tab.size() * sizeof(OnlineBlockW) / 4, &d));
+    c->online_blocks = reinterpret_cast<OnlineBlockW*>(d);
   }
   if (c->cfg.num_mixer_blocks <= FM_MAX_BLOCKS) {
     if (c->cfg.dtype == TAPIR_BF16) {
@@ -2023,9 +2061,18 @@ int tapir_debug_poison_lds(tapir_ctx* c, unsigned pattern, void* stream) {
   return TAPIR_OK;
 }
 
+int tapir_online_sync_error(tapir_ctx* c, unsigned* word) {
+  if (!c || !word) return TAPIR_ERR_INVALID;
+  *word = 0;
+  if (c->online_sync.p == nullptr) return TAPIR_OK;      // the persistent launch never ran
+  HIP_TRY(c, hipMemcpy(word, (const unsigned*)c->online_sync.p + 16 * ONL_CLUSTERS, 4, hipMemcpyDeviceToHost));
+  return TAPIR_OK;
+}
+
 int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 2) return TAPIR_ERR_INVALID;
-  c->small_gemm = mode;
+  if (!c || mode < 0 || mode > 3 + 4 * 3) return TAPIR_ERR_INVALID;   // (tests) + 4 x the persistent launch's form bits
+  c->small_gemm = mode & 3;
+  c->online_form = mode >> 2;
   return TAPIR_OK;
 }
 

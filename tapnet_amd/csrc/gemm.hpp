@@ -953,106 +953,158 @@ struct MlpSmallArgs {
   float* part;         // [2048 / MLP_HS][M, 512] f32 partial outputs (no bias, no residual)
   int M;
 };
+// One (row tile, hidden slice) unit of the kernel above, split into "request the weights", "request the rows" and "compute +
+// store", so that the persistent form (mixer_online.hpp) can request a block's weights before it waits for the rows.
 template <typename TA>
-__global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
-  constexpr int EPC = 16 / (int)sizeof(TA);          // elements per 16-byte chunk
-  constexpr int KS = 4 * EPC;                        // k per MFMA step
-  constexpr int K1 = 128 / KS;                       // k-steps of a wave's quarter of K = 512 (bf16: 4, f32: 8)
-  constexpr int K2 = MLP_HS / KS;                    // k-steps of the second product (bf16: 2, f32: 4)
-  constexpr int LDH = MLP_HS + EPC;                  // hidden row stride in LDS (+ one chunk: rows 16 lanes apart on different banks)
-  constexpr bool EARLY = sizeof(TA) == 2;            // W_dn's fragments requested before phase 1 (f32: too many registers; parity build)
-  __shared__ f32x4 s_part[4][8][64];                 // the four waves' partial hidden tiles (fragment layout)
-  __shared__ __attribute__((aligned(16))) TA s_hid[32 * LDH];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, gq = lane >> 4;
-  constexpr int slices = 2048 / MLP_HS;
-  const int tm = blockIdx.x / slices, sl = blockIdx.x - tm * slices;
-  const int m0 = tm * 32, h0 = sl * MLP_HS;
-  const TA* A = reinterpret_cast<const TA*>(g.xn);
-  const TA* Wu = reinterpret_cast<const TA*>(g.Wup);
-  const TA* Wd = reinterpret_cast<const TA*>(g.Wdn);
-  // ---- every operand of this wave, requested now: W_up rows h0 + 16 j + c and the tile's rows over k in [128 wave, 128 wave + 128),
-  // W_dn rows (output columns) 128 wave + 16 j + c over the slice's 64 hidden units
+struct MlpSmallTile {
+  static constexpr int EPC = 16 / (int)sizeof(TA);   // elements per 16-byte chunk
+  static constexpr int KS = 4 * EPC;                 // k per MFMA step
+  static constexpr int K1 = 128 / KS;                // k-steps of a wave's quarter of K = 512 (bf16: 4, f32: 8)
+  static constexpr int K2 = MLP_HS / KS;             // k-steps of the second product (bf16: 2, f32: 4)
+  static constexpr int LDH = MLP_HS + EPC;           // hidden row stride in LDS (+ one chunk: rows 16 lanes apart on different banks)
+  static constexpr bool EARLY = sizeof(TA) == 2;     // W_dn's fragments requested with W_up's (f32: too many registers; parity build)
   uint4 fw[K1][4], fa[K1][2], fd[K2][8];
-#pragma unroll
-  for (int ks = 0; ks < K1; ++ks) {
-    const int k = 128 * wave + ks * KS + EPC * gq;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fw[ks][j] = *reinterpret_cast<const uint4*>(Wu + (long)(h0 + 16 * j + c) * 512 + k);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fa[ks][i] = *reinterpret_cast<const uint4*>(A + (long)min(m0 + 16 * i + c, g.M - 1) * 512 + k);
+  int wave, c, gq;
+  __device__ __forceinline__ void init() {
+    const int lane = threadIdx.x & 63;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c = lane & 15; gq = lane >> 4;
   }
-  auto load_dn = [&]() {
+  // W_dn rows (output columns) 128 wave + 16 j + c over the slice's 64 hidden units
+  __device__ __forceinline__ void load_dn(const void* Wdn, int h0) {
+    const TA* Wd = reinterpret_cast<const TA*>(Wdn);
 #pragma unroll
     for (int ks = 0; ks < K2; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        fd[ks][j] = *reinterpret_cast<const uint4*>(Wd + (long)(128 * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
-  };
-  if (EARLY) load_dn();
-  // ---- phase 1: this wave's quarter of K
-  {
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fd[ks][j] = ldg16(Wd + (long)(128 * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
+  }
+  // W_up rows h0 + 16 j + c over k in [128 wave, 128 wave + 128)
+  __device__ __forceinline__ void load_weights(const void* Wup, const void* Wdn, int h0) {
+    const TA* Wu = reinterpret_cast<const TA*>(Wup);
 #pragma unroll
     for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
+        fw[ks][j] = ldg16(Wu + (long)(h0 + 16 * j + c) * 512 + 128 * wave + ks * KS + EPC * gq);
+    if (EARLY) load_dn(Wdn, h0);
   }
-  if (!EARLY) load_dn();
-  __syncthreads();
-  // wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units h0 + 16 j + 4 gq + e of row 16 i + c
+  // the tile's rows over the same k range (rows past M: clamped, computed and never stored)
+  __device__ __forceinline__ void load_rows(const void* xn, int m0, int M) {
+    const TA* A = reinterpret_cast<const TA*>(xn);
 #pragma unroll
-  for (int f0 = 0; f0 < 8; f0 += 4) {
-    const int f = f0 + wave;
-    const int j = f >> 1, i = f & 1;
-    f32x4 v = s_part[0][f][lane];
-    v = v + s_part[1][f][lane];
-    v = v + s_part[2][f][lane];
-    v = v + s_part[3][f][lane];
-    const int hl = 16 * j + 4 * gq;
-    v = v + *reinterpret_cast<const f32x4*>(g.bup + h0 + hl);
-    Store4<TA>::run(&s_hid[(16 * i + c) * LDH + hl], gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
+    for (int ks = 0; ks < K1; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[ks][i] = ldg16(A + (long)min(m0 + 16 * i + c, M - 1) * 512 + 128 * wave + ks * KS + EPC * gq);
   }
-  __syncthreads();
-  // ---- phase 2: part[sl][rows, 128 wave .. 128 wave + 127]
-  {
-    f32x4 acc[8][2];
+#ifndef TAPIR_HIPEMU
+  // the same rows handed over by other workgroups of this launch (mixer_online.hpp): loads past L1 (sc1)
+  __device__ __forceinline__ void load_rows_shared(__amdgpu_buffer_rsrc_t xn, int m0, int M) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 2; ++i) {
+        const int off = (min(m0 + 16 * i + c, M - 1) * 512 + 128 * wave + ks * KS + EPC * gq) * (int)sizeof(TA);
+        fa[ks][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xn, off, 0, 16));
+      }
+  }
+#endif
+  // SHARED: the partial outputs go to other workgroups of this launch: write-through (sc1) 16-byte stores through `prsrc`
+  template <bool SHARED = false>
+  __device__ __forceinline__ void run(const float* bup, const void* Wdn, float* part, int m0, int sl, int M,
+                                      f32x4 (*s_part)[8][64], TA* s_hid
+#ifndef TAPIR_HIPEMU
+                                      , __amdgpu_buffer_rsrc_t prsrc = __amdgpu_buffer_rsrc_t()
+#endif
+                                      ) {
+    const int lane = threadIdx.x & 63;
+    const int h0 = sl * MLP_HS;
+    // ---- phase 1: this wave's quarter of K
+    {
+      f32x4 acc[4][2];
 #pragma unroll
-    for (int ks = 0; ks < K2; ++ks) {
-      uint4 fh[2];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
+        for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < K1; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
+    }
+    if (!EARLY) load_dn(Wdn, h0);
+    __syncthreads();
+    // wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units h0 + 16 j + 4 gq + e of row 16 i + c
+#pragma unroll
+    for (int f0 = 0; f0 < 8; f0 += 4) {
+      const int f = f0 + wave;
+      const int j = f >> 1, i = f & 1;
+      f32x4 v = s_part[0][f][lane];
+      v = v + s_part[1][f][lane];
+      v = v + s_part[2][f][lane];
+      v = v + s_part[3][f][lane];
+      const int hl = 16 * j + 4 * gq;
+      v = v + ldg_f4(bup + h0 + hl);
+      Store4<TA>::run(&s_hid[(16 * i + c) * LDH + hl], gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
+    }
+    __syncthreads();
+    // ---- phase 2: part[sl][rows, 128 wave .. 128 wave + 127]
+    {
+      f32x4 acc[8][2];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
-    }
-    float* out = g.part + (long)sl * g.M * 512;
+        for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + 16 * i + c;
-      if (m < g.M) {
+      for (int ks = 0; ks < K2; ++ks) {
+        uint4 fh[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
+        for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
+      }
+      float* out = part + (long)sl * M * 512;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 16 * i + c;
+        if (m < M) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#ifndef TAPIR_HIPEMU
+            if (SHARED) {
+              typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+              const int off = (((sl * M + m) * 512) + 128 * wave + 16 * j + 4 * gq) * 4;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), prsrc, off, 0, 16);
+              continue;
+            }
+#endif
+            *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
+          }
+        }
       }
     }
   }
+};
+template <typename TA>
+__global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
+  __shared__ f32x4 s_part[4][8][64];                 // the four waves' partial hidden tiles (fragment layout)
+  __shared__ __attribute__((aligned(16))) TA s_hid[32 * MlpSmallTile<TA>::LDH];
+  constexpr int slices = 2048 / MLP_HS;
+  const int tm = blockIdx.x / slices, sl = blockIdx.x - tm * slices;
+  MlpSmallTile<TA> t;
+  t.init();
+  // every operand of this wave, requested now
+  t.load_weights(g.Wup, g.Wdn, sl * MLP_HS);
+  t.load_rows(g.xn, tm * 32, g.M);
+  t.run(g.bup, g.Wdn, g.part, tm * 32, sl, g.M, s_part, s_hid);
 }
 inline bool mlp_small_supported(int M) { return M >= 1 && M <= 512; }
 template <typename TA>

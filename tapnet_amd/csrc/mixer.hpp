@@ -61,6 +61,18 @@ __device__ __forceinline__ float2 parts_sum2(const float* parts, int /*nparts*/,
   return make_float2((v.x + b.x) + x.x, (v.y + b.y) + x.y);
 }
 
+// the same with the residual's two values in registers (mixer_online.hpp)
+__device__ __forceinline__ float2 parts_sum2v(const float* parts, long rows, const float* bias, float2 x, long r, int col) {
+  float2 w[MLP_PARTS];
+#pragma unroll
+  for (int p = 0; p < MLP_PARTS; ++p) w[p] = *reinterpret_cast<const float2*>(parts + ((long)p * rows + r) * kHidden + col);
+  const float2 b = *reinterpret_cast<const float2*>(bias + col);
+  float2 v = w[0];
+#pragma unroll
+  for (int p = 1; p < MLP_PARTS; ++p) { v.x += w[p].x; v.y += w[p].y; }
+  return make_float2((v.x + b.x) + x.x, (v.y + b.y) + x.y);
+}
+
 // Row statistics by ONE wave: the lane holds channels [4*lane, 4*lane+4) and
 // [256+4*lane, 256+4*lane+4) of the row.
 __device__ __forceinline__ void wave_row_stats(const float4& u, const float4& v, float& mean,

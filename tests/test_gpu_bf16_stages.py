@@ -248,12 +248,15 @@ def test_wide_mixer_inside_the_call_bf16():
 
 
 @pytest.mark.parametrize('N,T,causal', [(256, 1, True), (70, 1, True), (512, 1, True), (1, 1, True), (40, 7, False),
-                                        (46, 11, False)])
+                                        (46, 11, False), (33, 1, True), (225, 1, True)])
 def test_few_row_one_launch_mlp_vs_oracle(N, T, causal):
   """The few-row mixer of the online model and of small query shards (N x T <= 512 rows): the channel MLP of a block as
   ONE launch (csrc/gemm.hpp mlp_small_kernel, tapir_debug_set_gemm_mode 2 = default) whose partial outputs the next
   mix_kernel / the final LayerNorm add -- against the rounding oracle and against the two-launch form (mode 1), all 12
-  blocks, with causal context in and out for the single-frame case.  tapir_model.py:33-156."""
+  blocks, with causal context in and out for the single-frame case.  And the online model's persistent form (mode 3 =
+  default: csrc/mixer_online.hpp, one launch for all 12 blocks, clusters of 32 workgroups meeting on bounded counters; one
+  frame, causal, <= 256 rows -- every other case here runs mode 2 under mode 3): the same bits as mode 2, outputs and new
+  context, and no error word.  tapir_model.py:33-156."""
   pyr = 1
   w = synthetic.make_weights(80 + N, pyr, False, backbone=False)
   m = _model(pyr, weights=w, use_causal_conv=causal)
@@ -263,18 +266,28 @@ def test_few_row_one_launch_mlp_vs_oracle(N, T, causal):
   c1 = rng.standard_normal((nb, N, 2, 512)).astype(np.float32) if causal else None
   c2 = rng.standard_normal((nb, N, 2, 2048)).astype(np.float32) if causal else None
   outs = {}
-  for mode in (2, 1):
+  for mode in (3, 3 + 4, 3 + 8, 3 + 12, 2, 1, 3):     # + 4: a cluster per XCD instead of a weight slice per XCD; + 8: acquire + plain loads instead of sc1 loads
     assert m._lib.tapir_debug_set_gemm_mode(m._ctx, mode) == 0
     xt = torch.as_tensor(x, device='cuda').contiguous()
-    out = torch.empty((N, T, 388), device='cuda', dtype=torch.float32)
+    out = torch.full((N, T, 388), float('nan'), device='cuda', dtype=torch.float32)
     ci = [torch.as_tensor(c, device='cuda').contiguous() if causal else None for c in (c1, c2)]
     co = [torch.zeros_like(c) if causal else None for c in ci]
     ptr = lambda t: t.data_ptr() if t is not None else None
     m._check(m._lib.tapir_pips_mixer(m._ctx, xt.data_ptr(), N, T, out.data_ptr(), ptr(ci[0]), ptr(ci[1]), ptr(co[0]),
                                      ptr(co[1]), m._stream()), 'tapir_pips_mixer')
     torch.cuda.synchronize()
-    outs[mode] = (out.cpu().numpy(), [c.cpu().numpy() if c is not None else None for c in co])
-  assert m._lib.tapir_debug_set_gemm_mode(m._ctx, 2) == 0
+    new = (out.cpu().numpy(), [c.cpu().numpy() if c is not None else None for c in co])
+    if mode in outs:      # the persistent launch a second time: the same bits
+      assert np.array_equal(new[0], outs[mode][0])
+    outs[mode] = new
+  import ctypes
+  word = ctypes.c_uint(7)
+  assert m._lib.tapir_online_sync_error(m._ctx, ctypes.byref(word)) == 0 and word.value == 0, hex(word.value)
+  assert np.isfinite(outs[3][0]).all()
+  for form in (3, 7, 11, 15):
+    assert np.array_equal(outs[form][0], outs[2][0]), form
+    if causal:
+      assert np.array_equal(outs[form][1][0], outs[2][1][0]) and np.array_equal(outs[form][1][1], outs[2][1][1]), form
   ctx = None
   if causal:
     ctx = {}

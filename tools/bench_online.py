@@ -25,7 +25,7 @@ def main():
   ap.add_argument('--size', type=int, default=256)
   ap.add_argument('--dtype', default='bf16')
   ap.add_argument('--eager-only', action='store_true', help='one configuration, eager launches (kernel traces)')
-  ap.add_argument('--gemm-mode', type=int, default=2, help='0 = split-K + reduce pair (round 2), 1 = one-launch few-row GEMMs, 2 = 1 + the channel MLP of a block in one launch (the engine default)')
+  ap.add_argument('--gemm-mode', type=int, default=3, help='0 = split-K + reduce pair (round 2), 1 = one-launch few-row GEMMs, 2 = 1 + the channel MLP of a block in one launch, 3 = 2 + the whole mixer of a frame as one persistent launch (the engine default)')
   args = ap.parse_args()
   dtype = 'bfloat16' if args.dtype == 'bf16' else 'float32'
   w = synthetic.make_weights(0, pyramid_level=1, extra_convs=True)   # the causal checkpoint's kwargs

@@ -143,9 +143,9 @@ if [ "$PART" == "small" ]; then
 fi
 if [ "$PART" == "mlp" ]; then
   # the one-launch channel MLP of the few-row mixer (gemm.hpp mlp_small_kernel): parity, the online step with and without it, one frame launch by launch
-  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row" 2>&1 | tail -5 | tee $OUT/pytest_mlp.log
+  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row" 2>&1 | tail -25 | tee $OUT/pytest_mlp.log
   for rep in 1 2; do
-    for gm in 1 2; do
+    for gm in 2 3 7 11; do
       timeout 300 python tools/bench_online.py --frames 120 --gemm-mode $gm 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed "s/^/gemm_mode $gm /" | tee -a $OUT/ab_mlp_summary.txt
     done
   done
@@ -155,6 +155,16 @@ if [ "$PART" == "mlp" ]; then
   cd $R; for f in $(find $OUT/prof_online -name '*.db'); do python tools/online_timeline.py $f 3 > $OUT/online_timeline_mlp.txt 2>&1; done
   find $OUT/prof_online -name '*.db' -size +20M -delete
   head -40 $OUT/online_timeline_mlp.txt | cut -c1-150
+fi
+if [ "$PART" == "onl" ]; then
+  # the persistent mixer of the online model: parity, phase stamps, the online step per form
+  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row" 2>&1 | tail -5 | tee $OUT/pytest_mlp.log
+  for f in 0 1; do timeout 300 python tools/probe_online_mixer.py --form $f 2>&1 | grep -v amdgpu.ids | tee $OUT/probe_online_form$f.txt; done
+  for rep in 1 2; do
+    for gm in 2 3 7; do
+      timeout 300 python tools/bench_online.py --frames 120 --gemm-mode $gm 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed "s/^/gemm_mode $gm /" | tee -a $OUT/ab_mlp_summary.txt
+    done
+  done
 fi
 if [ "$PART" == "onlinetl" ]; then
   # one online frame launch by launch, with and without the few-frame convolutions
