@@ -100,7 +100,7 @@ struct tapir_ctx {
                                                   // allows it; set per clip by the caller's backbone (tapir_conv_set_small), follows the WHOLE clip's frame count
   int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
   int small_gemm = 3;                             // few-row GEMMs: 3 = 2 + the online model's mixer (one frame, causal, <= 256 rows) as ONE persistent launch over all blocks (mixer_online.hpp), 2 = 1 + the channel MLP of a block in ONE launch (mlp_small_kernel), 1 = gemm_small_kernel (one launch each), 0 = split-K + reduce
-  int online_form = 0;                            // (tests, TAPIR_ONLINE_FORM) bit 0: a cluster of the persistent launch on ONE XCD (default: the members that read the same weight slice on one XCD); bit 1: acquire + plain loads instead of sc1 loads
+  int online_form = 0;                            // (tests, TAPIR_ONLINE_FORM) bit 0: a cluster of the persistent launch on ONE XCD (default: the members that read the same weight slice on one XCD); bit 1: acquire + plain loads instead of sc1 loads; bit 2: one member never arrives (the timeout path)
   int n_cus = 0;                                  // compute units of the device (the persistent launch needs its 256 workgroups resident at once)
 
   // workspaces
@@ -881,6 +881,8 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     oa.ctx1_in = ctx1_in; oa.ctx2_in = ctx2_in; oa.ctx1_out = ctx1_out; oa.ctx2_out = ctx2_out;
     oa.sync = (unsigned*)c->online_sync.p; oa.M = N; oa.nb = nb;
     oa.by_xcd = (c->online_form & 1) ? 1 : 0;
+    oa.drop_member = (c->online_form & 4) ? 1 : 0;
+    oa.spin_limit = oa.drop_member ? (1u << 14) : ONL_SPIN_LIMIT;
     oa.dbg_times = (long long*)c->dbg_times;
     ProfScope ps(c, TAPIR_PROF_MIX, s);
     if (sizeof(TA) == 2) launch_mixer_online<bf16_t>(oa, s, (c->online_form & 2) != 0);
@@ -2070,7 +2072,7 @@ int tapir_online_sync_error(tapir_ctx* c, unsigned* word) {
 }
 
 int tapir_debug_set_gemm_mode(tapir_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 3 + 4 * 3) return TAPIR_ERR_INVALID;   // (tests) + 4 x the persistent launch's form bits
+  if (!c || mode < 0 || mode > 3 + 4 * 7) return TAPIR_ERR_INVALID;   // (tests) + 4 x the persistent launch's form bits
   c->small_gemm = mode & 3;
   c->online_form = mode >> 2;
   return TAPIR_OK;

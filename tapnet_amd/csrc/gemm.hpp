@@ -980,14 +980,13 @@ struct MlpSmallTile {
         fd[ks][j] = ldg16(Wd + (long)(128 * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
   }
   // W_up rows h0 + 16 j + c over k in [128 wave, 128 wave + 128)
-  __device__ __forceinline__ void load_weights(const void* Wup, const void* Wdn, int h0) {
+  __device__ __forceinline__ void load_up(const void* Wup, int h0) {
     const TA* Wu = reinterpret_cast<const TA*>(Wup);
 #pragma unroll
     for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         fw[ks][j] = ldg16(Wu + (long)(h0 + 16 * j + c) * 512 + 128 * wave + ks * KS + EPC * gq);
-    if (EARLY) load_dn(Wdn, h0);
   }
   // the tile's rows over the same k range (rows past M: clamped, computed and never stored)
   __device__ __forceinline__ void load_rows(const void* xn, int m0, int M) {
@@ -1010,37 +1009,30 @@ struct MlpSmallTile {
       }
   }
 #endif
-  // SHARED: the partial outputs go to other workgroups of this launch: write-through (sc1) 16-byte stores through `prsrc`
-  template <bool SHARED = false>
-  __device__ __forceinline__ void run(const float* bup, const void* Wdn, float* part, int m0, int sl, int M,
-                                      f32x4 (*s_part)[8][64], TA* s_hid
-#ifndef TAPIR_HIPEMU
-                                      , __amdgpu_buffer_rsrc_t prsrc = __amdgpu_buffer_rsrc_t()
-#endif
-                                      ) {
+  // ---- phase 1: this wave's quarter of K into the LDS meeting area (W_up's registers are free afterwards)
+  __device__ __forceinline__ void phase1(f32x4 (*s_part)[8][64]) {
     const int lane = threadIdx.x & 63;
-    const int h0 = sl * MLP_HS;
-    // ---- phase 1: this wave's quarter of K
-    {
-      f32x4 acc[4][2];
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
 #pragma unroll
-      for (int ks = 0; ks < K1; ++ks)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
-    }
-    if (!EARLY) load_dn(Wdn, h0);
+      for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
+  }
+  // ---- the four partial tiles meet: wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units
+  // h0 + 16 j + 4 gq + e of row 16 i + c; bias, gelu, rounded to the operand type into the hidden tile
+  __device__ __forceinline__ void mid(const float* bup, int h0, f32x4 (*s_part)[8][64], TA* s_hid) {
+    const int lane = threadIdx.x & 63;
     __syncthreads();
-    // wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units h0 + 16 j + 4 gq + e of row 16 i + c
 #pragma unroll
     for (int f0 = 0; f0 < 8; f0 += 4) {
       const int f = f0 + wave;
@@ -1054,40 +1046,46 @@ struct MlpSmallTile {
       Store4<TA>::run(&s_hid[(16 * i + c) * LDH + hl], gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
     }
     __syncthreads();
-    // ---- phase 2: part[sl][rows, 128 wave .. 128 wave + 127]
-    {
-      f32x4 acc[8][2];
+  }
+  // ---- phase 2: acc = hid W_dn[128 wave .. 128 wave + 127, slice]^T (W_dn's registers are free afterwards)
+  __device__ __forceinline__ void phase2(const TA* s_hid, f32x4 (&acc)[8][2]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K2; ++ks) {
+      uint4 fh[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < K2; ++ks) {
-        uint4 fh[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
-      }
-      float* out = part + (long)sl * M * 512;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 16 * i + c;
-        if (m < M) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
+        for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
+    }
+  }
+  // part[sl][rows, 128 wave .. 128 wave + 127]; SHARED: for other workgroups of this launch: write-through (sc1) 16-byte stores
+  template <bool SHARED = false>
+  __device__ __forceinline__ void store(const f32x4 (&acc)[8][2], float* part, int m0, int sl, int M
 #ifndef TAPIR_HIPEMU
-            if (SHARED) {
-              typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-              const int off = (((sl * M + m) * 512) + 128 * wave + 16 * j + 4 * gq) * 4;
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), prsrc, off, 0, 16);
-              continue;
-            }
+                                        , __amdgpu_buffer_rsrc_t prsrc = __amdgpu_buffer_rsrc_t()
 #endif
-            *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
+                                        ) {
+    float* out = part + (long)sl * M * 512;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + 16 * i + c;
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#ifndef TAPIR_HIPEMU
+          if (SHARED) {
+            const int off = (((sl * M + m) * 512) + 128 * wave + 16 * j + 4 * gq) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tapir_u32x4, acc[j][i]), prsrc, off, 0, 16);
+            continue;
           }
+#endif
+          *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
         }
       }
     }
@@ -1101,10 +1099,17 @@ __global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
   const int tm = blockIdx.x / slices, sl = blockIdx.x - tm * slices;
   MlpSmallTile<TA> t;
   t.init();
+  const int h0 = sl * MLP_HS, m0 = tm * 32;
   // every operand of this wave, requested now
-  t.load_weights(g.Wup, g.Wdn, sl * MLP_HS);
-  t.load_rows(g.xn, tm * 32, g.M);
-  t.run(g.bup, g.Wdn, g.part, tm * 32, sl, g.M, s_part, s_hid);
+  t.load_up(g.Wup, h0);
+  if (MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0);
+  t.load_rows(g.xn, m0, g.M);
+  t.phase1(s_part);
+  if (!MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0);
+  t.mid(g.bup, h0, s_part, s_hid);
+  f32x4 acc[8][2];
+  t.phase2(s_hid, acc);
+  t.store(acc, g.part, m0, sl, g.M);
 }
 inline bool mlp_small_supported(int M) { return M >= 1 && M <= 512; }
 template <typename TA>

@@ -57,6 +57,8 @@ struct MixerOnlineArgs {
   int M, nb;
   int by_xcd;                  // (tests) 1: cluster = blockIdx % 8 (a cluster on ONE XCD under round-robin dispatch) -- the same bits, slower
   long long* dbg_times;        // null, or [256][nb][8] wall-clock stamps of lane 0 (tools/probe_online_mixer.py)
+  unsigned spin_limit;         // polls before a member gives up (ONL_SPIN_LIMIT)
+  int drop_member;             // (tests) 1: member 0 of cluster 0 leaves before its first arrival: the others must time out, not hang
 };
 
 #ifndef TAPIR_HIPEMU
@@ -64,7 +66,7 @@ typedef unsigned onl_u32x2 __attribute__((ext_vector_type(2)));
 // 32 arrivals per barrier on the cluster's counter; false = gave up (the error word is set).  Every wave has stored its payload
 // write-through; it drains its queue, the workgroup meets, one lane arrives and polls.
 template <bool ACQ>
-__device__ __forceinline__ bool onl_cluster_barrier(unsigned* ctr, unsigned* err, unsigned target, int* s_flag) {
+__device__ __forceinline__ bool onl_cluster_barrier(unsigned* ctr, unsigned* err, unsigned target, int* s_flag, unsigned limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -72,7 +74,7 @@ __device__ __forceinline__ bool onl_cluster_barrier(unsigned* ctr, unsigned* err
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > ONL_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      if (++spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __hip_atomic_store(err, 0x80000000u | target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
@@ -88,11 +90,13 @@ __device__ __forceinline__ bool onl_cluster_barrier(unsigned* ctr, unsigned* err
 
 // (Pointers read from the device table are generic to the compiler; every load through them says "global" -- common.hpp ldg*:
 // as FLAT loads they count on the LDS counter too, and each LDS wait of the row phase waited for the 128 KB of weights: 8 us per block.)
-// mixer.hpp parts_sum2v on slabs other workgroups of this launch stored: 8-byte loads past L1 (sc1), the same order of additions
-__device__ __forceinline__ float2 onl_parts_sum2(__amdgpu_buffer_rsrc_t parts, int rows, const float* bias, float2 x, int r, int col) {
-  onl_u32x2 w[MLP_PARTS];
+// mixer.hpp parts_sum2v on slabs other workgroups of this launch stored: 8-byte loads past L1 (sc1) -- requested, then (behind
+// whatever else the caller requests meanwhile) added in the same order: ((((p_0 + p_1) + ...) + p_31) + bias) + residual
+__device__ __forceinline__ void onl_parts_request(onl_u32x2 (&w)[MLP_PARTS], __amdgpu_buffer_rsrc_t parts, int rows, int r, int col) {
 #pragma unroll
   for (int p = 0; p < MLP_PARTS; ++p) w[p] = __builtin_amdgcn_raw_buffer_load_b64(parts, ((p * rows + r) * kHidden + col) * 4, 0, 16);
+}
+__device__ __forceinline__ float2 onl_parts_finish(const onl_u32x2 (&w)[MLP_PARTS], const float* bias, float2 x, int col) {
   const float2 b = ldg_f2(bias + col);
   float2 v = make_float2(__uint_as_float(w[0].x), __uint_as_float(w[0].y));
 #pragma unroll
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   const int k = a.by_xcd ? blockIdx.x / ONL_CLUSTERS : blockIdx.x % ONL_MEMBERS;
   const int m0 = 32 * cl;
   if (m0 >= a.M) return;                        // the whole cluster has no rows (uniform over its members)
+  if (a.drop_member && cl == 0 && k == 0) return;
   const int r = m0 + k;
   const bool has_row = r < a.M;
   unsigned* ctr = a.sync + 16 * cl;
@@ -131,55 +136,58 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   auto stamp = [&](int i, int j) {
     if (a.dbg_times != nullptr && tid == 0) a.dbg_times[((long)blockIdx.x * a.nb + i) * 8 + j] = wall_clock64();
   };
+  // A block's row-phase operands -- parameters (2 channels x 4 multipliers x 3 taps, twice), causal context (LN1(x) and the GELU
+  // outputs of the two previous frames; zeros without one) -- and the MLP phase's weights: none of them depends on anything this
+  // launch computes.  They are requested during the PREVIOUS block's MLP phase, each into registers that phase has just finished
+  // with (W_up behind its first product, W_dn and the row operands behind its second), in front of the slab stores: the drain
+  // those stores need anyway covers them, and behind the barrier the 32 partial sums are alone in the wave's load queue (loads
+  // return in order: requested in front of them, 128 KB of weights cost 7 us per block).
+  float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2];
+  float c1[2][2], g0[2][2][4];      // [frame][channel]([multiplier])
+  float2 s2 = make_float2(0.f, 0.f);
+  const bool has1 = a.ctx1_in != nullptr, has2 = a.ctx2_in != nullptr;
+  const int rr = min(r, a.M - 1);    // (a member without a row requests the tile's last row and drops it: no branch in the run)
+  auto request = [&](int ib, const OnlineBlockW& b) {
+    {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        sc1[ch] = ldg_f(b.ln1 + c0 + ch);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int o = 4 * (c0 + ch) + m;
+          b1[ch][m] = ldg_f(b.b1 + o);
+          b2[ch][m] = ldg_f(b.b2 + o);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { w1[ch][m][q] = ldg_f(b.w1 + o * 3 + q); w2[ch][m][q] = ldg_f(b.w2 + o * 3 + q); }
+        }
+      }
+      s2 = ldg_f2(b.ln2 + c0);
+      // (no branch: without a context the loads read the input row and the values are dropped)
+      const float* p1 = has1 ? a.ctx1_in + (((long)ib * a.M + rr) * 2) * kHidden + c0 : a.x_in + (long)rr * kHidden + c0;
+      const float* p2 = has2 ? a.ctx2_in + (((long)ib * a.M + rr) * 2) * kHidden4 + 4 * c0 : a.x_in + (long)rr * kHidden;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float2 v = ldg_f2(p1 + (has1 ? j * kHidden : 0));
+        c1[j][0] = has1 ? v.x : 0.f; c1[j][1] = has1 ? v.y : 0.f;
+        const tapir_f32x4 v0 = ldg_f4(p2 + (has2 ? j * kHidden4 : 0));
+        const tapir_f32x4 v1 = ldg_f4(p2 + (has2 ? j * kHidden4 : 0) + 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { g0[j][0][m] = has2 ? v0[m] : 0.f; g0[j][1][m] = has2 ? v1[m] : 0.f; }
+      }
+    }
+  };
+  const int h0 = k * MLP_HS;
   OnlineBlockW bw = a.blocks[0];
-  const float* bdn_prev = nullptr;
+  float2 x = ldg_f2(a.x_in + (long)rr * kHidden + c0);
+  request(0, bw);
+  t.load_up(bw.Wup, h0);
+  t.load_dn(bw.Wdn, h0);
   for (int i = 0; i < a.nb && ok; ++i) {
     stamp(i, 0);
     // the next block's table entry (scalar loads): under this block, not in front of the next
     const OnlineBlockW bw_next = a.blocks[min(i + 1, a.nb - 1)];
-    // ---- row phase (mix_kernel for T = 1, causal): its loads first ...
-    float2 x = make_float2(0.f, 0.f);
-    float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2];   // 2 channels x 4 multipliers x 3 taps, twice
-    float c1[2][2], g0[2][2][4];                                  // context [frame][channel]([multiplier])
     if (has_row) {
-      if (i == 0) x = *reinterpret_cast<const float2*>(a.x_in + (long)r * kHidden + c0);
-      else x = onl_parts_sum2(rs_part, a.M, bdn_prev, xres, r, c0);
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-        sc1[ch] = ldg_f(bw.ln1 + c0 + ch);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int o = 4 * (c0 + ch) + m;
-          b1[ch][m] = ldg_f(bw.b1 + o);
-          b2[ch][m] = ldg_f(bw.b2 + o);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { w1[ch][m][q] = ldg_f(bw.w1 + o * 3 + q); w2[ch][m][q] = ldg_f(bw.w2 + o * 3 + q); }
-        }
-      }
-      // causal context: LN1(x) and the GELU outputs of the two previous frames (zeros without one)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (a.ctx1_in != nullptr) {
-          const float2 v = *reinterpret_cast<const float2*>(a.ctx1_in + (((long)i * a.M + r) * 2 + j) * kHidden + c0);
-          c1[j][0] = v.x; c1[j][1] = v.y;
-        } else { c1[j][0] = 0.f; c1[j][1] = 0.f; }
-        if (a.ctx2_in != nullptr) {
-          const float* p = a.ctx2_in + (((long)i * a.M + r) * 2 + j) * kHidden4 + 4 * c0;
-          const float4 v0 = *reinterpret_cast<const float4*>(p);
-          const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-          g0[j][0][0] = v0.x; g0[j][0][1] = v0.y; g0[j][0][2] = v0.z; g0[j][0][3] = v0.w;
-          g0[j][1][0] = v1.x; g0[j][1][1] = v1.y; g0[j][1][2] = v1.z; g0[j][1][3] = v1.w;
-        } else {
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) g0[j][ch][m] = 0.f;
-        }
-      }
-    }
-    // ... then the MLP phase's weights: they do not depend on anything this launch computes and arrive under the row phase
-    t.load_weights(bw.Wup, bw.Wdn, k * MLP_HS);
-    if (has_row) {
+      // ---- row phase (mix_kernel for T = 1, causal)
       *reinterpret_cast<float2*>(&s_x[0][c0]) = x;
       __syncthreads();
       stamp(i, 1);
@@ -232,7 +240,6 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
         const float4 v = *reinterpret_cast<const float4*>(&s_x[1][256 + lane * 4]);
         wave_row_stats(u, v, mean, rstd);
       }
-      const float2 s2 = ldg_f2(bw.ln2 + c0);
       // the operand row, write-through: through LDS (the MLP phase's hidden tile is free now) so that one wave stores it 16 bytes per lane
       TA* s_row = s_hid;
       Elem<TA>::st2(s_row + c0, (xres.x - mean) * rstd * s2.x, (xres.y - mean) * rstd * s2.y);
@@ -244,16 +251,27 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
       }
     }
     stamp(i, 2);
-    ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag);
+    ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag, a.spin_limit);
     if (!ok) break;
     stamp(i, 3);
     // ---- MLP phase: this member's 64 hidden units over the cluster's 32 rows
     if (ACQ) t.load_rows(a.xn, m0, a.M); else t.load_rows_shared(rs_xn, m0, a.M);
-    t.template run<true>(bw.bup, bw.Wdn, a.part, m0, k, a.M, s_part, s_hid, rs_part);
+    t.phase1(s_part);
+    t.load_up(bw_next.Wup, h0);                     // the next block's operands (after the last block: re-read and dropped)
+    t.mid(bw.bup, h0, s_part, s_hid);
+    f32x4 acc[8][2];
+    t.phase2(s_hid, acc);
+    t.load_dn(bw_next.Wdn, h0);
+    request(min(i + 1, a.nb - 1), bw_next);
+    t.template store<true>(acc, a.part, m0, k, a.M, rs_part);
     stamp(i, 4);
-    ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag);
+    ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag, a.spin_limit);
     stamp(i, 5);
-    bdn_prev = bw.bdn;
+    if (!ok) break;
+    // ---- the next row phase's input (after the last block: the final LayerNorm's): the 32 partial sums
+    onl_u32x2 pw[MLP_PARTS];
+    onl_parts_request(pw, rs_part, a.M, rr, c0);
+    x = onl_parts_finish(pw, bw.bdn, xres, c0);
     bw = bw_next;
   }
   if (!has_row) return;
@@ -264,8 +282,6 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   }
   // ---- the final LayerNorm (layernorm_kernel's arithmetic: a lane holds 8 consecutive channels)
   {
-    const float2 x = a.nb > 0 ? onl_parts_sum2(rs_part, a.M, bdn_prev, xres, r, c0)
-                              : *reinterpret_cast<const float2*>(a.x_in + (long)r * kHidden + c0);
     __syncthreads();
     *reinterpret_cast<float2*>(&s_x[0][c0]) = x;
     __syncthreads();

@@ -75,6 +75,17 @@ class OnlineTracker:
   def __del__(self):
     self.close()
 
+  def check(self) -> None:
+    """Raises if the mixer's persistent launch (csrc/mixer_online.hpp: up to 256 points) gave up waiting for one of its
+    workgroups -- the device could not hold its 256 workgroups at once; the tracks of that frame are NaN.  Synchronises the
+    device: call it where the results are read anyway, not per frame in a latency-critical loop."""
+    import ctypes
+    word = ctypes.c_uint(0)
+    self.model._check(self.model._lib.tapir_online_sync_error(self.model._ctx, ctypes.byref(word)), 'tapir_online_sync_error')
+    if word.value:
+      raise RuntimeError(f'online mixer: a workgroup timed out at a cluster barrier (word {word.value:#x}); rerun with '
+                         'TAPIR_SMALL_GEMM=2 (separate launches) if the GPU is shared')
+
   # ------------------------------------------------------------------ points
   def init(self, frames, query_points) -> QueryFeatures:
     """live_demo.online_model_init: query features of `query_points` [1,N,3] (t,y,x) in `frames`

@@ -307,3 +307,39 @@ def test_few_row_one_launch_mlp_vs_oracle(N, T, causal):
       np.testing.assert_allclose(outs[2][1][0][i], new_ctx[f'block_{i}_causal_1'], atol=2e-2)
       np.testing.assert_allclose(outs[2][1][1][i], new_ctx[f'block_{i}_causal_2'], atol=2e-2)
       np.testing.assert_allclose(outs[2][1][0][i], outs[1][1][0][i], atol=2e-2)
+
+
+def test_online_mixer_times_out_instead_of_hanging():
+  """csrc/mixer_online.hpp bounds every wait: with one member of cluster 0 missing (a test switch: the workgroup leaves before
+  its first arrival) the launch ENDS, the error word is set, the rows of that cluster are NaN (loud in the tracks), the other
+  clusters' rows are what they always are -- and the next launch is clean again (the words are zeroed in-stream per launch)."""
+  import ctypes
+  import time
+  N, pyr, nb = 256, 1, 12
+  w = synthetic.make_weights(91, pyr, False, backbone=False)
+  m = _model(pyr, weights=w, use_causal_conv=True)
+  rng = np.random.default_rng(5)
+  x = torch.as_tensor(rng.standard_normal((N, 1, 388 + 49 * (2 + pyr))).astype(np.float32), device='cuda')
+  c1 = torch.as_tensor(rng.standard_normal((nb, N, 2, 512)).astype(np.float32), device='cuda')
+  c2 = torch.as_tensor(rng.standard_normal((nb, N, 2, 2048)).astype(np.float32), device='cuda')
+  o1, o2 = torch.zeros_like(c1), torch.zeros_like(c2)
+
+  def run(mode):
+    assert m._lib.tapir_debug_set_gemm_mode(m._ctx, mode) == 0
+    out = torch.zeros((N, 1, 388), device='cuda')
+    m._check(m._lib.tapir_pips_mixer(m._ctx, x.data_ptr(), N, 1, out.data_ptr(), c1.data_ptr(), c2.data_ptr(), o1.data_ptr(),
+                                     o2.data_ptr(), m._stream()), 'tapir_pips_mixer')
+    torch.cuda.synchronize()
+    word = ctypes.c_uint(0)
+    assert m._lib.tapir_online_sync_error(m._ctx, ctypes.byref(word)) == 0
+    return out.cpu().numpy(), word.value
+  good, word = run(3)
+  assert word == 0 and np.isfinite(good).all()
+  t0 = time.perf_counter()
+  bad, word = run(3 + 4 * 4)
+  assert time.perf_counter() - t0 < 20.0
+  assert word != 0
+  assert np.isnan(bad[1:32]).all()                       # cluster 0 (rows 0..31; row 0's workgroup left without writing)
+  assert np.array_equal(bad[32:], good[32:])             # the other seven clusters never noticed
+  again, word = run(3)
+  assert word == 0 and np.array_equal(again, good)

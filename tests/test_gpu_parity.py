@@ -295,6 +295,7 @@ def test_online_tracker_matches_streaming_api(use_graph):
     out = trk.step(video[:, t:t + 1])
     for k in ref[t]:
       torch.testing.assert_close(out[k], ref[t][k], atol=1e-3, rtol=0, msg=f'frame {t} {k}')
+  trk.check()      # (the mixer's persistent launch never timed out)
   # replacing two points resets their state and features only
   new_qp = torch.as_tensor(synthetic.make_queries(7, 2, 1, S, S)).cuda()
   before = {k: v.clone() for k, v in trk.step(video[:, 2:3]).items()}

@@ -52,6 +52,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.frames * 1e3
     assert torch.isfinite(out['tracks']).all()
+    trk.check()
     rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', backbone_convs=conv_mode, gemm_mode=args.gemm_mode, ms_per_frame=round(ms, 3),
                      frames_per_s=round(1e3 / ms, 1), points_frames_per_s=round(Q * 1e3 / ms, 1)))
     print(json.dumps(dict(workload=f'online TAPIR {S}x{S}, Q={Q}, 4 iters/frame, {dtype}', **rows[-1])), flush=True)
