@@ -596,7 +596,22 @@ def secondary_legs(dev, steps):
       return trk.step(v[:, k[0] % 8:k[0] % 8 + 1])
     s, r = timed(step, 5, 40)
     assert torch.isfinite(r['tracks']).all()
-    return dict(ms_per_frame=round(s * 1e3, 3), frames_per_s=round(1.0 / s, 1),
+    trk.check()
+    # the replayed step is the step: a fresh replayed session against eager launches, frame by frame (a replay that skipped work --
+    # the persistent mixer leaves at once when it finds its error word set -- would be fast and wrong: profiles/r06_graph_memset_hazard.txt)
+    worst = 0.0
+    ta, tb = online.OnlineTracker(m, Q, (S, S), use_graph=True), online.OnlineTracker(m, Q, (S, S), use_graph=False)
+    outs = []
+    for t_ in (ta, tb):
+      t_.init(v[:, :1], q)
+      outs.append([{k_: x.clone() for k_, x in t_.step(v[:, f % 8:f % 8 + 1]).items()} for f in range(12)])
+      t_.check()
+      t_.close()
+    for fa, fb in zip(*outs):
+      assert torch.isfinite(fa['tracks']).all() and torch.isfinite(fb['tracks']).all()
+      worst = max(worst, float((fa['tracks'] - fb['tracks']).abs().max()))
+    assert worst < 1e-3, worst
+    return dict(ms_per_frame=round(s * 1e3, 3), frames_per_s=round(1.0 / s, 1), replay_vs_eager_max_px=worst, validated_frames=12,
                 workload='causal model (BootsTAPIR kwargs + use_causal_conv), 256x256 frames, 256 points, 4 iterations per frame, '
                          'bf16, hipGraph replay', backbone=m._backbone.describe(1))
 

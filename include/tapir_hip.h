@@ -448,7 +448,8 @@ int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* gri
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
 /* The persistent launch above bounds every wait: a workgroup that waited ~2 s for its cluster (the device could not hold the 256
  * workgroups at once) writes an error word, every member leaves, and the mixer's rows are NaN -- loud in the tracks.  Reads
- * the word of the LAST such launch (0 = no error; synchronises the device).  Never set on an otherwise idle MI355X. */
+ * the word (0 = no error; synchronises the device) and, if it was set, clears it together with the launch's counters: until then
+ * every further persistent launch of this context leaves at once with NaN rows.  Never set on an otherwise idle MI355X. */
 int tapir_online_sync_error(tapir_ctx* ctx, unsigned* word);
 /* The 3x3 256 -> 256 block convolutions (tapir_conv_fused*): 1 = always the flat tiling of the whole launch
  * (csrc/conv_flat.hpp: three consecutive 64-pixel slabs of the (image, row) space per workgroup) where the shape allows it,

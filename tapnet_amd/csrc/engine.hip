@@ -100,7 +100,7 @@ struct tapir_ctx {
                                                   // allows it; set per clip by the caller's backbone (tapir_conv_set_small), follows the WHOLE clip's frame count
   int conv_flat_min_slabs = 96;                   // (TAPIR_CONV_FLAT_MIN_SLABS)
   int small_gemm = 3;                             // few-row GEMMs: 3 = 2 + the online model's mixer (one frame, causal, <= 256 rows) as ONE persistent launch over all blocks (mixer_online.hpp), 2 = 1 + the channel MLP of a block in ONE launch (mlp_small_kernel), 1 = gemm_small_kernel (one launch each), 0 = split-K + reduce
-  int online_form = 0;                            // (tests, TAPIR_ONLINE_FORM) bit 0: a cluster of the persistent launch on ONE XCD (default: the members that read the same weight slice on one XCD); bit 1: acquire + plain loads instead of sc1 loads; bit 2: one member never arrives (the timeout path)
+  int online_form = 0;                            // (tests, TAPIR_ONLINE_FORM) bit 0: the members of the persistent launch that read the same weight slice on ONE XCD (default: a cluster on one XCD); bit 1: acquire + plain loads instead of sc1 loads; bit 2: one member never arrives (the timeout path)
   int n_cus = 0;                                  // compute units of the device (the persistent launch needs its 256 workgroups resident at once)
 
   // workspaces
@@ -873,17 +873,17 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   persistent = c->small_gemm >= 3 && mlp1 && mixer_online_supported(N, T, c->cfg.use_causal_conv != 0) &&
                c->n_cus >= ONL_CLUSTERS * ONL_MEMBERS && (ctx1_out == nullptr) == (ctx2_out == nullptr);
   if (persistent) {
-    TRY(ensure(c, c->online_sync, (size_t)ONL_SYNC_WORDS * 4));
-    HIP_TRY(c, hipMemsetAsync(c->online_sync.p, 0, (size_t)ONL_SYNC_WORDS * 4, s));
+    TRY(ensure_zeroed(c, c->online_sync, (size_t)ONL_SYNC_WORDS * 4));   // (every launch leaves the counters zero: mixer_online.hpp)
     MixerOnlineArgs oa{};
     oa.x_in = (const float*)c->xa.p; oa.xn = c->xn.p; oa.part = (float*)c->splitk.p;
     oa.blocks = c->online_blocks; oa.lnF = c->lnF;
     oa.ctx1_in = ctx1_in; oa.ctx2_in = ctx2_in; oa.ctx1_out = ctx1_out; oa.ctx2_out = ctx2_out;
     oa.sync = (unsigned*)c->online_sync.p; oa.M = N; oa.nb = nb;
-    oa.by_xcd = (c->online_form & 1) ? 1 : 0;
+    oa.by_xcd = (c->online_form & 1) ? 0 : 1;
     oa.drop_member = (c->online_form & 4) ? 1 : 0;
     oa.spin_limit = oa.drop_member ? (1u << 14) : ONL_SPIN_LIMIT;
     oa.dbg_times = (long long*)c->dbg_times;
+    if (getenv("TAPIR_ONLINE_PRE")) hipLaunchKernelGGL(onl_pre_kernel, dim3(atoi(getenv("TAPIR_ONLINE_PRE"))), dim3(64), 0, s, oa.sync);
     ProfScope ps(c, TAPIR_PROF_MIX, s);
     if (sizeof(TA) == 2) launch_mixer_online<bf16_t>(oa, s, (c->online_form & 2) != 0);
     else launch_mixer_online<float>(oa, s, (c->online_form & 2) != 0);
@@ -1382,6 +1382,7 @@ int tapir_reserve(tapir_ctx* c, int B, int Q, int T, int mh, int mw) {
     TRY(ensure_zeroed(c, c->grid_tiled, tiled_bytes((long)frames, (int)mh, (int)mw)));
   }
   if (c->cfg.pyramid_level >= 1) TRY(ensure(c, c->pooled, frames * (mh / 2) * (mw / 2) * kLowresDim * es));
+  TRY(ensure_zeroed(c, c->online_sync, (size_t)ONL_SYNC_WORDS * 4));   // (the online mixer's counters: allocated and zeroed before anything is captured)
   TRY(ensure(c, c->warm_sink, 4));   // (warm_stream_kernel's sink: the first fused-mixer iteration of a level must not allocate while pinned)
   return TAPIR_OK;
 }
@@ -2041,7 +2042,7 @@ int tapir_debug_mixer_stop(tapir_ctx* c, int stages) {
 
 int tapir_debug_workspace(tapir_ctx* c, int which, void** p, unsigned long long* bytes) {
   if (!c || !p || !bytes) return TAPIR_ERR_INVALID;
-  DevBuf* b[] = {&c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->splitk};
+  DevBuf* b[] = {&c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->splitk, &c->online_sync};
   if (which < 0 || which >= (int)(sizeof(b) / sizeof(b[0]))) return TAPIR_ERR_INVALID;
   *p = b[which]->p; *bytes = b[which]->cap;
   return TAPIR_OK;
@@ -2068,6 +2069,7 @@ int tapir_online_sync_error(tapir_ctx* c, unsigned* word) {
   *word = 0;
   if (c->online_sync.p == nullptr) return TAPIR_OK;      // the persistent launch never ran
   HIP_TRY(c, hipMemcpy(word, (const unsigned*)c->online_sync.p + 16 * ONL_CLUSTERS, 4, hipMemcpyDeviceToHost));
+  if (*word != 0) HIP_TRY(c, hipMemset(c->online_sync.p, 0, c->online_sync.cap));   // a launch that gave up leaves its counters behind
   return TAPIR_OK;
 }
 

@@ -933,18 +933,28 @@ inline void launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
 // (profiles/r06_online_timeline.txt).  What such a launch costs beyond the ~5.5 us of a dependent launch with nothing in it is
 // the bytes ONE CU has to pull in cold (96 KB / 256 KB per workgroup for up / down; a first form of this kernel with 544 KB per
 // workgroup and four dependent round trips per phase took 33.8 us, profiles/r06_ab_mlp_small.txt) -- so the decomposition
-// minimises bytes per workgroup with every CU busy: a workgroup = (tile of 32 rows, slice of MLP_HS = 64 hidden units) pulls
-// 64 KB of W_up + 32 KB of LN2(x) + 64 KB of W_dn = 160 KB, ALL of it requested before the first MFMA (one round trip):
-//   phase 1: hid[32, 64] = gelu(xn_tile W_up[h0 .. h0 + 64]^T + b_up): the four waves split K = 512 (one quarter each, all of
-//            a wave's fragments in flight), meet in LDS, add in wave order, round to the operand type into LDS;
-//   phase 2: part[slice][32, 512] = hid W_dn[:, h0 .. h0 + 64]^T: wave w takes output columns 128 w .. 128 w + 127, its 16
-//            weight fragments were requested at the top of the kernel.
+// keeps the bytes per workgroup low with every CU busy, and -- what the persistent form of mixer_online.hpp taught -- the bytes of
+// PARTIAL SUMS low, which are written and read back once per block: a workgroup = (tile of 32 rows, group of MLP_HS = 128
+// hidden units, one of MLP_CG = 2 halves of the output columns) pulls 128 KB of W_up + 32 KB of LN2(x) + 64 KB of W_dn, ALL of
+// it requested before the first MFMA (one round trip), and leaves a [32, 256] piece: 16 partial sums per output element
+// (8 MB per block at 256 rows; the first form, 64 hidden units x all 512 columns, left 32: 16 MB).  The two workgroups of a
+// hidden group compute the same hidden tile (the first product twice: MFMA time nobody waits for).
+//   phase 1: hid[32, 128] = gelu(xn_tile W_up[h0 .. h0 + 128]^T + b_up): the four waves split K = 512 (one quarter each, all
+//            of a wave's fragments in flight), meet in LDS, add in wave order, round to the operand type into LDS;
+//   phase 2: part[group][32, col0 .. col0 + 256] = hid W_dn[col0 .., h0 .. h0 + 128]^T: wave w takes output columns
+//            col0 + 64 w .. + 63, its 16 weight fragments were requested at the top of the kernel.
 // Nobody waits and nobody merges at the tail of the launch (the lesson of conv_small.hpp: a merge by the last arriver is ~6 us ON
 // the chain of a launch this small): the CONSUMER -- the next block's mix_kernel, or the final layernorm_kernel -- adds the
-// 2048 / 64 = 32 partials, b_dn and the residual in a fixed order while it stages its rows (mixer.hpp parts_sum2).  The hidden
+// 2048 / 128 = 16 partials, b_dn and the residual in a fixed order while it stages its rows (mixer.hpp parts_sum2).  The hidden
 // tensor never exists in HBM.  M <= 512 rows: 16 x 32 = 512 workgroups at most.
-constexpr int MLP_HS = 64;           // hidden units per workgroup
-constexpr int MLP_PARTS = 2048 / MLP_HS;
+#ifndef TAPIR_MLP_HS                 // (A/B builds: -DTAPIR_MLP_HS=64 -DTAPIR_MLP_CG=1 is the first decomposition, 32 partial sums)
+#define TAPIR_MLP_HS 128
+#define TAPIR_MLP_CG 2
+#endif
+constexpr int MLP_HS = TAPIR_MLP_HS; // hidden units per workgroup
+constexpr int MLP_PARTS = 2048 / MLP_HS;   // partial outputs per element (16)
+constexpr int MLP_CG = TAPIR_MLP_CG; // column groups of the second product: a workgroup stores 512 / MLP_CG output columns
+constexpr int MLP_UNITS = MLP_PARTS * MLP_CG;   // workgroups per row tile: unit u = (hidden group u % MLP_PARTS, column group u / MLP_PARTS)
 struct MlpSmallArgs {
   const void* xn;      // [M, 512] LN2(x) in the operand type
   const void* Wup;     // [2048, 512]
@@ -960,24 +970,28 @@ struct MlpSmallTile {
   static constexpr int EPC = 16 / (int)sizeof(TA);   // elements per 16-byte chunk
   static constexpr int KS = 4 * EPC;                 // k per MFMA step
   static constexpr int K1 = 128 / KS;                // k-steps of a wave's quarter of K = 512 (bf16: 4, f32: 8)
-  static constexpr int K2 = MLP_HS / KS;             // k-steps of the second product (bf16: 2, f32: 4)
+  static constexpr int K2 = MLP_HS / KS;             // k-steps of the second product (bf16: 4, f32: 8)
+  static constexpr int NJ1 = MLP_HS / 16;            // fragment rows of the hidden tile (8)
+  static constexpr int NF1 = NJ1 * 2;                // its fragments (x 2 row halves)
+  static constexpr int CW = 512 / MLP_CG / 4;        // output columns per wave (64)
+  static constexpr int NJ2 = CW / 16;                // its fragment rows (4)
   static constexpr int LDH = MLP_HS + EPC;           // hidden row stride in LDS (+ one chunk: rows 16 lanes apart on different banks)
   static constexpr bool EARLY = sizeof(TA) == 2;     // W_dn's fragments requested with W_up's (f32: too many registers; parity build)
-  uint4 fw[K1][4], fa[K1][2], fd[K2][8];
+  uint4 fw[K1][NJ1], fa[K1][2], fd[K2][NJ2];
   int wave, c, gq;
   __device__ __forceinline__ void init() {
     const int lane = threadIdx.x & 63;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c = lane & 15; gq = lane >> 4;
   }
-  // W_dn rows (output columns) 128 wave + 16 j + c over the slice's 64 hidden units
-  __device__ __forceinline__ void load_dn(const void* Wdn, int h0) {
+  // W_dn rows (output columns) col0 + CW wave + 16 j + c over the group's hidden units
+  __device__ __forceinline__ void load_dn(const void* Wdn, int h0, int col0) {
     const TA* Wd = reinterpret_cast<const TA*>(Wdn);
 #pragma unroll
     for (int ks = 0; ks < K2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        fd[ks][j] = ldg16(Wd + (long)(128 * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
+      for (int j = 0; j < NJ2; ++j)
+        fd[ks][j] = ldg16(Wd + (long)(col0 + CW * wave + 16 * j + c) * 2048 + h0 + ks * KS + EPC * gq);
   }
   // W_up rows h0 + 16 j + c over k in [128 wave, 128 wave + 128)
   __device__ __forceinline__ void load_up(const void* Wup, int h0) {
@@ -985,7 +999,7 @@ struct MlpSmallTile {
 #pragma unroll
     for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ1; ++j)
         fw[ks][j] = ldg16(Wu + (long)(h0 + 16 * j + c) * 512 + 128 * wave + ks * KS + EPC * gq);
   }
   // the tile's rows over the same k range (rows past M: clamped, computed and never stored)
@@ -1010,31 +1024,31 @@ struct MlpSmallTile {
   }
 #endif
   // ---- phase 1: this wave's quarter of K into the LDS meeting area (W_up's registers are free afterwards)
-  __device__ __forceinline__ void phase1(f32x4 (*s_part)[8][64]) {
+  __device__ __forceinline__ void phase1(f32x4 (*s_part)[NF1][64]) {
     const int lane = threadIdx.x & 63;
-    f32x4 acc[4][2];
+    f32x4 acc[NJ1][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ1; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < K1; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ1; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fw[ks][j], fa[ks][i], acc[j][i]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ1; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i) s_part[wave][j * 2 + i][lane] = acc[j][i];
   }
-  // ---- the four partial tiles meet: wave w finishes fragments f = w, w + 4 (f = 2 j + i): lane (c, gq) holds hidden units
+  // ---- the four partial tiles meet: wave w finishes fragments f = w, w + 4, ... (f = 2 j + i): lane (c, gq) holds hidden units
   // h0 + 16 j + 4 gq + e of row 16 i + c; bias, gelu, rounded to the operand type into the hidden tile
-  __device__ __forceinline__ void mid(const float* bup, int h0, f32x4 (*s_part)[8][64], TA* s_hid) {
+  __device__ __forceinline__ void mid(const float* bup, int h0, f32x4 (*s_part)[NF1][64], TA* s_hid) {
     const int lane = threadIdx.x & 63;
     __syncthreads();
 #pragma unroll
-    for (int f0 = 0; f0 < 8; f0 += 4) {
+    for (int f0 = 0; f0 < NF1; f0 += 4) {
       const int f = f0 + wave;
       const int j = f >> 1, i = f & 1;
       f32x4 v = s_part[0][f][lane];
@@ -1047,10 +1061,10 @@ struct MlpSmallTile {
     }
     __syncthreads();
   }
-  // ---- phase 2: acc = hid W_dn[128 wave .. 128 wave + 127, slice]^T (W_dn's registers are free afterwards)
-  __device__ __forceinline__ void phase2(const TA* s_hid, f32x4 (&acc)[8][2]) {
+  // ---- phase 2: acc = hid W_dn[col0 + CW wave .. + CW - 1, group]^T (W_dn's registers are free afterwards)
+  __device__ __forceinline__ void phase2(const TA* s_hid, f32x4 (&acc)[NJ2][2]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < NJ2; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1059,33 +1073,33 @@ struct MlpSmallTile {
 #pragma unroll
       for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const uint4*>(&s_hid[(16 * i + c) * LDH + ks * KS + EPC * gq]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < NJ2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) MfmaStep<TA>::run(fd[ks][j], fh[i], acc[j][i]);
     }
   }
-  // part[sl][rows, 128 wave .. 128 wave + 127]; SHARED: for other workgroups of this launch: write-through (sc1) 16-byte stores
+  // part[hg][rows, col0 + CW wave .. + CW - 1]; SHARED: for other workgroups of this launch: write-through (sc1) 16-byte stores
   template <bool SHARED = false>
-  __device__ __forceinline__ void store(const f32x4 (&acc)[8][2], float* part, int m0, int sl, int M
+  __device__ __forceinline__ void store(const f32x4 (&acc)[NJ2][2], float* part, int m0, int hg, int col0, int M
 #ifndef TAPIR_HIPEMU
                                         , __amdgpu_buffer_rsrc_t prsrc = __amdgpu_buffer_rsrc_t()
 #endif
                                         ) {
-    float* out = part + (long)sl * M * 512;
+    float* out = part + (long)hg * M * 512 + col0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = m0 + 16 * i + c;
       if (m < M) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ2; ++j) {
 #ifndef TAPIR_HIPEMU
           if (SHARED) {
-            const int off = (((sl * M + m) * 512) + 128 * wave + 16 * j + 4 * gq) * 4;
+            const int off = (((hg * M + m) * 512) + col0 + CW * wave + 16 * j + 4 * gq) * 4;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tapir_u32x4, acc[j][i]), prsrc, off, 0, 16);
             continue;
           }
 #endif
-          *reinterpret_cast<f32x4*>(out + (long)m * 512 + 128 * wave + 16 * j + 4 * gq) = acc[j][i];
+          *reinterpret_cast<f32x4*>(out + (long)m * 512 + CW * wave + 16 * j + 4 * gq) = acc[j][i];
         }
       }
     }
@@ -1093,28 +1107,28 @@ struct MlpSmallTile {
 };
 template <typename TA>
 __global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
-  __shared__ f32x4 s_part[4][8][64];                 // the four waves' partial hidden tiles (fragment layout)
+  __shared__ f32x4 s_part[4][MlpSmallTile<TA>::NF1][64];   // the four waves' partial hidden tiles (fragment layout)
   __shared__ __attribute__((aligned(16))) TA s_hid[32 * MlpSmallTile<TA>::LDH];
-  constexpr int slices = 2048 / MLP_HS;
-  const int tm = blockIdx.x / slices, sl = blockIdx.x - tm * slices;
+  const int tm = blockIdx.x / MLP_UNITS, u = blockIdx.x - tm * MLP_UNITS;
+  const int hg = u % MLP_PARTS, col0 = (u / MLP_PARTS) * (512 / MLP_CG);   // (workgroups of one hidden group on one XCD)
   MlpSmallTile<TA> t;
   t.init();
-  const int h0 = sl * MLP_HS, m0 = tm * 32;
+  const int h0 = hg * MLP_HS, m0 = tm * 32;
   // every operand of this wave, requested now
   t.load_up(g.Wup, h0);
-  if (MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0);
+  if (MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0, col0);
   t.load_rows(g.xn, m0, g.M);
   t.phase1(s_part);
-  if (!MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0);
+  if (!MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0, col0);
   t.mid(g.bup, h0, s_part, s_hid);
-  f32x4 acc[8][2];
+  f32x4 acc[MlpSmallTile<TA>::NJ2][2];
   t.phase2(s_hid, acc);
-  t.store(acc, g.part, m0, sl, g.M);
+  t.store(acc, g.part, m0, hg, col0, g.M);
 }
 inline bool mlp_small_supported(int M) { return M >= 1 && M <= 512; }
 template <typename TA>
 inline void launch_mlp_small(const MlpSmallArgs& g, hipStream_t stream) {
-  TAPIR_LAUNCH((mlp_small_kernel<TA>), dim3((unsigned)(((g.M + 31) / 32) * (2048 / MLP_HS))), dim3(256), stream, g);
+  TAPIR_LAUNCH((mlp_small_kernel<TA>), dim3((unsigned)(((g.M + 31) / 32) * MLP_UNITS)), dim3(256), stream, g);
 }
 
 #ifdef TAPIR_EXPERIMENTS

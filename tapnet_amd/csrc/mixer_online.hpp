@@ -9,18 +9,18 @@
 // every block, and what has to be spread over many CUs is only the 4 MB of weights per block.  So:
 //
 //   cluster  = 32 workgroups that own 32 rows for the whole launch (8 clusters = 256 rows = 256 workgroups, one per CU;
-//              cluster = blockIdx / 32, member = blockIdx % 32: the dispatcher deals workgroups round-robin over the 8 XCDs, so
-//              the eight workgroups that read the SAME weight slice sit on one XCD and its L2 fetches the slice once -- an
-//              expectation about speed only (1.72 against 1.81 ms per frame with a cluster per XCD: the exchange is written
-//              through to memory either way); every exchange below is agent-scope correct wherever the members run);
+//              cluster = blockIdx % 8, member = blockIdx / 8: the dispatcher deals workgroups round-robin over the 8 XCDs
+//              (observed: XCC_ID == blockIdx % 8), so a cluster's exchange and its counter stay on ONE XCD -- an expectation
+//              about speed only (1.66 against 1.80 ms per frame with the members that read the same weight slice on one XCD
+//              instead); every exchange below is agent-scope correct wherever the members run);
 //   member k = row k of the tile in the row phases (its residual stream lives in registers from the first block to the last),
-//              hidden slice k (64 units) in the MLP phases;
-//   block    = row phase (x = 32 partials + bias + residual; LayerNorm, causal temporal convolutions over [context ; frame],
+//              unit k = (hidden group k % 16 of 128 units, half k / 16 of the output columns) in the MLP phases;
+//   block    = row phase (x = 16 partials + bias + residual; LayerNorm, causal temporal convolutions over [context ; frame],
 //              new context, LayerNorm -> one operand row) | cluster barrier | MLP phase (gemm.hpp MlpSmallTile: the weights of
-//              the slice were requested BEFORE the barrier) | cluster barrier.
+//              the unit were requested during the previous block) | cluster barrier.
 //
 // Hand-offs follow the MI355X guide's recipe for data that crosses workgroups inside a launch (Guideline 16, R1): the payload
-// (an operand row; a 64 KB slab of partial sums) is stored WRITE-THROUGH (sc1), every storing wave drains its vector-memory
+// (an operand row; a 32 KB slab of partial sums) is stored WRITE-THROUGH (sc1), every storing wave drains its vector-memory
 // queue, one lane adds 1 to the cluster's counter (relaxed, agent scope; one 64-byte line per cluster), the readers poll that
 // word relaxed and then load the payload past L1 (sc1 loads; ACQ = true: one agent-scope acquire and plain loads instead).
 // No release fence: it writes back the XCD's whole L2 (a first form with release / acquire fences around every barrier took
@@ -42,8 +42,8 @@ struct OnlineBlockW {   // one block's parameters (device pointers)
   const float *ln1, *w1, *b1, *w2, *b2, *ln2;
   const void* Wup; const float* bup; const void* Wdn; const float* bdn;
 };
-constexpr int ONL_CLUSTERS = 8, ONL_MEMBERS = 32;              // MLP_PARTS members: one hidden slice each
-constexpr int ONL_SYNC_WORDS = ONL_CLUSTERS * 16 + 16;         // one 64-byte line per cluster + the error word's line
+constexpr int ONL_CLUSTERS = 8, ONL_MEMBERS = MLP_UNITS;       // 32 members: one (hidden group, column half) unit each
+constexpr int ONL_SYNC_WORDS = ONL_CLUSTERS * 16 + 32;         // one 64-byte line per cluster + the error word's line + the exit counter's
 constexpr unsigned ONL_SPIN_LIMIT = 1u << 21;                  // polls (~1 us each) before a member gives up
 struct MixerOnlineArgs {
   const float* x_in;           // [M, 512] the input Linear's output
@@ -53,9 +53,9 @@ struct MixerOnlineArgs {
   const float* lnF;
   const float *ctx1_in, *ctx2_in;   // [nb][M, 2, 512] / [nb][M, 2, 2048] or null (zeros)
   float *ctx1_out, *ctx2_out;       // same shapes or null
-  unsigned* sync;              // [ONL_SYNC_WORDS], zero at launch
+  unsigned* sync;              // [ONL_SYNC_WORDS], zero at launch: zeroed when allocated, and by the LAST workgroup of every launch to leave
   int M, nb;
-  int by_xcd;                  // (tests) 1: cluster = blockIdx % 8 (a cluster on ONE XCD under round-robin dispatch) -- the same bits, slower
+  int by_xcd;                  // 1 (default): cluster = blockIdx % 8 (a cluster on ONE XCD under round-robin dispatch); 0 (tests): cluster = blockIdx / 32 -- the same bits, slower
   long long* dbg_times;        // null, or [256][nb][8] wall-clock stamps of lane 0 (tools/probe_online_mixer.py)
   unsigned spin_limit;         // polls before a member gives up (ONL_SPIN_LIMIT)
   int drop_member;             // (tests) 1: member 0 of cluster 0 leaves before its first arrival: the others must time out, not hang
@@ -91,7 +91,7 @@ __device__ __forceinline__ bool onl_cluster_barrier(unsigned* ctr, unsigned* err
 // (Pointers read from the device table are generic to the compiler; every load through them says "global" -- common.hpp ldg*:
 // as FLAT loads they count on the LDS counter too, and each LDS wait of the row phase waited for the 128 KB of weights: 8 us per block.)
 // mixer.hpp parts_sum2v on slabs other workgroups of this launch stored: 8-byte loads past L1 (sc1) -- requested, then (behind
-// whatever else the caller requests meanwhile) added in the same order: ((((p_0 + p_1) + ...) + p_31) + bias) + residual
+// whatever else the caller requests meanwhile) added in the same order: ((((p_0 + p_1) + ...) + p_15) + bias) + residual
 __device__ __forceinline__ void onl_parts_request(onl_u32x2 (&w)[MLP_PARTS], __amdgpu_buffer_rsrc_t parts, int rows, int r, int col) {
 #pragma unroll
   for (int p = 0; p < MLP_PARTS; ++p) w[p] = __builtin_amdgcn_raw_buffer_load_b64(parts, ((p * rows + r) * kHidden + col) * 4, 0, 16);
@@ -107,7 +107,7 @@ __device__ __forceinline__ float2 onl_parts_finish(const onl_u32x2 (&w)[MLP_PART
 template <typename TA, bool ACQ>
 __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   using Tile = MlpSmallTile<TA>;
-  __shared__ f32x4 s_part[4][8][64];
+  __shared__ f32x4 s_part[4][Tile::NF1][64];
   __shared__ __attribute__((aligned(16))) TA s_hid[32 * Tile::LDH];
   __shared__ __attribute__((aligned(16))) float s_x[2][kHidden];
   __shared__ int s_flag;
@@ -117,8 +117,22 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   const int cl = a.by_xcd ? blockIdx.x % ONL_CLUSTERS : blockIdx.x / ONL_MEMBERS;
   const int k = a.by_xcd ? blockIdx.x / ONL_CLUSTERS : blockIdx.x % ONL_MEMBERS;
   const int m0 = 32 * cl;
-  if (m0 >= a.M) return;                        // the whole cluster has no rows (uniform over its members)
-  if (a.drop_member && cl == 0 && k == 0) return;
+  // The counters are zero at launch because the last workgroup to leave the PREVIOUS launch zeroed them (and the allocation was
+  // zeroed once).  Not a memset node in front of the launch: replayed from a captured hipGraph, hipMemsetAsync of these 576 bytes
+  // filled them with a 16-byte pattern of stale host data every other replay (profiles/r06_graph_memset_hazard.txt), and it
+  // cost a dependent dispatch (~5 us) per launch.  The error word is NOT cleared here: a launch that finds it set leaves at once
+  // (NaN rows) until the host has read it (tapir_online_sync_error reads and clears everything).
+  auto leave = [&]() {
+    if (tid == 0) {
+      unsigned* done = a.sync + 16 * ONL_CLUSTERS + 16;
+      if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        for (int q = 0; q < ONL_CLUSTERS; ++q) __hip_atomic_store(a.sync + 16 * q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (m0 >= a.M) { leave(); return; }           // the whole cluster has no rows (uniform over its members)
+  if (a.drop_member && cl == 0 && k == 0) return;   // (test: never arrives, never leaves)
   const int r = m0 + k;
   const bool has_row = r < a.M;
   unsigned* ctr = a.sync + 16 * cl;
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   // outputs of the two previous frames; zeros without one) -- and the MLP phase's weights: none of them depends on anything this
   // launch computes.  They are requested during the PREVIOUS block's MLP phase, each into registers that phase has just finished
   // with (W_up behind its first product, W_dn and the row operands behind its second), in front of the slab stores: the drain
-  // those stores need anyway covers them, and behind the barrier the 32 partial sums are alone in the wave's load queue (loads
+  // those stores need anyway covers them, and behind the barrier the 16 partial sums are alone in the wave's load queue (loads
   // return in order: requested in front of them, 128 KB of weights cost 7 us per block).
   float w1[2][4][3], b1[2][4], w2[2][4][3], b2[2][4], sc1[2];
   float c1[2][2], g0[2][2][4];      // [frame][channel]([multiplier])
@@ -176,12 +190,16 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
       }
     }
   };
-  const int h0 = k * MLP_HS;
+  const int hg = k % MLP_PARTS, h0 = hg * MLP_HS, col0 = (k / MLP_PARTS) * (512 / MLP_CG);   // (both halves of a hidden group on one XCD)
+  if (a.dbg_times != nullptr && tid == 0) {      // where this workgroup runs: XCC_ID (hwreg 20), HW_ID (hwreg 4)
+    a.dbg_times[((long)blockIdx.x * a.nb) * 8 + 6] = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+    a.dbg_times[((long)blockIdx.x * a.nb) * 8 + 7] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+  }
   OnlineBlockW bw = a.blocks[0];
   float2 x = ldg_f2(a.x_in + (long)rr * kHidden + c0);
   request(0, bw);
   t.load_up(bw.Wup, h0);
-  t.load_dn(bw.Wdn, h0);
+  t.load_dn(bw.Wdn, h0, col0);
   for (int i = 0; i < a.nb && ok; ++i) {
     stamp(i, 0);
     // the next block's table entry (scalar loads): under this block, not in front of the next
@@ -254,26 +272,27 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
     ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag, a.spin_limit);
     if (!ok) break;
     stamp(i, 3);
-    // ---- MLP phase: this member's 64 hidden units over the cluster's 32 rows
+    // ---- MLP phase: this member's unit (128 hidden units, half of the output columns) over the cluster's 32 rows
     if (ACQ) t.load_rows(a.xn, m0, a.M); else t.load_rows_shared(rs_xn, m0, a.M);
     t.phase1(s_part);
     t.load_up(bw_next.Wup, h0);                     // the next block's operands (after the last block: re-read and dropped)
     t.mid(bw.bup, h0, s_part, s_hid);
-    f32x4 acc[8][2];
+    f32x4 acc[Tile::NJ2][2];
     t.phase2(s_hid, acc);
-    t.load_dn(bw_next.Wdn, h0);
+    t.load_dn(bw_next.Wdn, h0, col0);
     request(min(i + 1, a.nb - 1), bw_next);
-    t.template store<true>(acc, a.part, m0, k, a.M, rs_part);
+    t.template store<true>(acc, a.part, m0, hg, col0, a.M, rs_part);
     stamp(i, 4);
     ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag, a.spin_limit);
     stamp(i, 5);
     if (!ok) break;
-    // ---- the next row phase's input (after the last block: the final LayerNorm's): the 32 partial sums
+    // ---- the next row phase's input (after the last block: the final LayerNorm's): the 16 partial sums
     onl_u32x2 pw[MLP_PARTS];
     onl_parts_request(pw, rs_part, a.M, rr, c0);
     x = onl_parts_finish(pw, bw.bdn, xres, c0);
     bw = bw_next;
   }
+  leave();       // (past this workgroup's last poll)
   if (!has_row) return;
   TA* o = reinterpret_cast<TA*>(a.xn) + (long)r * kHidden;
   if (!ok) {     // a member gave up: loud in the data
@@ -304,6 +323,10 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   }
 }
 
+// (A/B: a one-workgroup launch in front of the persistent one)
+__global__ void onl_pre_kernel(unsigned* sync) {
+  if (threadIdx.x < ONL_CLUSTERS) __hip_atomic_store(sync + 16 * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <typename TA>
 inline void launch_mixer_online(const MixerOnlineArgs& a, hipStream_t stream, bool acq = false) {
   if (acq) TAPIR_LAUNCH((mixer_online_kernel<TA, true>), dim3(ONL_CLUSTERS * ONL_MEMBERS), dim3(256), stream, a);

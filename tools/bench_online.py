@@ -36,6 +36,7 @@ def main():
   video = torch.as_tensor(synthetic.make_video(1, 8, S, S)).cuda()
   qp = torch.as_tensor(synthetic.make_queries(2, Q, 1, S, S)).cuda()
   rows = []
+  checked = {}
   configs = (('auto', False),) if args.eager_only else (('auto', False), ('auto', True), ('miopen', True), ('hip', True))
   for conv_mode, use_graph in configs:
     if m._backbone.dtype != torch.bfloat16 and conv_mode == 'hip':
@@ -53,6 +54,15 @@ def main():
     ms = (time.perf_counter() - t0) / args.frames * 1e3
     assert torch.isfinite(out['tracks']).all()
     trk.check()
+    # every frame of a fresh session finite and equal across the configurations of one backbone mode (a replay that skipped work
+    # would be fast and wrong: profiles/r06_graph_memset_hazard.txt)
+    trk.init(video[:, :1], qp)
+    frames = [trk.step(video[:, t % 8:t % 8 + 1])['tracks'].clone() for t in range(12)]
+    trk.check()
+    assert all(bool(torch.isfinite(f).all()) for f in frames)
+    ref = checked.setdefault(conv_mode, frames)
+    worst = max(float((a - b).abs().max()) for a, b in zip(frames, ref))
+    assert worst < 1e-3, worst
     rows.append(dict(mode='hipGraph replay' if use_graph else 'eager launches', backbone_convs=conv_mode, gemm_mode=args.gemm_mode, ms_per_frame=round(ms, 3),
                      frames_per_s=round(1e3 / ms, 1), points_frames_per_s=round(Q * 1e3 / ms, 1)))
     print(json.dumps(dict(workload=f'online TAPIR {S}x{S}, Q={Q}, 4 iters/frame, {dtype}', **rows[-1])), flush=True)

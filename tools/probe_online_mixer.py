@@ -61,6 +61,11 @@ def main():
     s2 = [np.ptp(blk[cl == c, :, 2], axis=0).mean() for c in np.unique(cl)]
     s4 = [np.ptp(blk[cl == c, :, 4], axis=0).mean() for c in np.unique(cl)]
     skew[rep] = np.mean(s2), np.mean(s4)
+    if rep == 0:
+      xcc = tr.cpu().numpy()[:, 0, 6]
+      print('XCC_ID of workgroups 0..31:', xcc[:32].tolist())
+      print('workgroups per XCC:', np.bincount(xcc.astype(np.int64), minlength=8).tolist(),
+            ' blockIdx % 8 == XCC_ID + const for all:', [int(np.all((ids % 8) == ((xcc[ids] + o) % 8))) for o in range(8)])
     total = t[:, -1, 5].max() - t[:, 0, 0].min()
     print(f'rep {rep}: launch {total:7.1f} us  block0 {np.mean(t[:, 0, 5] - t[:, 0, 0]):6.2f}', flush=True)
   names = ['loads -> x staged', 'row arithmetic + row stored', 'barrier 1', 'MLP phase (slab stores issued)', 'barrier 2', 'block']

@@ -158,12 +158,23 @@ if [ "$PART" == "mlp" ]; then
 fi
 if [ "$PART" == "onl" ]; then
   # the persistent mixer of the online model: parity, phase stamps, the online step per form
-  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row" 2>&1 | tail -5 | tee $OUT/pytest_mlp.log
+  timeout 900 python -m pytest tests/test_gpu_bf16_stages.py -q -x -k "few_row or times_out" 2>&1 | tail -5 | tee $OUT/pytest_mlp.log
+  timeout 300 python tools/dbg_online_tmp.py 2>&1 | grep -v amdgpu.ids | grep "True 1[01]\|False 1[01]" | tee $OUT/sync_words.txt
   for f in 0 1; do timeout 300 python tools/probe_online_mixer.py --form $f 2>&1 | grep -v amdgpu.ids | tee $OUT/probe_online_form$f.txt; done
   for rep in 1 2; do
     for gm in 2 3 7; do
       timeout 300 python tools/bench_online.py --frames 120 --gemm-mode $gm 2>/dev/null | grep hipGraph | grep '"auto"' | cut -c1-260 | sed "s/^/gemm_mode $gm /" | tee -a $OUT/ab_mlp_summary.txt
     done
+  done
+fi
+if [ "$PART" == "onltl" ]; then
+  # one online frame launch by launch per persistent-mixer form
+  for gm in 3 7; do
+    cd /tmp
+    timeout 300 rocprofv3 --kernel-trace -d $R/$OUT/prof_online$gm -o online -- python $R/tools/bench_online.py --frames 30 --eager-only --gemm-mode $gm > $R/$OUT/online_under_trace$gm.json 2> $R/$OUT/rocprof_online$gm.err
+    cd $R; for f in $(find $OUT/prof_online$gm -name '*.db'); do python tools/online_timeline.py $f 3 > $OUT/online_timeline_mode$gm.txt 2>&1; done
+    find $OUT/prof_online$gm -name '*.db' -size +20M -delete
+    head -6 $OUT/online_timeline_mode$gm.txt | cut -c1-150
   done
 fi
 if [ "$PART" == "onlinetl" ]; then
