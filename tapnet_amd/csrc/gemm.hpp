@@ -978,6 +978,7 @@ struct MlpSmallTile {
   static constexpr int LDH = MLP_HS + EPC;           // hidden row stride in LDS (+ one chunk: rows 16 lanes apart on different banks)
   static constexpr bool EARLY = sizeof(TA) == 2;     // W_dn's fragments requested with W_up's (f32: too many registers; parity build)
   uint4 fw[K1][NJ1], fa[K1][2], fd[K2][NJ2];
+  f32x4 fb[NF1 / 4];                                 // the up-projection's bias of the fragments this wave finishes
   int wave, c, gq;
   __device__ __forceinline__ void init() {
     const int lane = threadIdx.x & 63;
@@ -1001,6 +1002,11 @@ struct MlpSmallTile {
 #pragma unroll
       for (int j = 0; j < NJ1; ++j)
         fw[ks][j] = ldg16(Wu + (long)(h0 + 16 * j + c) * 512 + 128 * wave + ks * KS + EPC * gq);
+  }
+  // bias of the fragments f = wave, wave + 4, ... (requested with the rows: behind the next block's weights it would wait for them)
+  __device__ __forceinline__ void load_bias(const float* bup, int h0) {
+#pragma unroll
+    for (int n = 0; n < NF1 / 4; ++n) fb[n] = ldg_f4(bup + h0 + 16 * ((4 * n + wave) >> 1) + 4 * gq);
   }
   // the tile's rows over the same k range (rows past M: clamped, computed and never stored)
   __device__ __forceinline__ void load_rows(const void* xn, int m0, int M) {
@@ -1044,9 +1050,9 @@ struct MlpSmallTile {
   }
   // ---- the four partial tiles meet: wave w finishes fragments f = w, w + 4, ... (f = 2 j + i): lane (c, gq) holds hidden units
   // h0 + 16 j + 4 gq + e of row 16 i + c; bias, gelu, rounded to the operand type into the hidden tile
-  __device__ __forceinline__ void mid(const float* bup, int h0, f32x4 (*s_part)[NF1][64], TA* s_hid) {
+  __device__ __forceinline__ void mid(f32x4 (*s_part)[NF1][64], TA* s_hid) {
     const int lane = threadIdx.x & 63;
-    __syncthreads();
+    lds_barrier();   // (LDS only: __syncthreads() would wait for every global load in flight -- the next block's weights)
 #pragma unroll
     for (int f0 = 0; f0 < NF1; f0 += 4) {
       const int f = f0 + wave;
@@ -1056,10 +1062,10 @@ struct MlpSmallTile {
       v = v + s_part[2][f][lane];
       v = v + s_part[3][f][lane];
       const int hl = 16 * j + 4 * gq;
-      v = v + ldg_f4(bup + h0 + hl);
+      v = v + fb[f0 / 4];
       Store4<TA>::run(&s_hid[(16 * i + c) * LDH + hl], gelu_tanh(v[0]), gelu_tanh(v[1]), gelu_tanh(v[2]), gelu_tanh(v[3]));
     }
-    __syncthreads();
+    lds_barrier();
   }
   // ---- phase 2: acc = hid W_dn[col0 + CW wave .. + CW - 1, group]^T (W_dn's registers are free afterwards)
   __device__ __forceinline__ void phase2(const TA* s_hid, f32x4 (&acc)[NJ2][2]) {
@@ -1118,9 +1124,10 @@ __global__ __launch_bounds__(256) void mlp_small_kernel(MlpSmallArgs g) {
   t.load_up(g.Wup, h0);
   if (MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0, col0);
   t.load_rows(g.xn, m0, g.M);
+  t.load_bias(g.bup, h0);
   t.phase1(s_part);
   if (!MlpSmallTile<TA>::EARLY) t.load_dn(g.Wdn, h0, col0);
-  t.mid(g.bup, h0, s_part, s_hid);
+  t.mid(s_part, s_hid);
   f32x4 acc[MlpSmallTile<TA>::NJ2][2];
   t.phase2(s_hid, acc);
   t.store(acc, g.part, m0, hg, col0, g.M);

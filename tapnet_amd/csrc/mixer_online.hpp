@@ -11,7 +11,7 @@
 //   cluster  = 32 workgroups that own 32 rows for the whole launch (8 clusters = 256 rows = 256 workgroups, one per CU;
 //              cluster = blockIdx % 8, member = blockIdx / 8: the dispatcher deals workgroups round-robin over the 8 XCDs
 //              (observed: XCC_ID == blockIdx % 8), so a cluster's exchange and its counter stay on ONE XCD -- an expectation
-//              about speed only (1.66 against 1.80 ms per frame with the members that read the same weight slice on one XCD
+//              about speed only (1.60 against 1.71 ms per frame with the members that read the same weight slice on one XCD
 //              instead); every exchange below is agent-scope correct wherever the members run);
 //   member k = row k of the tile in the row phases (its residual stream lives in registers from the first block to the last),
 //              unit k = (hidden group k % 16 of 128 units, half k / 16 of the output columns) in the MLP phases;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
     if (has_row) {
       // ---- row phase (mix_kernel for T = 1, causal)
       *reinterpret_cast<float2*>(&s_x[0][c0]) = x;
-      __syncthreads();
+      lds_barrier();
       stamp(i, 1);
       float mean, rstd;
       {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
         *reinterpret_cast<float4*>(p2 + kHidden4) = make_float4(g[0][0], g[0][1], g[0][2], g[0][3]);
         *reinterpret_cast<float4*>(p2 + kHidden4 + 4) = make_float4(g[1][0], g[1][1], g[1][2], g[1][3]);
       }
-      __syncthreads();
+      lds_barrier();
       {
         const float4 u = *reinterpret_cast<const float4*>(&s_x[1][lane * 4]);
         const float4 v = *reinterpret_cast<const float4*>(&s_x[1][256 + lane * 4]);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
       // the operand row, write-through: through LDS (the MLP phase's hidden tile is free now) so that one wave stores it 16 bytes per lane
       TA* s_row = s_hid;
       Elem<TA>::st2(s_row + c0, (xres.x - mean) * rstd * s2.x, (xres.y - mean) * rstd * s2.y);
-      __syncthreads();
+      lds_barrier();
       if (tid < (int)(kHidden * sizeof(TA) / 16)) {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(s_row) + 16 * tid);
@@ -274,13 +274,15 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
     stamp(i, 3);
     // ---- MLP phase: this member's unit (128 hidden units, half of the output columns) over the cluster's 32 rows
     if (ACQ) t.load_rows(a.xn, m0, a.M); else t.load_rows_shared(rs_xn, m0, a.M);
+    t.load_bias(bw.bup, h0);
+    request(min(i + 1, a.nb - 1), bw_next);         // the next block's row operands (its registers are free since barrier 1); with the
+                                                    // weights below a wave would have more than the 63 requests in flight vmcnt can count
     t.phase1(s_part);
     t.load_up(bw_next.Wup, h0);                     // the next block's operands (after the last block: re-read and dropped)
-    t.mid(bw.bup, h0, s_part, s_hid);
+    t.mid(s_part, s_hid);
     f32x4 acc[Tile::NJ2][2];
     t.phase2(s_hid, acc);
     t.load_dn(bw_next.Wdn, h0, col0);
-    request(min(i + 1, a.nb - 1), bw_next);
     t.template store<true>(acc, a.part, m0, hg, col0, a.M, rs_part);
     stamp(i, 4);
     ok = onl_cluster_barrier<ACQ>(ctr, err, (arrivals += ONL_MEMBERS), &s_flag, a.spin_limit);
@@ -301,9 +303,9 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   }
   // ---- the final LayerNorm (layernorm_kernel's arithmetic: a lane holds 8 consecutive channels)
   {
-    __syncthreads();
+    lds_barrier();
     *reinterpret_cast<float2*>(&s_x[0][c0]) = x;
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {
       float e[8];
       const float4 u = *reinterpret_cast<const float4*>(&s_x[0][lane * 8]);

@@ -15,7 +15,7 @@ from tapnet_amd import synthetic, tapir_model  # noqa: E402
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--points', type=int, default=256)
-  ap.add_argument('--form', type=int, default=0, help='tapir_debug_set_gemm_mode 3 + 4 x form')
+  ap.add_argument('--form', type=int, default=0, help='tapir_debug_set_gemm_mode 3 + 4 x form (bit 0: a weight slice per XCD instead of a cluster per XCD; bit 1: acquire + plain loads)')
   ap.add_argument('--reps', type=int, default=5)
   args = ap.parse_args()
   N, nb = args.points, 12
@@ -55,7 +55,7 @@ def main():
     seg[rep, 4] = (blk[:, :, 5] - blk[:, :, 4]).mean()       # barrier 2
     seg[rep, 5] = (blk[:, :, 5] - blk[:, :, 0]).mean()
     ncl = t.shape[0] // 32
-    form_by_xcd = args.form & 1
+    form_by_xcd = not (args.form & 1)      # (default placement: cluster = blockIdx % 8)
     ids = np.arange(256)[act]
     cl = ids % 8 if form_by_xcd else ids // 32
     s2 = [np.ptp(blk[cl == c, :, 2], axis=0).mean() for c in np.unique(cl)]
