@@ -444,7 +444,9 @@ int tapir_debug_contraction(tapir_ctx* ctx, const float* qfeat, const float* gri
  * CUs, else 2); 2 = 1, and the channel MLP of a block (up-projection + gelu + down-projection, tapir_model.py:127-156) as ONE
  * launch whose partial outputs the next consumer of the residual stream adds (csrc/gemm.hpp mlp_small_kernel); 1 = one launch
  * of the whole-K small-tile kernel per GEMM; 0 = the split-K kernel + element-wise reduce pair of round 2 (A/B measurements).
- * Modes 1-3 give the same bits (3 = 2 exactly; 1 differs from 2 by the summation order of the down-projection). */
+ * Modes 2 and 3 give the same bits; 1 differs from them by the summation order of the down-projection (same tolerance to the
+ * oracle).  Tests add 4 x form to mode 3 (bit 0: the workgroups that read the same weight slice on one XCD instead of a cluster per
+ * XCD; bit 1: acquire + plain loads instead of sc1 loads; bit 2: one member never arrives -- the timeout path): same bits. */
 int tapir_debug_set_gemm_mode(tapir_ctx* ctx, int mode);
 /* The persistent launch above bounds every wait: a workgroup that waited ~2 s for its cluster (the device could not hold the 256
  * workgroups at once) writes an error word, every member leaves, and the mixer's rows are NaN -- loud in the tracks.  Reads
