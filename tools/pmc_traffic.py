@@ -38,6 +38,10 @@ KERNELS = {
     'cv_rows': ('cv_rows_kernel<unsigned short', ''),
     'l2norm': ('l2norm_kernel<unsigned short', ''),
     'pool_cast': ('pool_cast_kernel<unsigned short', ''),
+    # round 6 (the online frame: tools/r06.sh onlpmc)
+    'mixer_online': ('mixer_online_kernel<unsigned short', ''),
+    'mlp_small': ('mlp_small_kernel<unsigned short', ''),
+    'mix_few_rows': ('mix_kernel<unsigned short', ''),
 }
 
 

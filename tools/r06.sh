@@ -177,6 +177,22 @@ if [ "$PART" == "onltl" ]; then
     head -6 $OUT/online_timeline_mode$gm.txt | cut -c1-150
   done
 fi
+if [ "$PART" == "onlpmc" ]; then
+  # HBM traffic per launch of the online mixer's forms by the counters (separate passes, eager frames)
+  for gm in 3 2; do
+    cd /tmp
+    timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch$gm -o f -- python $R/tools/bench_online.py --frames 6 --eager-only --gemm-mode $gm > /dev/null 2> $R/$OUT/pmc_fetch$gm.err
+    timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/pmc_write$gm -o w -- python $R/tools/bench_online.py --frames 6 --eager-only --gemm-mode $gm > /dev/null 2> $R/$OUT/pmc_write$gm.err
+    cd $R; python tools/pmc_traffic.py $OUT/pmc_fetch$gm $OUT/pmc_write$gm > $OUT/pmc_traffic_online_mode$gm.json 2> $OUT/pmc_traffic$gm.err
+    python - <<PY
+import json
+d=json.load(open('$OUT/pmc_traffic_online_mode$gm.json'))
+for k in ('mixer_online','mlp_small','mix_few_rows'):
+    if k in d.get('kernels', d): print('mode $gm', k, json.dumps(d.get('kernels', d)[k])[:400])
+PY
+    find $OUT/pmc_fetch$gm $OUT/pmc_write$gm -size +8M -delete
+  done
+fi
 if [ "$PART" == "onlinetl" ]; then
   # one online frame launch by launch, with and without the few-frame convolutions
   for m in 1 0; do
