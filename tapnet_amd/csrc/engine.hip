@@ -883,7 +883,6 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
     oa.drop_member = (c->online_form & 4) ? 1 : 0;
     oa.spin_limit = oa.drop_member ? (1u << 14) : ONL_SPIN_LIMIT;
     oa.dbg_times = (long long*)c->dbg_times;
-    if (getenv("TAPIR_ONLINE_PRE")) hipLaunchKernelGGL(onl_pre_kernel, dim3(atoi(getenv("TAPIR_ONLINE_PRE"))), dim3(64), 0, s, oa.sync);
     ProfScope ps(c, TAPIR_PROF_MIX, s);
     if (sizeof(TA) == 2) launch_mixer_online<bf16_t>(oa, s, (c->online_form & 2) != 0);
     else launch_mixer_online<float>(oa, s, (c->online_form & 2) != 0);

@@ -325,10 +325,6 @@ __global__ __launch_bounds__(256) void mixer_online_kernel(MixerOnlineArgs a) {
   }
 }
 
-// (A/B: a one-workgroup launch in front of the persistent one)
-__global__ void onl_pre_kernel(unsigned* sync) {
-  if (threadIdx.x < ONL_CLUSTERS) __hip_atomic_store(sync + 16 * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 template <typename TA>
 inline void launch_mixer_online(const MixerOnlineArgs& a, hipStream_t stream, bool acq = false) {
   if (acq) TAPIR_LAUNCH((mixer_online_kernel<TA, true>), dim3(ONL_CLUSTERS * ONL_MEMBERS), dim3(256), stream, a);
