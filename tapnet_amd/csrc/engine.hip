@@ -112,6 +112,10 @@ struct tapir_ctx {
   DevBuf grid_tiled;                 // bf16 low-res grid in the cost-volume kernel's operand order (pips.hpp: PoolArgs::tiled)
   const float* tiled_src = nullptr;  // which grid it holds (valid together with cast_src[1])
   DevBuf splitk;    // [splits, M, N] f32 partial sums of the few-row GEMMs
+  hipStream_t side = nullptr;       // the weight warm-up of a clip's first refinement iteration runs here, under the cost volume
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool warm_pending = false;        // do_estimate launched that pass: run_mixer joins it instead of launching its own
+  int warm_side = 1;                // (TAPIR_WARM_SIDE=0: on the caller's stream in front of the mixer, as before)
   DevBuf online_sync;               // mixer_online.hpp: cluster counters + error word (zeroed in-stream before every launch)
   OnlineBlockW* online_blocks = nullptr;   // device table of the blocks' parameters
   int pinned = 0;               // tapir_pin_workspaces count: > 0 = growth is an error (hipGraphs hold the pointers)
@@ -779,6 +783,36 @@ inline int warm_stream(tapir_ctx* c, const void* p, size_t bytes, hipStream_t s)
   return TAPIR_OK;
 }
 
+// Which form of the mixer a call takes (run_mixer, and do_estimate's early weight warm-up): the track-resident fused kernel, its
+// wide form, or (both false) separate launches.
+template <typename TA>
+int mixer_form(tapir_ctx* c, int N, int T, bool has_ctx, bool* fused_out, bool* wide_out) {
+  const long R = (long)N * T;
+  const bool causal = c->cfg.use_causal_conv != 0;
+  bool fused = c->fused_stream != nullptr && fused_mixer_supported<TA>(T, c->k0_pad, causal, has_ctx);
+  // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
+  bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
+              fused_wide_supported(T, c->k0_pad, causal, has_ctx);
+  if (c->mixer_mode == 2 && !fused)
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
+  if (c->mixer_mode == 3 && !wide)
+    return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
+  if (c->mixer_mode == 1) fused = wide = false;
+  if (c->mixer_mode == 2) wide = false;
+  if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
+  if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
+  if (c->mixer_mode == 0) {
+    // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
+    // share the weight stream (MFMA-bound instead of L2-fill-bound); below fused_min_tracks (48) the tiled /
+    // few-row GEMMs on all rows are faster than a mostly idle chip
+    if (fused) fused = N >= c->fused_min_tracks && R >= (long)c->fused_min_tracks * 32;
+    if (wide) wide = T > 48 ? N >= 64 : N > 256;
+    if (wide) fused = false;
+  }
+  *fused_out = fused; *wide_out = wide;
+  return TAPIR_OK;
+}
+
 template <typename TA>
 int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx2_in,
               float* ctx1_out, float* ctx2_out, hipStream_t s, const UpdateArgs* upd = nullptr,
@@ -792,30 +826,17 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   // chip is mostly idle and the split-K / tiled GEMMs on all rows are faster)
   {
     const bool has_ctx = ctx1_in || ctx2_in || ctx1_out || ctx2_out;
-    const bool causal = c->cfg.use_causal_conv != 0;
-    bool fused = c->fused_stream != nullptr && fused_mixer_supported<TA>(T, c->k0_pad, causal, has_ctx);
-    // wide form (bf16): two tracks of 17..48 frames per workgroup, or one track of 49..96 frames
-    bool wide = sizeof(TA) == 2 && c->fused_wide_stream != nullptr && T > 16 &&
-                fused_wide_supported(T, c->k0_pad, causal, has_ctx);
-    if (c->mixer_mode == 2 && !fused)
-      return fail(c, TAPIR_ERR_UNSUPPORTED, "fused mixer forced, but it does not cover this shape");
-    if (c->mixer_mode == 3 && !wide)
-      return fail(c, TAPIR_ERR_UNSUPPORTED, "wide fused mixer forced, but it does not cover this shape");
-    if (c->mixer_mode == 1) fused = wide = false;
-    if (c->mixer_mode == 2) wide = false;
-    if (c->mixer_mode == 3 || c->mixer_mode == 4) fused = false;
-    if (c->mixer_mode == 4 && !wide) return fail(c, TAPIR_ERR_UNSUPPORTED, "pair simulation: wide shapes only");
-    if (c->mixer_mode == 0) {
-      // one workgroup per track fills the chip up to 256 tracks; beyond that two tracks per workgroup
-      // share the weight stream (MFMA-bound instead of L2-fill-bound); below fused_min_tracks (48) the tiled /
-      // few-row GEMMs on all rows are faster than a mostly idle chip
-      if (fused) fused = N >= c->fused_min_tracks && R >= (long)c->fused_min_tracks * 32;
-      if (wide) wide = T > 48 ? N >= 64 : N > 256;
-      if (wide) fused = false;
+    bool fused = false, wide = false;
+    TRY(mixer_form<TA>(c, N, T, has_ctx, &fused, &wide));
+    if ((fused || wide) && c->warm_weights && upd != nullptr && upd->first_of_level) {
+      if (c->warm_pending) {       // do_estimate started the pass on the side stream, under the cost volume: join it
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        c->warm_pending = false;
+      } else {
+        TRY(warm_stream(c, wide ? c->fused_wide_stream : c->fused_stream,
+                        (size_t)FM_WAVES * (size_t)(wide ? c->fused_wide_fpw : c->fused_fpw) * 1024, s));
+      }
     }
-    if ((fused || wide) && c->warm_weights && upd != nullptr && upd->first_of_level)
-      TRY(warm_stream(c, wide ? c->fused_wide_stream : c->fused_stream,
-                      (size_t)FM_WAVES * (size_t)(wide ? c->fused_wide_fpw : c->fused_fpw) * 1024, s));
     const bool in_prologue = patch != nullptr && fused && !wide && c->fuse_patch && c->mixer_mode != 4;
     if (patch != nullptr && !in_prologue) launch_patch_args<TA>(c, *patch, s);
     patch = in_prologue ? patch : nullptr;
@@ -1161,6 +1182,24 @@ int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
     hipLaunchKernelGGL(scale_qpts_kernel, dim3((unsigned)((BQ + 255) / 256)), dim3(256), 0, s, ia);
     qinit = (const float*)c->qpts.p;
   }
+  // The first refinement iteration's mixer finds its weight stream cold (the backbone's traffic has pushed it out: 185 us on that
+  // launch); one pass over it (warm_stream_kernel, ~15 us + a dependent dispatch) sat between the cost volume and the first patch
+  // correlation.  It depends on nothing: forked onto a side stream here, it runs under the cost volume and run_mixer joins it.
+  c->warm_pending = false;
+#ifndef TAPIR_HIPEMU
+  if (c->warm_weights && c->warm_side && num_iters > 0 && a->ctx1_in == nullptr && a->ctx2_in == nullptr && a->ctx1_out == nullptr &&
+      a->ctx2_out == nullptr && c->dbg_mixer_stop == 0) {
+    bool fused = false, wide = false;
+    if (c->side != nullptr && mixer_form<TA>(c, (int)BQ, T, false, &fused, &wide) == TAPIR_OK && (fused || wide)) {
+      HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+      HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      TRY(warm_stream(c, wide ? c->fused_wide_stream : c->fused_stream,
+                      (size_t)FM_WAVES * (size_t)(wide ? c->fused_wide_fpw : c->fused_fpw) * 1024, c->side));
+      HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+      c->warm_pending = true;
+    }
+  }
+#endif
   TRY(cost_volume_stage<TA>(c, a->q_lowres[0], a->lowres[0], qinit, B, Q, T, a->lowres_h[0],
                             a->lowres_w[0], pos, occ, expd, s));
   const float vx = (float)a->video_w / (float)iw, vy = (float)a->video_h / (float)ih;
@@ -1182,6 +1221,10 @@ int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
                         a->ctx2_in ? a->ctx2_in + i * s2 : nullptr,
                         a->ctx1_out ? a->ctx1_out + i * s1 : nullptr,
                         a->ctx2_out ? a->ctx2_out + i * s2 : nullptr, s));
+  }
+  if (c->warm_pending) {   // (nobody joined the side stream: a capture must not end with it open)
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    c->warm_pending = false;
   }
   return TAPIR_OK;
 }
@@ -1232,10 +1275,16 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_SMALL_GEMM")) c->small_gemm = std::min(3, std::max(0, atoi(e)));
 #ifndef TAPIR_HIPEMU
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->n_cus = n; }
+  // the side stream of do_estimate's early weight warm-up (created here: never inside somebody's stream capture)
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+    c->side = nullptr;
 #endif
   if (const char* e = getenv("TAPIR_CV_FORM")) c->cv_form = atoi(e);
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_WARM_SIDE")) c->warm_side = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_STREAM_OUT")) c->cv_stream_out = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));
@@ -1254,12 +1303,15 @@ void tapir_destroy(tapir_ctx* c) {
   DevBuf* bufs[] = {&c->cv, &c->mlp_in, &c->xa, &c->xb, &c->xn, &c->hid, &c->res, &c->pos, &c->occ,
                     &c->expd, &c->occ0, &c->expd0, &c->feats, &c->qpts, &c->qf_cast,
                     &c->grid_cast[0], &c->grid_cast[1], &c->grid_cast[2], &c->pooled, &c->splitk,
-                    &c->cyc_pts, &c->cyc_feat, &c->cyc_map, &c->cyc_inv, &c->grid_tiled, &c->warm_sink};
+                    &c->cyc_pts, &c->cyc_feat, &c->cyc_map, &c->cyc_inv, &c->grid_tiled, &c->warm_sink, &c->online_sync};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (int k = 0; k < TAPIR_PROF_KINDS; ++k)
     for (auto& ev : c->prof_ev[k]) c->prof_free.push_back(ev);
   for (auto& ev : c->prof_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 

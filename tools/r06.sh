@@ -193,6 +193,16 @@ PY
     find $OUT/pmc_fetch$gm $OUT/pmc_write$gm -size +8M -delete
   done
 fi
+if [ "$PART" == "warmside" ]; then
+  # the weight warm-up of a clip's first refinement iteration on a side stream under the cost volume vs in front of the mixer
+  timeout 900 python -m pytest tests -m gpu -q -x -k "headline or full_call or hot_path or fuzz or bench_launch" 2>&1 | tail -3 | tee $OUT/pytest_warm.log
+  for rep in 1 2 3; do
+    for v in 0 1; do
+      TAPIR_WARM_SIDE=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-accuracy --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $OUT/ab_warm_${v}_$rep.json
+    done
+  done
+  summ $OUT/ab_warm_*.json | tee $OUT/ab_warm_summary.txt
+fi
 if [ "$PART" == "onlinetl" ]; then
   # one online frame launch by launch, with and without the few-frame convolutions
   for m in 1 0; do
