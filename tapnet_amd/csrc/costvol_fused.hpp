@@ -59,6 +59,11 @@ struct CvFusedArgs {
   int raw;                // 1: no heads -- points = soft arg max of softmax(temperature * cost map) (occ / expd not written);
                           // 2: stop after the contraction (tools: tapir_debug_contraction)
   const int* frame_map;   // null, or [B*T]: unit frame -> index of the grid frame it correlates with
+  // costvol_rows.hpp only, or null: what estimate_trajectories does with the stage's result before the first refinement (engine.hip
+  // iter0_kernel: a launch of its own otherwise) -- the values the later levels reset to, and iteration 0 of the outputs
+  float* occ0; float* expd0;                       // [B*Q*T] copies of occ / expd
+  float* out_tracks; float* out_occ; float* out_expd;   // [B*Q*T, 2] points x (vx, vy) (video pixels), [B*Q*T], [B*Q*T]
+  float vx, vy;
 };
 
 template <typename TA> struct CvFusedCfg;

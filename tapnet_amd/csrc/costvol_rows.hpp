@@ -657,6 +657,9 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : ((QPW == 16 && WAVES 
         float acc = s_head[560 + lane];
         for (int k = 0; k < 16; ++k) acc = fmaf(s_head[528 + lane * 16 + k], vec[32 + k], acc);
         if (lane == 0) a.occ[map] = acc; else a.expd[map] = acc;
+        if (a.out_tracks != nullptr) {      // iter0_kernel's copies
+          if (lane == 0) { a.occ0[map] = acc; a.out_occ[map] = acc; } else { a.expd0[map] = acc; a.out_expd[map] = acc; }
+        }
       }
     }
     if (lane == 0) {
@@ -672,6 +675,10 @@ __global__ __launch_bounds__(WAVES * 64, PW > CVR_PW ? 1 : ((QPW == 16 && WAVES 
       }
       a.points[map * 2 + 0] = outx;
       a.points[map * 2 + 1] = outy;
+      if (a.out_tracks != nullptr) {
+        a.out_tracks[map * 2 + 0] = outx * a.vx;
+        a.out_tracks[map * 2 + 1] = outy * a.vy;
+      }
     }
     wave_sync();   // vec is reused by the next map
     tick(3);

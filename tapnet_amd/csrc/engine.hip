@@ -115,6 +115,7 @@ struct tapir_ctx {
   hipStream_t side = nullptr;       // the weight warm-up of a clip's first refinement iteration runs here, under the cost volume
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool warm_pending = false;        // do_estimate launched that pass: run_mixer joins it instead of launching its own
+  int fuse_iter0 = 1;               // (TAPIR_FUSE_ITER0=0: iter0_kernel as its own launch behind the cost volume, as before)
   int warm_side = 1;                // (TAPIR_WARM_SIDE=0: on the caller's stream in front of the mixer, as before)
   DevBuf online_sync;               // mixer_online.hpp: cluster counters + error word (zeroed in-stream before every launch)
   OnlineBlockW* online_blocks = nullptr;   // device table of the blocks' parameters
@@ -542,7 +543,8 @@ int launch_cv_heads(tapir_ctx* c, const float* cv, const float* qpts_init, long 
 template <typename TA>
 int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const float* qpts_init,
                       int B, int Q, int T, int h, int w, float* points, float* occ, float* expd,
-                      hipStream_t s, bool tapnet = false) {
+                      hipStream_t s, bool tapnet = false, const Iter0Args* i0 = nullptr, bool* i0_done = nullptr) {
+  // i0 != null: the caller's iter0_kernel arguments; the row-streamed kernel writes those copies itself (*i0_done = true)
   const int C = kLowresDim, hw = h * w;
   const void* qf_op = qfeat;
   const void* grid_op = grid;
@@ -580,6 +582,11 @@ int cost_volume_stage(tapir_ctx* c, const float* qfeat, const float* grid, const
     ProfScope ps(c, TAPIR_PROF_CV_HEADS, s);
     // row-streamed form (every wave owns whole maps, costvol_rows.hpp) for rows of up to 32 cells; the
     // pixel-tiled form (costvol_fused.hpp) for the other shapes it covers, and on request (cv_mode 2, A/B)
+    if (rows && i0 != nullptr && i0_done != nullptr && !tapnet && c->fuse_iter0) {
+      fa.occ0 = i0->occ0; fa.expd0 = i0->expd0; fa.out_tracks = i0->out_tracks; fa.out_occ = i0->out_occ; fa.out_expd = i0->out_expd;
+      fa.vx = i0->vx; fa.vy = i0->vy;
+      *i0_done = true;
+    }
     if (rows) launch_cv_rows<TA>(fa, s, tapnet ? c->tapnet_heads : 1, c->cv_form);
     else launch_cv_fused<TA>(fa, s, tapnet ? c->tapnet_heads : 1);
     return TAPIR_OK;
@@ -1200,11 +1207,12 @@ int do_estimate(tapir_ctx* c, const tapir_traj_args* a, hipStream_t s) {
     }
   }
 #endif
-  TRY(cost_volume_stage<TA>(c, a->q_lowres[0], a->lowres[0], qinit, B, Q, T, a->lowres_h[0],
-                            a->lowres_w[0], pos, occ, expd, s));
   const float vx = (float)a->video_w / (float)iw, vy = (float)a->video_h / (float)ih;
   Iter0Args i0{pos, occ, expd, occ0, expd0, a->tracks, a->occlusion, a->expected_dist, R, vx, vy};
-  hipLaunchKernelGGL(iter0_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, i0);
+  bool i0_done = false;   // (the row-streamed cost-volume kernel writes iter0's copies itself: one dependent launch less)
+  TRY(cost_volume_stage<TA>(c, a->q_lowres[0], a->lowres[0], qinit, B, Q, T, a->lowres_h[0],
+                            a->lowres_w[0], pos, occ, expd, s, false, &i0, &i0_done));
+  if (!i0_done) hipLaunchKernelGGL(iter0_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, i0);
 
   for (int i = 0; i < num_iters; ++i) {
     const int lvl = i / P + 1;
@@ -1285,6 +1293,7 @@ int tapir_create(tapir_ctx** out, const tapir_cfg* cfg, int device) {
   if (const char* e = getenv("TAPIR_FUSE_PATCH")) c->fuse_patch = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_WEIGHTS")) c->warm_weights = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_WARM_SIDE")) c->warm_side = atoi(e) != 0;
+  if (const char* e = getenv("TAPIR_FUSE_ITER0")) c->fuse_iter0 = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_TILED")) c->cv_tiled = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_CV_STREAM_OUT")) c->cv_stream_out = atoi(e) != 0;
   if (const char* e = getenv("TAPIR_FUSED_MIN_TRACKS")) c->fused_min_tracks = std::max(1, atoi(e));

@@ -203,6 +203,16 @@ if [ "$PART" == "warmside" ]; then
   done
   summ $OUT/ab_warm_*.json | tee $OUT/ab_warm_summary.txt
 fi
+if [ "$PART" == "iter0" ]; then
+  # iter0's copies written by the cost-volume kernel vs as a launch of their own
+  timeout 1200 python -m pytest tests -m gpu -q -x -k "headline or full_call or hot_path or fuzz or cost_volume or golden or bench_launch" 2>&1 | tail -3 | tee $OUT/pytest_iter0.log
+  for rep in 1 2 3; do
+    for v in 0 1; do
+      TAPIR_FUSE_ITER0=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-accuracy --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $OUT/ab_iter0_${v}_$rep.json
+    done
+  done
+  summ $OUT/ab_iter0_*.json | tee $OUT/ab_iter0_summary.txt
+fi
 if [ "$PART" == "onlinetl" ]; then
   # one online frame launch by launch, with and without the few-frame convolutions
   for m in 1 0; do
