@@ -962,6 +962,15 @@ int run_mixer(tapir_ctx* c, int N, int T, const float* ctx1_in, const float* ctx
   GemmArgs g{};
   g.A = c->xn.p; g.lda = kHidden; g.W = c->Wout; g.ldw = kHidden; g.bias = c->bout;
   g.C = c->res.p; g.ldc = kMixOut; g.M = (int)R; g.N = kMixOut; g.K = kHidden;
+  // few rows inside refine_pips: the output Linear applies the state update itself (gemm.hpp EPI_BIAS_UPDATE: update_kernel's
+  // operations in its order; the [R, 388] output never exists) -- one dependent launch less per refinement iteration
+  if (upd != nullptr && upd_done != nullptr && c->fuse_update && c->small_gemm && gemm_small_supported<TA>(g.M, g.N, g.K) &&
+      c->dbg_mixer_stop == 0) {
+    g.upd = *upd;
+    launch_gemm_small<TA, float, EPI_BIAS_UPDATE>(g, s);
+    *upd_done = true;
+    return TAPIR_OK;
+  }
   TRY((mixer_gemm<TA, float, EPI_BIAS>(c, g, s)));
   return TAPIR_OK;
 }

@@ -43,13 +43,34 @@
 
 namespace tapir {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
+// Applies one mixer output to the running estimate (tapir_model.py:613-623,
+// 1026-1039):  pos += d_xy * (orig/resized), occ += d, expd += d, feats += d.
+struct UpdateArgs {
+  const float* res;        // [R, 388]
+  float* pos;              // [R, 2]  (x, y) in initial_resolution pixels
+  float* occ; float* expd; // [R]
+  float* feats;            // [R, 384] in/out
+  const float* q_hires;    // [B*Q, 128] used when first_of_level
+  const float* q_lowres;   // [B*Q, 256]
+  float* out_tracks;       // [R, 2] this iteration's slice, video pixels
+  float* out_occ; float* out_expd;
+  const float* occ0; const float* expd0;   // cost-volume values (reset after a level)
+  long R; int T;
+  float sx, sy;            // orig / resized  (x, y)
+  float vx, vy;            // video / initial_resolution (train2orig)
+  int first_of_level;      // feats input was the tiled query feature
+  int last_of_level;       // reset occ/expd to the cost-volume values afterwards
+};
+// EPI_BIAS_UPDATE (gemm_small_kernel only): the [M, 388] output of the mixer's last Linear is not stored; it is applied to the
+// running estimate as update_kernel (mixer.hpp) would: the same operations in the same order
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_BIAS_UPDATE = 3 };
 
 struct GemmArgs {
   const void* A; long lda;                 // strides in elements
   const void* W; long ldw;
   const float* bias;                       // [N] or null
   const float* resid; long ldr;            // EPI_BIAS_RESID: [M, ldr] f32
+  UpdateArgs upd;                          // EPI_BIAS_UPDATE
   void* C; long ldc;
   int M, N, K;                             // K multiple of (128 / sizeof(T)); N, ldc multiples of 4
   int w_rows;                              // 0, or the rows W really has (< N: N is rounded up to a multiple of 4 for the
@@ -905,7 +926,34 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
       if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
       if (EPI == EPI_BIAS_GELU) { v[0] = gelu_tanh(v[0]); v[1] = gelu_tanh(v[1]); v[2] = gelu_tanh(v[2]); v[3] = gelu_tanh(v[3]); }
       if (EPI == EPI_BIAS_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
-      Store4<TO>::run(reinterpret_cast<TO*>(g.C) + (long)m * g.ldc + n, v[0], v[1], v[2], v[3]);
+      if (EPI == EPI_BIAS_UPDATE) {
+        // update_kernel on row r = m of the (never stored) [M, 388] output: columns 0..3 move the state, 4.. the features
+        const UpdateArgs& a = g.upd;
+        const long r = m;
+        if (n == 0) {
+          const float px = a.pos[r * 2 + 0] + v[0] * a.sx;
+          const float py = a.pos[r * 2 + 1] + v[1] * a.sy;
+          const float oc = a.occ[r] + v[2];
+          const float ex = a.expd[r] + v[3];
+          a.pos[r * 2 + 0] = px; a.pos[r * 2 + 1] = py;
+          a.out_tracks[r * 2 + 0] = px * a.vx; a.out_tracks[r * 2 + 1] = py * a.vy;
+          a.out_occ[r] = oc; a.out_expd[r] = ex;
+          a.occ[r] = a.last_of_level ? a.occ0[r] : oc;
+          a.expd[r] = a.last_of_level ? a.expd0[r] : ex;
+        } else {
+          const int c0 = n - 4;                      // (a multiple of 4: never across the hires | lowres boundary at 128)
+          const long bq = r / a.T;
+          f32x4 prev;
+          if (a.first_of_level)
+            prev = c0 < kHiresDim ? *reinterpret_cast<const f32x4*>(a.q_hires + bq * kHiresDim + c0)
+                                  : *reinterpret_cast<const f32x4*>(a.q_lowres + bq * kLowresDim + (c0 - kHiresDim));
+          else
+            prev = *reinterpret_cast<const f32x4*>(a.feats + r * kFeatDim + c0);
+          *reinterpret_cast<f32x4*>(a.feats + r * kFeatDim + c0) = v + prev;
+        }
+      } else {
+        Store4<TO>::run(reinterpret_cast<TO*>(g.C) + (long)m * g.ldc + n, v[0], v[1], v[2], v[3]);
+      }
     }
   }
 }

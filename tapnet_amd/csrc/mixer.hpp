@@ -596,24 +596,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   for (int i = 0; i < 8; ++i) Elem<TO>::st(o + i, e[i] * rs * a.scale[lane * 8 + i]);
 }
 
-// Applies one mixer output to the running estimate (tapir_model.py:613-623,
-// 1026-1039):  pos += d_xy * (orig/resized), occ += d, expd += d, feats += d.
-struct UpdateArgs {
-  const float* res;        // [R, 388]
-  float* pos;              // [R, 2]  (x, y) in initial_resolution pixels
-  float* occ; float* expd; // [R]
-  float* feats;            // [R, 384] in/out
-  const float* q_hires;    // [B*Q, 128] used when first_of_level
-  const float* q_lowres;   // [B*Q, 256]
-  float* out_tracks;       // [R, 2] this iteration's slice, video pixels
-  float* out_occ; float* out_expd;
-  const float* occ0; const float* expd0;   // cost-volume values (reset after a level)
-  long R; int T;
-  float sx, sy;            // orig / resized  (x, y)
-  float vx, vy;            // video / initial_resolution (train2orig)
-  int first_of_level;      // feats input was the tiled query feature
-  int last_of_level;       // reset occ/expd to the cost-volume values afterwards
-};
+// (UpdateArgs: gemm.hpp -- the few-row output Linear applies the update in its epilogue)
 __global__ __launch_bounds__(128) void update_kernel(UpdateArgs a) {
   const long r = blockIdx.x;
   const int tid = threadIdx.x;

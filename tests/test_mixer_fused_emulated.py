@@ -96,11 +96,13 @@ def test_wide_fused_mixer_needs_bf16():
   e.close()
 
 
-@pytest.mark.parametrize('mode,dtype,T,Q', [(2, _ffi.TAPIR_F32, 20, 3), (2, _ffi.TAPIR_BF16, 33, 2), (3, _ffi.TAPIR_BF16, 40, 3)])
+@pytest.mark.parametrize('mode,dtype,T,Q', [(2, _ffi.TAPIR_F32, 20, 3), (2, _ffi.TAPIR_BF16, 33, 2), (3, _ffi.TAPIR_BF16, 40, 3),
+                                             (1, _ffi.TAPIR_F32, 9, 5), (1, _ffi.TAPIR_BF16, 11, 40)])
 def test_fused_state_update_is_bit_identical(mode, dtype, T, Q):
   """refine_pips's state update (tapir_model.py:613-623, 1026-1039: pos / occ / expd / feats, the per-iteration
   output slices, the reset after a level) applied by the output stage of the track-resident mixer kernels
-  (fused_emit) against the separate update_kernel on the mixer's [R,388] output: the same operations in the same
+  (fused_emit) -- and, for few rows on the separate-launch path (mode 1), by the epilogue of the output Linear (gemm.hpp
+  EPI_BIAS_UPDATE) -- against the separate update_kernel on the mixer's [R,388] output: the same operations in the same
   order, so every output of estimate_trajectories -- two refinement levels, first / later iterations -- is
   bit-identical; and (f32) equal to the oracle."""
   w = synthetic.make_weights(4, 1, False, num_mixer_blocks=2, backbone=False)
