@@ -1,6 +1,7 @@
 """Where one online (causal, per-frame) step goes, launch by launch: from a rocprofv3 --kernel-trace rocpd database of
 `tools/bench_online.py --eager-only` (or of the hipGraph replay), one steady-state frame = the dispatches between two
-consecutive `iter0_kernel` launches (one per estimate_trajectories call).  Prints per kernel class: launches, busy time,
+consecutive `stem_conv_kernel` launches (one per frame's backbone; `iter0_kernel`, the marker of rounds 5-6, no longer exists in
+the frame: its copies are written by the cost-volume kernel).  Prints per kernel class: launches, busy time,
 and the idle time in FRONT of its launches (device idle: no kernel of the frame running), then the frame's totals.
 
     python tools/online_timeline.py gpurun_out/xxx/prof/online_results.db [frame index from the end, default 3]
@@ -25,6 +26,8 @@ def short(n):
 
 
 marks = [i for i, r in enumerate(rows) if 'iter0_kernel' in r[0]]
+if len(marks) < 3:
+  marks = [i for i, r in enumerate(rows) if 'stem_conv_kernel' in r[0]]
 if len(marks) < back + 2:
   sys.exit('not enough frames in the trace')
 a, b = marks[-back - 1], marks[-back]
@@ -53,7 +56,7 @@ for s, e in ev[1:]:
     ce = max(ce, e)
 covered += ce - cs
 idle_total += max(0, t1 - cur_end)
-print(f'frame: {len(sel)} dispatches, {(t1 - t0) / 1e3:.1f} us from this frame\'s iter0 launch to the next frame\'s; '
+print(f'frame: {len(sel)} dispatches, {(t1 - t0) / 1e3:.1f} us from this frame\'s first launch to the next frame\'s; '
       f'device busy {covered / 1e3:.1f} us, idle {idle_total / 1e3:.1f} us ({100.0 * idle_total / (t1 - t0):.0f} %)')
 print(f'{"kernel":72s} {"n":>4s} {"busy us":>9s} {"avg us":>8s} {"idle before, us":>16s}')
 for k, (n, busy, gap) in sorted(per.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
