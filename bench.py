@@ -54,6 +54,8 @@ def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--prof-stride', type=int, default=5,
+                  help='inside the timed region every n-th launch of the dominant kernel class carries timing events (1 = every launch)')
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--model', default='tapir', choices=list(MODELS))
@@ -696,6 +698,10 @@ def main():
   probe = model.profile_read()
   dom = max(probe, key=lambda k: probe[k][0])   # kernel class with the largest share of a step
   model.profile_enable([dom])
+  # ... and of that class only every 5th launch (co-prime to the four refinement launches of a clip: every position is sampled):
+  # a timed launch is dispatched with start / stop signals and leaves ~12 us of idle device on either side of it -- all eight
+  # sides of a step's four mixer launches cost 2 % of the step (profiles/r06_ab_prof_stride.txt)
+  model.profile_stride(args.prof_stride)
   model.profile_read()
   t0 = time.perf_counter()
   for _ in range(args.steps):
@@ -703,6 +709,7 @@ def main():
   barrier()
   elapsed = time.perf_counter() - t0
   prof = model.profile_read()
+  model.profile_stride(1)
   model.profile_enable(True)
   for _ in range(2):
     step()
@@ -848,7 +855,9 @@ def main():
                 frac=round(ach / peak, 4) if ach else None, traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes=alg_bytes,
                 launches=d_n, avg_us=round(d_ms / d_n * 1e3, 2) if d_n else None,
-                flops_per_launch=flops, share_of_step=round(d_ms / args.steps / ms_per_step, 3))
+                flops_per_launch=flops, share_of_step=round(d_ms * args.prof_stride / args.steps / ms_per_step, 3),
+                launch_sampling=f'every {args.prof_stride}th launch of the class inside the timed region carries timing events '
+                                f'(`launches` = the sampled ones; a timed launch costs ~12 us of idle device on either side of it)')
     kernels = {k: dict(total_ms=round(v[0], 3), launches=v[1],
                        avg_us=round(v[0] / v[1] * 1e3, 2) if v[1] else None)
                for k, v in prof.items()}

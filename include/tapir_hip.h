@@ -219,6 +219,10 @@ int tapir_estimate_trajectories(tapir_ctx* ctx, const tapir_traj_args* args, voi
 /* on: bit mask of kernel classes (1 << TAPIR_PROF_*) to bracket with events; -1 = all, 0 = off. */
 int tapir_profile_enable(tapir_ctx* ctx, int on);
 int tapir_profile_read(tapir_ctx* ctx, int kind, double* total_ms, int64_t* launches);
+/* Times only every stride-th launch of an enabled class (default 1 = every launch; resets the launch counters).  A timed launch is
+ * dispatched with start / stop signals and costs ~12 us of idle device on either side of it: bench.py samples the dominant class
+ * with a stride co-prime to the four refinement launches of a clip inside its timed region (averages per launch, not totals). */
+int tapir_profile_stride(tapir_ctx* ctx, int stride);
 
 /* Feature backbone, the memory-bound half (TAPIR.get_feature_grids, tapir_model.py:626-729; ResNet
  * blocks, tapnet/models/resnet.py:152-257).  Every convolution of the ResNet (stem, 3x3, strided, 1x1)

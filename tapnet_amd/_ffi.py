@@ -140,6 +140,7 @@ PROTOTYPES = {
     'tapir_debug_mix': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p]),
     'tapir_profile_enable': (c_int, [c_void_p, c_int]),
+    'tapir_profile_stride': (c_int, [c_void_p, c_int]),
     'tapir_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 

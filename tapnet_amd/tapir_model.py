@@ -286,6 +286,11 @@ class TAPIR:
         mask |= 1 << _ffi.PROF_KINDS[name]
     self._check(self._lib.tapir_profile_enable(self._ctx, mask), 'tapir_profile_enable')
 
+  def profile_stride(self, stride: int = 1) -> None:
+    """Only every stride-th launch of an enabled class carries events (a timed launch costs ~12 us of idle device on either
+    side of it); profile_read() then returns the sum and the count of the SAMPLED launches."""
+    self._check(self._lib.tapir_profile_stride(self._ctx, int(stride)), 'tapir_profile_stride')
+
   def profile_read(self) -> Dict[str, Tuple[float, int]]:
     """{kernel class: (summed ms, launches)} since the last read; synchronises on the events."""
     out = {}
